@@ -1,0 +1,33 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.  Internal view of a parsed circuit blob (format: include/r0hip_circuit.h). */
+#ifndef ORC_CIRCUIT_H
+#define ORC_CIRCUIT_H
+#include "orc.h"
+#include "orc_field.h"
+
+typedef struct { uint32_t group, offset, back; } orc_tap_t;
+typedef struct { uint32_t group, offset, first_tap, size, combo; } orc_reg_t;
+typedef struct { uint32_t op, a, b, c; } orc_step_t;
+typedef struct { uint32_t kind, param; } orc_code_col_t;
+typedef struct { uint32_t kind, a, b, c, e; } orc_data_col_t;
+typedef struct { uint32_t first, a, b; } orc_acc_col_t;
+
+struct orc_circuit {
+  uint32_t group_size[3];
+  uint32_t n_taps; orc_tap_t* taps;
+  uint32_t n_regs; orc_reg_t* regs;
+  uint32_t n_combos; uint32_t* combo_begin; uint32_t* combo_backs; /* combo_begin has n_combos+1 entries */
+  uint32_t group_tap_begin[4];
+  uint32_t n_global, n_mix; uint32_t* global_cols; /* global k = DATA column global_cols[k] at row 0 */
+  uint32_t n_steps, ret; orc_step_t* steps;
+  uint32_t n_fp_vars, n_mix_vars;
+  uint32_t n_code; orc_code_col_t* code_cols;
+  uint32_t n_data; orc_data_col_t* data_cols;
+  uint32_t n_acc; orc_acc_col_t* acc_cols;
+};
+
+/* poly_ext opcodes (risc0-zkp adapter.rs `PolyExtStep`) */
+enum { OP_CONST = 0, OP_GET = 2, OP_GET_GLOBAL = 3, OP_ADD = 4, OP_SUB = 5, OP_MUL = 6, OP_TRUE = 7, OP_AND_EQZ = 8, OP_AND_COND = 9 };
+#define REF_GROUP(r) ((r) >> 28)
+#define REF_BACK(r) (((r) >> 20) & 0xffu)
+#define REF_COL(r) ((r) & 0xfffffu)
+#endif

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Synthetic circuit blobs for the segment prover (format: include/r0hip_circuit.h).
+
+The reference's real circuit (risc0-circuit-rv32im 4.0.4: tap table + generated constraint polynomial) is an
+un-vendored, machine-generated artefact that cannot be reproduced here (hard part 2).  The prover takes
+the circuit as DATA, so this tool emits circuits of the same *shape* -- three tap groups (ACCUM/CODE/DATA), registers
+with back-offsets, a `PolyExtStep` program (Const/Get/GetGlobal/Add/Sub/Mul/True/AndEqz/AndCond), grand-product
+accumulators gated by a first-row selector -- together with a column program from which a satisfying witness can be
+generated, so that proofs of it verify.
+
+Shapes:
+  tiny   W=(8 accum, 4 code, 12 data)      unit tests (CPU oracle in milliseconds)
+  small  W=(16, 8, 40)                      GPU parity tests
+  bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
+"""
+import argparse
+import struct
+import sys
+
+P = 15 * 2**27 + 1
+MAGIC = 0x31433052
+SEC_GROUPS, SEC_TAPS, SEC_GLOBALS, SEC_POLY, SEC_WITGEN, SEC_ACCUM = 1, 2, 3, 4, 5, 6
+G_ACCUM, G_CODE, G_DATA = 0, 1, 2
+OP_CONST, OP_GET, OP_GET_GLOBAL, OP_ADD, OP_SUB, OP_MUL, OP_TRUE, OP_AND_EQZ, OP_AND_COND = 0, 2, 3, 4, 5, 6, 7, 8, 9
+BETA = 11
+
+
+class Rng:
+    def __init__(self, seed):
+        self.s = seed & (2**64 - 1)
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        x = self.s
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return x ^ (x >> 31)
+
+    def below(self, n):
+        return self.next() % n
+
+    def pick(self, seq):
+        return seq[self.below(len(seq))]
+
+
+def ref(group, col, back):
+    return (group << 28) | (back << 20) | col
+
+
+class Builder:
+    """Collects taps symbolically; fp/mix variables are numbered in creation order (as risc0's PolyExtStepDef)."""
+
+    def __init__(self):
+        self.steps = []  # (op, a, b, c) with a = ('tap', g, col, back) for GET until finalised
+        self.n_fp = 0
+        self.n_mix = 0
+        self.taps = set()
+        self.memo = {}
+        self.n_mul = 0
+        self.n_add = 0
+
+    def _fp(self, op, a=0, b=0, c=0):
+        self.steps.append((op, a, b, c))
+        self.n_fp += 1
+        return self.n_fp - 1
+
+    def _mix(self, op, a=0, b=0, c=0):
+        self.steps.append((op, a, b, c))
+        self.n_mix += 1
+        return self.n_mix - 1
+
+    def const(self, v):
+        key = ("c", v % P)
+        if key not in self.memo:
+            self.memo[key] = self._fp(OP_CONST, v % P)
+        return self.memo[key]
+
+    def get(self, g, col, back):
+        key = ("t", g, col, back)
+        if key not in self.memo:
+            self.taps.add((g, col, back))
+            self.memo[key] = self._fp(OP_GET, key)
+        return self.memo[key]
+
+    def glob(self, base, off):
+        key = ("g", base, off)
+        if key not in self.memo:
+            self.memo[key] = self._fp(OP_GET_GLOBAL, base, off)
+        return self.memo[key]
+
+    def add(self, a, b):
+        self.n_add += 1
+        return self._fp(OP_ADD, a, b)
+
+    def sub(self, a, b):
+        self.n_add += 1
+        return self._fp(OP_SUB, a, b)
+
+    def mul(self, a, b):
+        self.n_mul += 1
+        return self._fp(OP_MUL, a, b)
+
+    def true(self):
+        return self._mix(OP_TRUE)
+
+    def and_eqz(self, x, v):
+        self.n_mul += 4
+        self.n_add += 4
+        return self._mix(OP_AND_EQZ, x, v)
+
+    def and_cond(self, x, cond, inner):
+        self.n_mul += 20
+        self.n_add += 16
+        return self._mix(OP_AND_COND, x, cond, inner)
+
+
+def fp4_mul_sym(b, x, y):
+    """Schoolbook Fp4 product of two 4-lists of fp vars, x^4 = 11."""
+    c = [None] * 7
+    for i in range(4):
+        for j in range(4):
+            t = b.mul(x[i], y[j])
+            c[i + j] = t if c[i + j] is None else b.add(c[i + j], t)
+    beta = b.const(BETA)
+    return [b.add(c[0], b.mul(beta, c[4])), b.add(c[1], b.mul(beta, c[5])), b.add(c[2], b.mul(beta, c[6])), c[3]]
+
+
+def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5):
+    rng = Rng(seed)
+    assert n_code >= 4 and n_free >= max(2, n_global) and n_data > n_free
+    code_cols = [(0, 0), (1, 0), (2, 0)] + [(3, k) for k in range(3, n_code)]
+    data_cols = []
+    for k in range(n_data):
+        if k < n_free:
+            data_cols.append((0, 0, 0, 0, 0))
+            continue
+
+        def pick_ref():
+            if rng.below(100) < 85:
+                return ref(G_DATA, rng.below(k), rng.pick([0, 0, 0, 1, 1, 2]))
+            return ref(G_CODE, rng.below(n_code), rng.pick([0, 0, 1]))
+
+        kind = 2 if rng.below(3) == 0 else 1
+        data_cols.append((kind, pick_ref(), pick_ref(), pick_ref() if kind == 2 else 0, pick_ref()))
+    acc_cols = [(0, rng.below(n_data), rng.below(n_data)) for _ in range(n_acc)]
+    global_cols = list(range(n_global))
+
+    b = Builder()
+    for g, size in ((G_ACCUM, 4 * n_acc), (G_CODE, n_code), (G_DATA, n_data)):
+        for col in range(size):
+            b.taps.add((g, col, 0))
+
+    def rget(r):
+        return b.get(r >> 28, r & 0xFFFFF, (r >> 20) & 0xFF)
+
+    one = b.const(1)
+    first = b.get(G_CODE, 0, 0)
+    defects = []  # (fp var of (column - definition), degree): zero on every trace row
+    for k in range(n_free, n_data):
+        kind, ra, rb, rc, re = data_cols[k]
+        prod = b.mul(rget(ra), rget(rb))
+        if kind == 2:
+            prod = b.mul(prod, rget(rc))
+        defects.append((b.sub(b.get(G_DATA, k, 0), b.add(prod, rget(re))), kind + 1))
+    glob_defects = [(b.mul(first, b.sub(b.get(G_DATA, global_cols[k], 0), b.glob(0, k))), 2) for k in range(n_global)]
+    acc_defects = []
+    not_first = b.sub(one, first)
+    for j, (_, ca, cb) in enumerate(acc_cols):
+        a, bb = b.get(G_DATA, ca, 0), b.get(G_DATA, cb, 0)
+        m0 = [b.glob(1, 8 * j + i) for i in range(4)]
+        m1 = [b.glob(1, 8 * j + 4 + i) for i in range(4)]
+        term = [b.add(m0[i], b.mul(m1[i], bb)) for i in range(4)]
+        term[0] = b.add(term[0], a)
+        prev = [b.get(G_ACCUM, 4 * j + i, 1) for i in range(4)]
+        sel = [b.mul(not_first, prev[i]) for i in range(4)]
+        sel[0] = b.add(sel[0], first)
+        want = fp4_mul_sym(b, term, sel)
+        acc_defects.extend((b.sub(b.get(G_ACCUM, 4 * j + i, 0), want[i]), 3) for i in range(4))
+
+    pad = []
+    tap_pool = sorted(b.taps)
+    for _ in range(n_pad):
+        d, deg = rng.pick(defects)
+        t = [b.get(*rng.pick(tap_pool)) for _ in range(7)]
+        g = b.add(b.add(b.add(b.add(b.mul(t[0], t[1]), b.mul(t[2], t[3])), t[4]), t[5]), t[6])
+        pad.append((b.mul(d, g), deg + 2))
+
+    all_vals = defects + glob_defects + acc_defects + pad
+    assert max(deg for _, deg in all_vals) <= 5  # check = C / (x^N - 1) must stay below degree 4N
+    # constraint chain; every cond_every-th run of 8 constraints sits inside an AndCond gated by a CODE column.
+    # The gate costs one degree, so only runs of degree <= 4 may be gated.
+    x = b.true()
+    i, run = 0, 0
+    while i < len(all_vals):
+        chunk = all_vals[i:i + 8]
+        i += 8
+        run += 1
+        if cond_every and run % cond_every == 0 and max(deg for _, deg in chunk) <= 4:
+            inner = b.true()
+            for v, _ in chunk:
+                inner = b.and_eqz(inner, v)
+            x = b.and_cond(x, b.get(G_CODE, 3 + rng.below(n_code - 3), 0), inner)
+        else:
+            for v, _ in chunk:
+                x = b.and_eqz(x, v)
+    ret = x
+
+    taps = sorted(b.taps)
+    tap_index = {t: i for i, t in enumerate(taps)}
+    steps = []
+    for op, a, bb, c in b.steps:
+        if op == OP_GET:
+            a = tap_index[(a[1], a[2], a[3])]
+        steps.append((op, a, bb, c))
+
+    def section(tag, words):
+        return [tag, len(words)] + list(words)
+
+    words = [MAGIC, 1, 6]
+    words += section(SEC_GROUPS, [4 * n_acc, n_code, n_data])
+    words += section(SEC_TAPS, [len(taps)] + [w for t in taps for w in t])
+    words += section(SEC_GLOBALS, [n_global, 8 * n_acc] + global_cols)
+    words += section(SEC_POLY, [len(steps), ret] + [w for s in steps for w in s])
+    words += section(SEC_WITGEN, [n_code] + [w for cc in code_cols for w in cc] + [n_data] + [w for d in data_cols for w in d])
+    words += section(SEC_ACCUM, [n_acc] + [w for a in acc_cols for w in a])
+    info = {"taps": len(taps), "steps": len(steps), "constraints": len(all_vals), "mul_per_point": b.n_mul,
+            "addsub_per_point": b.n_add, "groups": [4 * n_acc, n_code, n_data]}
+    return words, info
+
+
+SHAPES = {
+    "tiny": dict(n_code=4, n_data=12, n_acc=2, n_free=4, n_pad=6, n_global=2, seed=1),
+    "small": dict(n_code=8, n_data=40, n_acc=4, n_free=8, n_pad=60, n_global=4, seed=2),
+    "bench": dict(n_code=16, n_data=192, n_acc=12, n_free=24, n_pad=2350, n_global=8, seed=3),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("shape", choices=sorted(SHAPES))
+    ap.add_argument("out")
+    args = ap.parse_args()
+    words, info = generate(**SHAPES[args.shape])
+    with open(args.out, "wb") as f:
+        f.write(struct.pack("<%dI" % len(words), *words))
+    print(args.shape, info, "words", len(words))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
