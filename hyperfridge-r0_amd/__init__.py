@@ -1,0 +1,338 @@
+"""Host-side harness over libr0hip.so (ctypes), mirroring risc0's `Hal` / `CircuitHal` / segment-prover surface.
+
+The product is the C-ABI library (include/r0hip.h); this module only makes it callable from the tests and bench.py.
+The reference's host side is Rust (`risc0_zkvm::default_prover()`, host/src/main.rs:420-423); no Rust toolchain exists
+in this image, so the sequencer lives in C++ inside the library and this harness stays a thin binding
+(INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add instead).
+
+There is NO CPU fallback: importing works without a GPU (so the ABI can be inspected), but every compute entry point
+needs a device and raises R0HipError otherwise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+P = 2013265921
+INV_RATE = 4
+QUERIES = 50
+FRI_FOLD = 16
+CHECK_SIZE = 16
+GROUP_ACCUM, GROUP_CODE, GROUP_DATA = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libr0hip.so")
+
+
+class R0HipError(RuntimeError):
+    pass
+
+
+_c = ctypes
+_vp, _u32, _u64, _sz, _cp = _c.c_void_p, _c.c_uint32, _c.c_uint64, _c.c_size_t, _c.c_char_p
+_pp = _c.POINTER(_c.c_void_p)
+
+# name -> argtypes; every entry returns `const char*` (NULL = ok) unless listed in _PLAIN
+_SIGNATURES = {
+    "r0h_ctx_create": [_c.c_int, _pp],
+    "r0h_ctx_destroy": [_vp],
+    "r0h_sync": [_vp],
+    "r0h_buf_alloc": [_vp, _sz, _pp],
+    "r0h_buf_wrap": [_vp, _vp, _sz, _pp],
+    "r0h_buf_slice": [_vp, _sz, _sz, _pp],
+    "r0h_buf_free": [_vp],
+    "r0h_buf_h2d": [_vp, _vp, _sz, _vp, _sz],
+    "r0h_buf_d2h": [_vp, _vp, _sz, _vp, _sz],
+    "r0h_buf_zero": [_vp, _vp],
+    "r0h_batch_interpolate_ntt": [_vp, _vp, _u32, _u32],
+    "r0h_batch_expand_into_evaluate_ntt": [_vp, _vp, _vp, _u32, _u32, _u32],
+    "r0h_batch_bit_reverse": [_vp, _vp, _u32, _u32],
+    "r0h_zk_shift": [_vp, _vp, _u32, _u32],
+    "r0h_poseidon2_set_consts": [_vp, _vp, _vp],
+    "r0h_hash_rows": [_vp, _vp, _vp, _u32, _u32],
+    "r0h_hash_fold": [_vp, _vp, _u32],
+    "r0h_merkle_build": [_vp, _vp, _vp, _u32, _u32],
+    "r0h_batch_evaluate_any": [_vp, _vp, _u32, _vp, _vp, _u32, _vp],
+    "r0h_mix_poly_coeffs": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32],
+    "r0h_eltwise_add_elem": [_vp, _vp, _vp, _vp, _u32],
+    "r0h_eltwise_copy_elem": [_vp, _vp, _vp, _u32],
+    "r0h_eltwise_sum_extelem": [_vp, _vp, _vp, _u32, _u32],
+    "r0h_gather_sample": [_vp, _vp, _vp, _u32, _u32, _u32],
+    "r0h_scatter": [_vp, _vp, _vp, _vp, _vp, _u32],
+    "r0h_fri_fold": [_vp, _vp, _vp, _vp, _u32],
+    "r0h_prefix_products": [_vp, _vp, _u32],
+    "r0h_poly_divide": [_vp, _vp, _u32, _vp, _vp],
+    "r0h_circuit_emit_hip": [_vp, _sz, _c.POINTER(_c.c_char_p)],
+    "r0h_circuit_load": [_vp, _vp, _sz, _cp, _pp],
+    "r0h_circuit_free": [_vp],
+    "r0h_witgen": [_vp, _vp, _u32, _u64, _vp, _vp, _vp],
+    "r0h_accum": [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
+    "r0h_eval_check": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "r0h_prove_segment": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)],
+    "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],
+}
+_PLAIN = {
+    "r0h_free_error": ([_vp], None),
+    "r0h_version": ([], _cp),
+    "r0h_buf_device_ptr": ([_vp], _vp),
+    "r0h_buf_bytes": ([_vp], _sz),
+    "r0h_circuit_group_size": ([_vp, _u32], _u32),
+    "r0h_circuit_n_global": ([_vp], _u32),
+    "r0h_circuit_n_mix": ([_vp], _u32),
+    "r0h_circuit_n_taps": ([_vp], _u32),
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_PLAIN))
+
+_lib = None
+
+
+def lib():
+    """Load libr0hip.so; fails loudly when the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise R0HipError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                             "There is no CPU fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = _vp  # keep the pointer so it can be freed
+        for name, (args, res) in _PLAIN.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = h
+    return _lib
+
+
+def _check(err):
+    if err:
+        msg = ctypes.cast(err, ctypes.c_char_p).value.decode("utf-8", "replace")
+        lib().r0h_free_error(err)
+        raise R0HipError(msg)
+
+
+def _u32arr(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(_vp)
+
+
+class Buf:
+    """A device buffer of uint32 words owned by the library (risc0 `Buffer<Elem>`)."""
+
+    def __init__(self, hal, handle, words):
+        self.hal, self.handle, self.words = hal, handle, words
+
+    def to_host(self, offset_words=0, words=None):
+        words = self.words - offset_words if words is None else words
+        out = np.empty(words, dtype=np.uint32)
+        _check(lib().r0h_buf_d2h(self.hal.ctx, self.handle, offset_words * 4, out.ctypes.data_as(_vp), words * 4))
+        return out
+
+    def upload(self, array, offset_words=0):
+        a, p = _u32arr(array)
+        _check(lib().r0h_buf_h2d(self.hal.ctx, self.handle, offset_words * 4, p, a.size * 4))
+
+    def slice(self, offset_words, words):
+        h = _vp()
+        _check(lib().r0h_buf_slice(self.handle, offset_words * 4, words * 4, ctypes.byref(h)))
+        return Buf(self.hal, h, words)
+
+    def device_ptr(self):
+        return lib().r0h_buf_device_ptr(self.handle)
+
+    def free(self):
+        if self.handle:
+            _check(lib().r0h_buf_free(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Circuit:
+    def __init__(self, hal, handle, blob):
+        self.hal, self.handle, self.blob = hal, handle, blob
+        L = lib()
+        self.group_size = [L.r0h_circuit_group_size(handle, g) for g in range(3)]
+        self.n_global = L.r0h_circuit_n_global(handle)
+        self.n_mix = L.r0h_circuit_n_mix(handle)
+        self.n_taps = L.r0h_circuit_n_taps(handle)
+
+    def free(self):
+        if self.handle:
+            _check(lib().r0h_circuit_free(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def emit_eval_check_source(blob):
+    """HIP source of the circuit's eval_check kernels (pure host; needs no GPU)."""
+    a, p = _u32arr(blob)
+    out = ctypes.c_char_p()
+    _check(lib().r0h_circuit_emit_hip(p, a.size, ctypes.byref(out)))
+    src = out.value.decode()
+    lib().r0h_free_error(ctypes.cast(out, _vp))
+    return src
+
+
+class Hal:
+    """One context = one GPU + one stream (risc0 `Hal` + `CircuitHal` + segment prover, by name)."""
+
+    def __init__(self, device=0):
+        self.ctx = _vp()
+        _check(lib().r0h_ctx_create(device, ctypes.byref(self.ctx)))
+
+    def close(self):
+        if self.ctx:
+            _check(lib().r0h_ctx_destroy(self.ctx))
+            self.ctx = None
+
+    def sync(self):
+        _check(lib().r0h_sync(self.ctx))
+
+    # ---- buffers
+    def alloc(self, words):
+        h = _vp()
+        _check(lib().r0h_buf_alloc(self.ctx, int(words) * 4, ctypes.byref(h)))
+        return Buf(self, h, int(words))
+
+    def copy_from(self, array):
+        a = np.ascontiguousarray(array, dtype=np.uint32).reshape(-1)
+        b = self.alloc(max(a.size, 1))
+        if a.size:
+            b.upload(a)
+        b.words = a.size
+        return b
+
+    def wrap(self, device_ptr, words):
+        h = _vp()
+        _check(lib().r0h_buf_wrap(self.ctx, device_ptr, int(words) * 4, ctypes.byref(h)))
+        return Buf(self, h, int(words))
+
+    def zero(self, buf):
+        _check(lib().r0h_buf_zero(self.ctx, buf.handle))
+
+    # ---- Hal ops
+    def batch_interpolate_ntt(self, io, count, po2):
+        _check(lib().r0h_batch_interpolate_ntt(self.ctx, io.handle, count, po2))
+
+    def batch_expand_into_evaluate_ntt(self, out, inp, count, in_po2, expand_bits):
+        _check(lib().r0h_batch_expand_into_evaluate_ntt(self.ctx, out.handle, inp.handle, count, in_po2, expand_bits))
+
+    def batch_bit_reverse(self, io, count, po2):
+        _check(lib().r0h_batch_bit_reverse(self.ctx, io.handle, count, po2))
+
+    def zk_shift(self, io, count, po2):
+        _check(lib().r0h_zk_shift(self.ctx, io.handle, count, po2))
+
+    def poseidon2_set_consts(self, rc, diag_m1):
+        a, pa = _u32arr(rc)
+        b, pb = _u32arr(diag_m1)
+        assert a.size == 24 * 29 and b.size == 24
+        _check(lib().r0h_poseidon2_set_consts(self.ctx, pa, pb))
+
+    def hash_rows(self, digests, matrix, rows, cols):
+        _check(lib().r0h_hash_rows(self.ctx, digests.handle, matrix.handle, rows, cols))
+
+    def hash_fold(self, nodes, output_size):
+        _check(lib().r0h_hash_fold(self.ctx, nodes.handle, output_size))
+
+    def merkle_build(self, nodes, matrix, rows, cols):
+        _check(lib().r0h_merkle_build(self.ctx, nodes.handle, matrix.handle, rows, cols))
+
+    def batch_evaluate_any(self, coeffs, po2, which, xs, out):
+        w, pw = _u32arr(which)
+        x, px = _u32arr(xs)
+        assert x.size == 4 * w.size
+        _check(lib().r0h_batch_evaluate_any(self.ctx, coeffs.handle, po2, pw, px, w.size, out.handle))
+
+    def mix_poly_coeffs(self, combos, mix_start, mix, inp, combo_of, po2):
+        ms, pms = _u32arr(mix_start)
+        m, pm = _u32arr(mix)
+        co, pco = _u32arr(combo_of)
+        _check(lib().r0h_mix_poly_coeffs(self.ctx, combos.handle, pms, pm, inp.handle, pco, co.size, po2))
+
+    def eltwise_add_elem(self, out, a, b, n):
+        _check(lib().r0h_eltwise_add_elem(self.ctx, out.handle, a.handle, b.handle, n))
+
+    def eltwise_copy_elem(self, out, inp, n):
+        _check(lib().r0h_eltwise_copy_elem(self.ctx, out.handle, inp.handle, n))
+
+    def eltwise_sum_extelem(self, out, inp, count, n):
+        _check(lib().r0h_eltwise_sum_extelem(self.ctx, out.handle, inp.handle, count, n))
+
+    def gather_sample(self, dst, src, idx, size, stride):
+        _check(lib().r0h_gather_sample(self.ctx, dst.handle, src.handle, idx, size, stride))
+
+    def scatter(self, into, index, offsets, values, n_index):
+        _check(lib().r0h_scatter(self.ctx, into.handle, index.handle, offsets.handle, values.handle, n_index))
+
+    def fri_fold(self, out, inp, mix, n_out):
+        m, pm = _u32arr(mix)
+        _check(lib().r0h_fri_fold(self.ctx, out.handle, inp.handle, pm, n_out))
+
+    def prefix_products(self, io, n):
+        _check(lib().r0h_prefix_products(self.ctx, io.handle, n))
+
+    def poly_divide(self, poly, n, z):
+        zz, pz = _u32arr(z)
+        rem = np.zeros(4, dtype=np.uint32)
+        _check(lib().r0h_poly_divide(self.ctx, poly.handle, n, pz, rem.ctypes.data_as(_vp)))
+        return rem
+
+    # ---- CircuitHal + sequencer
+    def load_circuit(self, blob, code_object_path=None):
+        a, p = _u32arr(blob)
+        h = _vp()
+        path = code_object_path.encode() if code_object_path else None
+        _check(lib().r0h_circuit_load(self.ctx, p, a.size, path, ctypes.byref(h)))
+        return Circuit(self, h, a)
+
+    def witgen(self, circuit, po2, seed):
+        n = 1 << po2
+        code = self.alloc(circuit.group_size[GROUP_CODE] * n)
+        data = self.alloc(circuit.group_size[GROUP_DATA] * n)
+        glob = np.zeros(max(circuit.n_global, 1), dtype=np.uint32)
+        _check(lib().r0h_witgen(self.ctx, circuit.handle, po2, seed, code.handle, data.handle, glob.ctypes.data_as(_vp)))
+        return code, data, glob[:circuit.n_global]
+
+    def accum(self, circuit, po2, code, data, mix):
+        n = 1 << po2
+        m, pm = _u32arr(mix)
+        out = self.alloc(circuit.group_size[GROUP_ACCUM] * n)
+        _check(lib().r0h_accum(self.ctx, circuit.handle, po2, code.handle, data.handle, pm, out.handle))
+        return out
+
+    def eval_check(self, circuit, po2, eval_accum, eval_code, eval_data, glob, mix, poly_mix):
+        g, pg = _u32arr(glob)
+        m, pm = _u32arr(mix)
+        q, pq = _u32arr(poly_mix)
+        check = self.alloc(16 << po2)
+        _check(lib().r0h_eval_check(self.ctx, circuit.handle, po2, eval_accum.handle, eval_code.handle, eval_data.handle,
+                                    pg, pm, pq, check.handle))
+        return check
+
+    def prove_segment(self, circuit, po2, code, data, glob, seal_capacity_words=1 << 20):
+        g, pg = _u32arr(glob)
+        seal = np.empty(seal_capacity_words, dtype=np.uint32)
+        n = _sz(0)
+        _check(lib().r0h_prove_segment(self.ctx, circuit.handle, po2, code.handle, data.handle, pg,
+                                       seal.ctypes.data_as(_vp), seal.size, ctypes.byref(n)))
+        return seal[:n.value].copy()
+
+    def last_profile(self):
+        names = _c.POINTER(_cp)()
+        ms = _c.POINTER(_c.c_float)()
+        n = _u32(0)
+        _check(lib().r0h_last_profile(self.ctx, ctypes.byref(names), ctypes.byref(ms), ctypes.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]

@@ -1,0 +1,561 @@
+// Circuit side of the prover: blob loading, eval_check code generation + launch, synthetic witness generation and
+// accumulation.  Replaces the CircuitHal half of risc0-circuit-rv32im 4.0.4 / risc0-circuit-rv32im-sys 4.0.2
+// (`eval_check` + generated `poly_fp`, `generate_witness`, `step_accum`) -- SURVEY.md 8(a) a9-a11.
+//
+// Upstream compiles a machine-generated constraint polynomial into its kernels at build time.  Here the circuit is
+// data (include/r0hip_circuit.h): r0h_circuit_emit_hip turns its PolyExtStep program into straight-line HIP --
+//   check[i] = (sum_t poly_mix^{p_t} * val_t(i)) / ((3 w^i)^N - 1)      on the 4N coset domain
+// where AndCond gates are flattened into their inner terms (val = cond * inner value, power = outer + inner), the
+// powers of poly_mix are wave-uniform (scalar loads), every lane owns one domain point and reads tap (col, back) at
+// row (i - 4*back) mod 4N: consecutive lanes hit consecutive words of one column.  The program is cut into several
+// kernels so that each has a bounded live set; partial sums accumulate through the check buffer.
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <sstream>
+
+#include "../../include/r0hip_circuit.h"
+#include "circuit.hpp"
+
+namespace r0h {
+
+static const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
+  R0H_REQUIRE(n_words >= 3 && w[0] == R0H_BLOB_MAGIC && w[1] == 1, "circuit blob: bad magic or version");
+  size_t pos = 3;
+  bool seen[8] = {false};
+  for (uint32_t s = 0; s < w[2]; s++) {
+    R0H_REQUIRE(pos + 2 <= n_words, "circuit blob: truncated section header");
+    uint32_t tag = w[pos], len = w[pos + 1];
+    const uint32_t* p = w + pos + 2;
+    R0H_REQUIRE(pos + 2 + len <= n_words, "circuit blob: section %u overruns the blob", tag);
+    if (tag < 8) seen[tag] = true;
+    switch (tag) {
+      case R0H_SEC_GROUPS:
+        R0H_REQUIRE(len >= 3, "circuit blob: GROUPS too short");
+        memcpy(c->group_size, p, 12);
+        break;
+      case R0H_SEC_TAPS: {
+        R0H_REQUIRE(len >= 1 && len == 1 + 3 * (size_t)p[0], "circuit blob: TAPS length mismatch");
+        c->taps.resize(p[0]);
+        memcpy(c->taps.data(), p + 1, 12 * (size_t)p[0]);
+        break;
+      }
+      case R0H_SEC_GLOBALS:
+        R0H_REQUIRE(len >= 2 && len == 2 + (size_t)p[0], "circuit blob: GLOBALS length mismatch");
+        c->n_global = p[0]; c->n_mix = p[1];
+        c->global_cols.assign(p + 2, p + 2 + p[0]);
+        break;
+      case R0H_SEC_POLY:
+        R0H_REQUIRE(len >= 2 && len == 2 + 4 * (size_t)p[0], "circuit blob: POLY length mismatch");
+        c->ret = p[1];
+        c->steps.resize(p[0]);
+        memcpy(c->steps.data(), p + 2, 16 * (size_t)p[0]);
+        break;
+      case R0H_SEC_WITGEN: {
+        R0H_REQUIRE(len >= 1 && len >= 2 + 2 * (size_t)p[0], "circuit blob: WITGEN too short");
+        c->code_cols.resize(p[0]);
+        memcpy(c->code_cols.data(), p + 1, 8 * (size_t)p[0]);
+        const uint32_t* q = p + 1 + 2 * (size_t)p[0];
+        R0H_REQUIRE(len == 2 + 2 * (size_t)p[0] + 5 * (size_t)q[0], "circuit blob: WITGEN length mismatch");
+        c->data_cols.resize(q[0]);
+        memcpy(c->data_cols.data(), q + 1, 20 * (size_t)q[0]);
+        break;
+      }
+      case R0H_SEC_ACCUM:
+        R0H_REQUIRE(len >= 1 && len == 1 + 3 * (size_t)p[0], "circuit blob: ACCUM length mismatch");
+        c->acc_cols.resize(p[0]);
+        memcpy(c->acc_cols.data(), p + 1, 12 * (size_t)p[0]);
+        break;
+      default: break;
+    }
+    pos += 2 + len;
+  }
+  for (int t = 1; t <= 6; t++) R0H_REQUIRE(seen[t], "circuit blob: section %d missing", t);
+  R0H_REQUIRE(c->code_cols.size() == c->group_size[R0H_GROUP_CODE] && c->data_cols.size() == c->group_size[R0H_GROUP_DATA] &&
+                  4 * c->acc_cols.size() == c->group_size[R0H_GROUP_ACCUM] && c->n_mix == 8 * c->acc_cols.size(),
+              "circuit blob: group sizes disagree with the column programs");
+  // taps: sorted, in range, every column owns back 0
+  std::vector<std::vector<bool>> has0(3);
+  for (int g = 0; g < 3; g++) has0[g].assign(c->group_size[g], false);
+  for (size_t t = 0; t < c->taps.size(); t++) {
+    const Tap& tp = c->taps[t];
+    R0H_REQUIRE(tp.group < 3 && tp.offset < c->group_size[tp.group] && tp.back < 64, "circuit blob: tap %zu out of range", t);
+    if (t) {
+      const Tap& pv = c->taps[t - 1];
+      bool ordered = pv.group < tp.group || (pv.group == tp.group && (pv.offset < tp.offset || (pv.offset == tp.offset && pv.back < tp.back)));
+      R0H_REQUIRE(ordered, "circuit blob: taps not strictly sorted at %zu", t);
+    }
+    if (tp.back == 0) has0[tp.group][tp.offset] = true;
+  }
+  for (int g = 0; g < 3; g++)
+    for (uint32_t k = 0; k < c->group_size[g]; k++) R0H_REQUIRE(has0[g][k], "circuit blob: group %d column %u has no back-0 tap", g, k);
+  // registers and combos
+  c->combo_begin.assign(1, 0);
+  for (int g = 0; g < 4; g++) c->group_tap_begin[g] = (uint32_t)c->taps.size();
+  for (uint32_t t = 0; t < c->taps.size();) {
+    uint32_t e = t;
+    while (e < c->taps.size() && c->taps[e].group == c->taps[t].group && c->taps[e].offset == c->taps[t].offset) e++;
+    uint32_t size = e - t, n_combos = (uint32_t)c->combo_begin.size() - 1, combo = n_combos;
+    for (uint32_t k = 0; k < n_combos && combo == n_combos; k++) {
+      uint32_t b = c->combo_begin[k];
+      if (c->combo_begin[k + 1] - b != size) continue;
+      bool same = true;
+      for (uint32_t i = 0; i < size; i++) same = same && c->combo_backs[b + i] == c->taps[t + i].back;
+      if (same) combo = k;
+    }
+    if (combo == n_combos) {
+      for (uint32_t i = 0; i < size; i++) c->combo_backs.push_back(c->taps[t + i].back);
+      c->combo_begin.push_back((uint32_t)c->combo_backs.size());
+    }
+    c->regs.push_back(Reg{c->taps[t].group, c->taps[t].offset, t, size, combo});
+    t = e;
+  }
+  for (uint32_t t = (uint32_t)c->taps.size(); t-- > 0;) c->group_tap_begin[c->taps[t].group] = t;
+  for (int g = 2; g >= 0; g--)
+    if (c->group_tap_begin[g] == c->taps.size()) c->group_tap_begin[g] = c->group_tap_begin[g + 1];
+  // variable numbering + operand validation
+  for (uint32_t i = 0; i < c->steps.size(); i++) {
+    const Step& s = c->steps[i];
+    uint32_t nf = (uint32_t)c->fp_step.size(), nm = (uint32_t)c->mix_step.size();
+    switch (s.op) {
+      case R0H_OP_CONST: R0H_REQUIRE(s.a < P, "poly step %u: constant not canonical", i); c->fp_step.push_back(i); break;
+      case R0H_OP_GET: R0H_REQUIRE(s.a < c->taps.size(), "poly step %u: tap out of range", i); c->fp_step.push_back(i); break;
+      case R0H_OP_GET_GLOBAL:
+        R0H_REQUIRE(s.a < 2 && s.b < (s.a == 0 ? c->n_global : c->n_mix), "poly step %u: global out of range", i);
+        c->fp_step.push_back(i);
+        break;
+      case R0H_OP_ADD: case R0H_OP_SUB: case R0H_OP_MUL:
+        R0H_REQUIRE(s.a < nf && s.b < nf, "poly step %u: operand not yet defined", i);
+        c->fp_step.push_back(i);
+        break;
+      case R0H_OP_TRUE: c->mix_step.push_back(i); break;
+      case R0H_OP_AND_EQZ: R0H_REQUIRE(s.a < nm && s.b < nf, "poly step %u: operand not yet defined", i); c->mix_step.push_back(i); break;
+      case R0H_OP_AND_COND: R0H_REQUIRE(s.a < nm && s.b < nf && s.c < nm, "poly step %u: operand not yet defined", i); c->mix_step.push_back(i); break;
+      default: return make_error("poly step %u: unknown opcode %u", i, s.op);
+    }
+  }
+  R0H_REQUIRE(c->ret < c->mix_step.size(), "circuit blob: ret is not a mix variable");
+  for (uint32_t k = 0; k < c->n_global; k++) R0H_REQUIRE(c->global_cols[k] < c->data_cols.size(), "circuit blob: global column out of range");
+  for (size_t k = 0; k < c->data_cols.size(); k++) {
+    const DataCol& d = c->data_cols[k];
+    R0H_REQUIRE(d.kind <= 2, "witgen: data column %zu has unknown kind", k);
+    if (d.kind == 0) continue;
+    const uint32_t refs[4] = {d.a, d.b, d.kind == 2 ? d.c : d.a, d.e};
+    for (uint32_t r : refs) {
+      uint32_t g = r >> 28, col = r & 0xfffffu;
+      R0H_REQUIRE((g == R0H_GROUP_CODE && col < c->code_cols.size()) || (g == R0H_GROUP_DATA && col < k), "witgen: data column %zu has a forward or foreign reference", k);
+    }
+  }
+  for (const AccCol& a : c->acc_cols) R0H_REQUIRE(a.a < c->data_cols.size() && a.b < c->data_cols.size(), "accum: column out of range");
+  c->blob.assign(w, w + n_words);
+  return nullptr;
+}
+
+// Flatten the MixState chain that ends in `m` into (power, value, gates) terms; returns the number of powers consumed.
+static uint32_t flatten(const r0h_circuit* c, uint32_t m, uint32_t base_pow, std::vector<uint32_t>& gates, std::vector<Term>& out) {
+  std::vector<uint32_t> chain;
+  for (uint32_t cur = m;;) {
+    const Step& s = c->steps[c->mix_step[cur]];
+    if (s.op == R0H_OP_TRUE) break;
+    chain.push_back(cur);
+    cur = s.a;
+  }
+  uint32_t pow = base_pow;
+  for (size_t k = chain.size(); k-- > 0;) {
+    const Step& s = c->steps[c->mix_step[chain[k]]];
+    if (s.op == R0H_OP_AND_EQZ) {
+      out.push_back(Term{pow, s.b, gates});
+      pow += 1;
+    } else {
+      gates.push_back(s.b);
+      pow += flatten(c, s.c, pow, gates, out);
+      gates.pop_back();
+    }
+  }
+  return pow - base_pow;
+}
+
+static void make_plan(r0h_circuit* c) {
+  Plan& pl = c->plan;
+  std::vector<uint32_t> gates;
+  pl.n_pow = flatten(c, c->ret, 0, gates, pl.terms);
+  // cut into kernels of bounded arithmetic: cost of a term = its not-yet-emitted expression nodes + 8
+  const uint32_t budget = 2500;
+  std::vector<uint32_t> stamp(c->fp_step.size(), UINT32_MAX);
+  uint32_t kernel = 0, cost = 0;
+  pl.cut.assign(1, 0);
+  std::vector<uint32_t> stack;
+  for (uint32_t t = 0; t < pl.terms.size(); t++) {
+    uint32_t add = 8;
+    stack.assign(1, pl.terms[t].v);
+    for (uint32_t g : pl.terms[t].conds) stack.push_back(g);
+    while (!stack.empty()) {
+      uint32_t v = stack.back();
+      stack.pop_back();
+      if (stamp[v] == kernel) continue;
+      stamp[v] = kernel;
+      add++;
+      const Step& s = c->steps[c->fp_step[v]];
+      if (s.op == R0H_OP_ADD || s.op == R0H_OP_SUB || s.op == R0H_OP_MUL) { stack.push_back(s.a); stack.push_back(s.b); }
+    }
+    if (cost && cost + add > budget) {
+      pl.cut.push_back(t);
+      kernel++;
+      cost = 0;
+      t--;  // re-cost this term inside the new kernel
+      continue;
+    }
+    cost += add;
+  }
+  pl.cut.push_back((uint32_t)pl.terms.size());
+}
+
+static const char* PRELUDE = R"SRC(// GENERATED by r0h_circuit_emit_hip -- eval_check for one circuit blob (gfx950).
+#if !defined(__HIPCC_RTC__)
+#include <hip/hip_runtime.h>
+#endif
+typedef unsigned int u32;
+typedef unsigned long long u64;
+#define FP_P 2013265921u
+__device__ __forceinline__ u32 fred(u32 x) { u32 y = x - FP_P; return y < x ? y : x; }
+__device__ __forceinline__ u32 fadd(u32 a, u32 b) { return fred(a + b); }
+__device__ __forceinline__ u32 fsub(u32 a, u32 b) { u32 d = a - b; return a < b ? d + FP_P : d; }
+__device__ __forceinline__ u32 fmul(u32 a, u32 b) {
+  u64 t = (u64)a * b;
+  u32 m = (u32)t * 0x77ffffffu;
+  u64 u = t + (u64)m * FP_P;
+  return fred((u32)(u >> 32));
+}
+#define TAP(g, col, back) g[(size_t)(col) * domain + ((i - 4u * (back)) & mask)]
+#define TERM(p, val)                                          \
+  do {                                                        \
+    u32 v_ = (val);                                           \
+    t0 = fadd(t0, fmul(mixpow[4 * (p) + 0], v_));             \
+    t1 = fadd(t1, fmul(mixpow[4 * (p) + 1], v_));             \
+    t2 = fadd(t2, fmul(mixpow[4 * (p) + 2], v_));             \
+    t3 = fadd(t3, fmul(mixpow[4 * (p) + 3], v_));             \
+  } while (0)
+)SRC";
+
+static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& done, std::ostringstream& os) {
+  // iterative post-order emission of the expression DAG below `root`
+  std::vector<std::pair<uint32_t, int>> stack;
+  stack.push_back({root, 0});
+  while (!stack.empty()) {
+    auto [v, state] = stack.back();
+    if (done[v]) { stack.pop_back(); continue; }
+    const Step& s = c->steps[c->fp_step[v]];
+    bool binary = s.op == R0H_OP_ADD || s.op == R0H_OP_SUB || s.op == R0H_OP_MUL;
+    if (binary && state == 0) {
+      stack.back().second = 1;
+      if (!done[s.b]) stack.push_back({s.b, 0});
+      if (!done[s.a]) stack.push_back({s.a, 0});
+      continue;
+    }
+    stack.pop_back();
+    done[v] = true;
+    os << "  const u32 v" << v << " = ";
+    switch (s.op) {
+      case R0H_OP_CONST: os << enc(s.a) << "u"; break;
+      case R0H_OP_GET: {
+        const Tap& t = c->taps[s.a];
+        os << "TAP(g" << t.group << ", " << t.offset << "u, " << t.back << "u)";
+        break;
+      }
+      case R0H_OP_GET_GLOBAL: os << (s.a == 0 ? "glob[" : "mix[") << s.b << "]"; break;
+      case R0H_OP_ADD: os << "fadd(v" << s.a << ", v" << s.b << ")"; break;
+      case R0H_OP_SUB: os << "fsub(v" << s.a << ", v" << s.b << ")"; break;
+      case R0H_OP_MUL: os << "fmul(v" << s.a << ", v" << s.b << ")"; break;
+      default: break;
+    }
+    os << ";\n";
+  }
+}
+
+static std::string emit_source(const r0h_circuit* c) {
+  const Plan& pl = c->plan;
+  std::ostringstream os;
+  os << PRELUDE;
+  os << "// terms: " << pl.terms.size() << ", powers of poly_mix: " << pl.n_pow << ", kernels: " << pl.cut.size() - 1 << "\n";
+  for (size_t k = 0; k + 1 < pl.cut.size(); k++) {
+    os << "extern \"C\" __global__ __launch_bounds__(256) void eval_check_" << k
+       << "(u32* __restrict__ check, const u32* __restrict__ g0, const u32* __restrict__ g1, const u32* __restrict__ g2,\n"
+          "    const u32* __restrict__ glob, const u32* __restrict__ mix, const u32* __restrict__ mixpow,\n"
+          "    const u32* __restrict__ inv_van, u32 po2, u32 accumulate) {\n"
+          "  const u32 domain = 4u << po2, mask = domain - 1u;\n"
+          "  const u32 i = blockIdx.x * 256u + threadIdx.x;\n"
+          "  u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;\n";
+    std::vector<bool> done(c->fp_step.size(), false);
+    for (uint32_t t = pl.cut[k]; t < pl.cut[k + 1]; t++) {
+      const Term& tm = pl.terms[t];
+      emit_var(c, tm.v, done, os);
+      for (uint32_t g : tm.conds) emit_var(c, g, done, os);
+      os << "  TERM(" << tm.pow << "u, ";
+      for (size_t g = 0; g < tm.conds.size(); g++) os << "fmul(v" << tm.conds[g] << ", ";
+      os << "v" << tm.v;
+      for (size_t g = 0; g < tm.conds.size(); g++) os << ")";
+      os << ");\n";
+    }
+    os << "  const u32 iv = inv_van[i & 3u];\n"
+          "  t0 = fmul(t0, iv); t1 = fmul(t1, iv); t2 = fmul(t2, iv); t3 = fmul(t3, iv);\n"
+          "  if (accumulate) {\n"
+          "    t0 = fadd(t0, check[i]); t1 = fadd(t1, check[(size_t)domain + i]);\n"
+          "    t2 = fadd(t2, check[2 * (size_t)domain + i]); t3 = fadd(t3, check[3 * (size_t)domain + i]);\n"
+          "  }\n"
+          "  check[i] = t0; check[(size_t)domain + i] = t1; check[2 * (size_t)domain + i] = t2; check[3 * (size_t)domain + i] = t3;\n"
+          "}\n\n";
+  }
+  return os.str();
+}
+
+static const char* compile_in_process(const std::string& src, std::vector<char>& code) {
+  hiprtcProgram prog;
+  hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "eval_check.hip", 0, nullptr, nullptr);
+  R0H_REQUIRE(r == HIPRTC_SUCCESS, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+  const char* opts[] = {"--offload-arch=gfx950", "-O3"};
+  r = hiprtcCompileProgram(prog, 2, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, 0);
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    return make_error("hiprtcCompileProgram: %s\n%.2000s", hiprtcGetErrorString(r), log.c_str());
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  code.resize(n);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  return nullptr;
+}
+
+// ------------------------------------------------------------------ synthetic witness + accumulation kernels
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint32_t synth_word(uint64_t seed_mixed, uint32_t stream, uint32_t row) {
+  uint64_t h = splitmix64(seed_mixed ^ (((uint64_t)stream << 32) | row));
+  return (uint32_t)(((h >> 32) * (uint64_t)P) >> 32);
+}
+static uint64_t splitmix64_host(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void witgen_fixed_kernel(uint32_t* __restrict__ buf, const uint32_t* __restrict__ kinds /* (kind, stream) per col */,
+                                    uint32_t po2, uint64_t seed_mixed) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << po2, col = blockIdx.y;
+  const uint32_t kind = kinds[2 * col], stream = kinds[2 * col + 1];
+  uint32_t v;
+  if (kind == 0) v = r == 0 ? ONE : 0u;
+  else if (kind == 1) v = r == n - 1 ? ONE : 0u;
+  else if (kind == 2) v = enc(r);
+  else if (kind == 3) v = synth_word(seed_mixed, stream, r);
+  else return;  // derived column: filled later
+  buf[((size_t)col << po2) + r] = v;
+}
+__global__ void witgen_derived_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                      const uint32_t* __restrict__ c, const uint32_t* __restrict__ e, uint32_t ba, uint32_t bb,
+                                      uint32_t bc, uint32_t be, uint32_t kind, uint32_t po2) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, mask = (1u << po2) - 1;
+  uint32_t prod = mul(a[(r - ba) & mask], b[(r - bb) & mask]);
+  if (kind == 2) prod = mul(prod, c[(r - bc) & mask]);
+  dst[r] = add(prod, e[(r - be) & mask]);
+}
+__global__ void accum_term_kernel(uint32_t* __restrict__ term, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, Fp4 m0, Fp4 m1) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  Fp4 t = m0 + scale(m1, b[r]);
+  t.e[0] = add(t.e[0], a[r]);
+  *(uint4*)(term + 4 * (size_t)r) = make_uint4(t.e[0], t.e[1], t.e[2], t.e[3]);
+}
+__global__ void accum_unpack_kernel(uint32_t* __restrict__ cols, const uint32_t* __restrict__ term, uint32_t po2) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  uint4 v = *(const uint4*)(term + 4 * (size_t)r);
+  cols[r] = v.x; cols[((size_t)1 << po2) + r] = v.y; cols[((size_t)2 << po2) + r] = v.z; cols[((size_t)3 << po2) + r] = v.w;
+}
+
+}  // namespace r0h
+
+using namespace r0h;
+
+extern "C" {
+
+const char* r0h_circuit_emit_hip(const uint32_t* blob, size_t n_words, char** source_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(blob && source_out, "r0h_circuit_emit_hip: NULL argument");
+  r0h_circuit c;
+  R0H_TRY(parse_blob(&c, blob, n_words));
+  make_plan(&c);
+  std::string src = emit_source(&c);
+  char* out = (char*)malloc(src.size() + 1);
+  R0H_REQUIRE(out, "r0h_circuit_emit_hip: out of memory");
+  memcpy(out, src.c_str(), src.size() + 1);
+  *source_out = out;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_circuit_load(r0h_ctx* ctx, const uint32_t* blob, size_t n_words, const char* code_object_path, r0h_circuit** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && blob && out, "r0h_circuit_load: NULL argument");
+  r0h_circuit* c = new r0h_circuit();
+  c->ctx = ctx;
+  const char* err = parse_blob(c, blob, n_words);
+  if (err) { delete c; return err; }
+  make_plan(c);
+  R0H_TRY_HIP(hipSetDevice(ctx->device));
+  std::vector<char> code;
+  if (code_object_path) {
+    FILE* f = fopen(code_object_path, "rb");
+    if (!f) { delete c; return make_error("r0h_circuit_load: cannot open code object %s", code_object_path); }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    code.resize(sz > 0 ? (size_t)sz : 0);
+    size_t got = fread(code.data(), 1, code.size(), f);
+    fclose(f);
+    if (got != code.size() || code.empty()) { delete c; return make_error("r0h_circuit_load: short read of %s", code_object_path); }
+  } else {
+    err = compile_in_process(emit_source(c), code);
+    if (err) { delete c; return err; }
+  }
+  hipError_t e = hipModuleLoadData(&c->module, code.data());
+  if (e != hipSuccess) { delete c; return make_error("r0h_circuit_load: hipModuleLoadData: %s", hipGetErrorString(e)); }
+  for (size_t k = 0; k + 1 < c->plan.cut.size(); k++) {
+    char name[64];
+    snprintf(name, sizeof name, "eval_check_%zu", k);
+    hipFunction_t fn;
+    e = hipModuleGetFunction(&fn, c->module, name);
+    if (e != hipSuccess) {
+      hipModuleUnload(c->module);
+      delete c;
+      return make_error("r0h_circuit_load: the code object lacks %s (built from another blob?): %s", name, hipGetErrorString(e));
+    }
+    c->kernels.push_back(fn);
+  }
+  size_t words = c->n_global + c->n_mix + 4 * (size_t)c->plan.n_pow + 4;
+  e = hipMalloc((void**)&c->d_params, words * 4);
+  if (e != hipSuccess) { hipModuleUnload(c->module); delete c; return make_error("r0h_circuit_load: hipMalloc: %s", hipGetErrorString(e)); }
+  *out = c;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_circuit_free(r0h_circuit* c) {
+  if (!c) return nullptr;
+  hipSetDevice(c->ctx->device);
+  hipStreamSynchronize(c->ctx->stream);
+  if (c->d_params) hipFree(c->d_params);
+  if (c->module) hipModuleUnload(c->module);
+  delete c;
+  return nullptr;
+}
+
+uint32_t r0h_circuit_group_size(const r0h_circuit* c, uint32_t group) { return c && group < 3 ? c->group_size[group] : 0; }
+uint32_t r0h_circuit_n_global(const r0h_circuit* c) { return c ? c->n_global : 0; }
+uint32_t r0h_circuit_n_mix(const r0h_circuit* c) { return c ? c->n_mix : 0; }
+uint32_t r0h_circuit_n_taps(const r0h_circuit* c) { return c ? (uint32_t)c->taps.size() : 0; }
+
+const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, r0h_buf* code, r0h_buf* data, uint32_t* global_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && c && code && data, "r0h_witgen: NULL argument");
+  R0H_REQUIRE(po2 >= 4 && po2 <= R0H_MAX_PO2, "r0h_witgen: po2 %u outside [4, %u]", po2, R0H_MAX_PO2);
+  const uint32_t n = 1u << po2, threads = n < 256 ? n : 256, nc = (uint32_t)c->code_cols.size(), nd = (uint32_t)c->data_cols.size();
+  R0H_REQUIRE(((size_t)nc << po2) * 4 <= code->bytes && ((size_t)nd << po2) * 4 <= data->bytes, "r0h_witgen: buffers too small for 2^%u rows", po2);
+  std::vector<uint32_t> kinds(2 * (size_t)(nc + nd));
+  for (uint32_t k = 0; k < nc; k++) { kinds[2 * k] = c->code_cols[k].kind; kinds[2 * k + 1] = (1u << 16) | k; }
+  for (uint32_t k = 0; k < nd; k++) { kinds[2 * (nc + k)] = c->data_cols[k].kind == 0 ? 3u : 99u; kinds[2 * (nc + k) + 1] = (2u << 16) | k; }
+  R0H_TRY(ensure_scratch(ctx, kinds.size() * 4));
+  R0H_TRY_HIP(hipMemcpyAsync(ctx->scratch, kinds.data(), kinds.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  const uint32_t* dk = (const uint32_t*)ctx->scratch;
+  hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nc), dim3(threads), 0, ctx->stream, u32(code), dk, po2, splitmix64_host(0xC0DEull));
+  hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nd), dim3(threads), 0, ctx->stream, u32(data), dk + 2 * nc, po2, splitmix64_host(seed));
+  for (uint32_t k = 0; k < nd; k++) {
+    const DataCol& d = c->data_cols[k];
+    if (d.kind == 0) continue;
+    auto col = [&](uint32_t r) { return ((r >> 28) == R0H_GROUP_CODE ? u32(code) : u32(data)) + ((size_t)(r & 0xfffffu) << po2); };
+    auto back = [](uint32_t r) { return (r >> 20) & 0xffu; };
+    uint32_t rc = d.kind == 2 ? d.c : d.a;
+    hipLaunchKernelGGL(witgen_derived_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(data) + ((size_t)k << po2), col(d.a), col(d.b),
+                       col(rc), col(d.e), back(d.a), back(d.b), back(rc), back(d.e), d.kind, po2);
+  }
+  hipError_t e = hipGetLastError();
+  R0H_REQUIRE(e == hipSuccess, "r0h_witgen: launch failed: %s", hipGetErrorString(e));
+  if (global_out) {
+    for (uint32_t k = 0; k < c->n_global; k++)
+      R0H_TRY_HIP(hipMemcpyAsync(global_out + k, u32(data) + ((size_t)c->global_cols[k] << po2), 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data, const uint32_t* mix, r0h_buf* accum) {
+  R0H_GUARD_BEGIN
+  (void)code;
+  R0H_REQUIRE(ctx && c && data && accum && (mix || c->n_mix == 0), "r0h_accum: NULL argument");
+  R0H_REQUIRE(po2 >= 4 && po2 <= R0H_MAX_PO2, "r0h_accum: po2 %u outside [4, %u]", po2, R0H_MAX_PO2);
+  const uint32_t n = 1u << po2, threads = n < 256 ? n : 256;
+  R0H_REQUIRE(((size_t)c->data_cols.size() << po2) * 4 <= data->bytes && ((size_t)c->group_size[R0H_GROUP_ACCUM] << po2) * 4 <= accum->bytes,
+              "r0h_accum: buffers too small for 2^%u rows", po2);
+  for (uint32_t i = 0; i < c->n_mix; i++) R0H_REQUIRE(mix[i] < P, "r0h_accum: mix[%u] not canonical", i);
+  r0h_buf* term = nullptr;
+  R0H_TRY(r0h_buf_alloc(ctx, (size_t)n * 16, &term));
+  for (uint32_t j = 0; j < c->acc_cols.size(); j++) {
+    Fp4 m0{{mix[8 * j], mix[8 * j + 1], mix[8 * j + 2], mix[8 * j + 3]}}, m1{{mix[8 * j + 4], mix[8 * j + 5], mix[8 * j + 6], mix[8 * j + 7]}};
+    hipLaunchKernelGGL(accum_term_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(term), u32(data) + ((size_t)c->acc_cols[j].a << po2),
+                       u32(data) + ((size_t)c->acc_cols[j].b << po2), m0, m1);
+    const char* err = r0h_prefix_products(ctx, term, n);
+    if (err) { r0h_buf_free(term); return err; }
+    hipLaunchKernelGGL(accum_unpack_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(accum) + ((size_t)(4 * j) << po2), u32(term), po2);
+  }
+  hipError_t e = hipGetLastError();
+  R0H_TRY(r0h_buf_free(term));
+  R0H_REQUIRE(e == hipSuccess, "r0h_accum: launch failed: %s", hipGetErrorString(e));
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* eval_accum, const r0h_buf* eval_code,
+                           const r0h_buf* eval_data, const uint32_t* global, const uint32_t* mix, const uint32_t poly_mix[4], r0h_buf* check) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && c && eval_accum && eval_code && eval_data && check && poly_mix, "r0h_eval_check: NULL argument");
+  R0H_REQUIRE((global || !c->n_global) && (mix || !c->n_mix), "r0h_eval_check: NULL globals");
+  R0H_REQUIRE(po2 >= 6 && po2 <= R0H_MAX_PO2, "r0h_eval_check: po2 %u outside [6, %u]", po2, R0H_MAX_PO2);
+  const size_t domain = (size_t)4 << po2;
+  const r0h_buf* g[3] = {eval_accum, eval_code, eval_data};
+  for (int k = 0; k < 3; k++) R0H_REQUIRE(domain * c->group_size[k] * 4 <= g[k]->bytes, "r0h_eval_check: group %d buffer too small", k);
+  R0H_REQUIRE(domain * 16 <= check->bytes, "r0h_eval_check: check buffer too small");
+  // parameters: globals, mix, powers of poly_mix, inverse vanishing values
+  std::vector<uint32_t> params(c->n_global + c->n_mix + 4 * (size_t)c->plan.n_pow + 4);
+  uint32_t* p = params.data();
+  for (uint32_t i = 0; i < c->n_global; i++) { R0H_REQUIRE(global[i] < P, "r0h_eval_check: global[%u] not canonical", i); *p++ = global[i]; }
+  for (uint32_t i = 0; i < c->n_mix; i++) { R0H_REQUIRE(mix[i] < P, "r0h_eval_check: mix[%u] not canonical", i); *p++ = mix[i]; }
+  Fp4 pm{{poly_mix[0], poly_mix[1], poly_mix[2], poly_mix[3]}}, cur = fp4_one();
+  for (uint32_t k = 0; k < c->plan.n_pow; k++) { memcpy(p, cur.e, 16); p += 4; cur = cur * pm; }
+  {
+    uint32_t three_n = fpow(enc(3), (uint64_t)1 << po2), w4 = rou_fwd(2), w = ONE;
+    for (int k = 0; k < 4; k++) { *p++ = inv(sub(mul(three_n, w), ONE)); w = mul(w, w4); }
+  }
+  R0H_TRY_HIP(hipMemcpyAsync(c->d_params, params.data(), params.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // params is a host temporary
+  uint32_t* d_check = u32(check);
+  const uint32_t *g0 = u32(g[0]), *g1 = u32(g[1]), *g2 = u32(g[2]);
+  const uint32_t *d_glob = c->d_params, *d_mix = d_glob + c->n_global, *d_pow = d_mix + c->n_mix, *d_van = d_pow + 4 * (size_t)c->plan.n_pow;
+  for (size_t k = 0; k < c->kernels.size(); k++) {
+    uint32_t accumulate = k ? 1u : 0u;
+    void* args[] = {&d_check, &g0, &g1, &g2, &d_glob, &d_mix, &d_pow, &d_van, &po2, &accumulate};
+    R0H_TRY_HIP(hipModuleLaunchKernel(c->kernels[k], (uint32_t)(domain / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+  }
+  if (c->kernels.empty()) R0H_TRY_HIP(hipMemsetAsync(check->ptr, 0, domain * 16, ctx->stream));
+  return nullptr;
+  R0H_GUARD_END
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Parsed circuit blob (include/r0hip_circuit.h) shared by circuit.hip (loading, eval_check) and prover.hip (sequencer).
+#pragma once
+#include "internal.hpp"
+
+namespace r0h {
+
+struct Tap { uint32_t group, offset, back; };
+struct Reg { uint32_t group, offset, first_tap, size, combo; };
+struct Step { uint32_t op, a, b, c; };
+struct CodeCol { uint32_t kind, param; };
+struct DataCol { uint32_t kind, a, b, c, e; };
+struct AccCol { uint32_t first, a, b; };
+struct Term { uint32_t pow, v; std::vector<uint32_t> conds; };
+
+struct Plan {                      // how the constraint program is cut into kernels
+  std::vector<Term> terms;         // flattened, in chain order
+  std::vector<uint32_t> cut;       // kernel k owns terms [cut[k], cut[k+1])
+  uint32_t n_pow = 0;
+};
+
+}  // namespace r0h
+
+struct r0h_circuit {
+  r0h_ctx* ctx = nullptr;
+  uint32_t group_size[3] = {0, 0, 0};
+  std::vector<r0h::Tap> taps;
+  std::vector<r0h::Reg> regs;
+  std::vector<uint32_t> combo_begin, combo_backs;
+  uint32_t group_tap_begin[4] = {0, 0, 0, 0};
+  uint32_t n_global = 0, n_mix = 0;
+  std::vector<uint32_t> global_cols;
+  std::vector<r0h::Step> steps;
+  uint32_t ret = 0;
+  std::vector<uint32_t> fp_step, mix_step;  // variable index -> step index
+  std::vector<r0h::CodeCol> code_cols;
+  std::vector<r0h::DataCol> data_cols;
+  std::vector<r0h::AccCol> acc_cols;
+  std::vector<uint32_t> blob;
+  r0h::Plan plan;
+  hipModule_t module = nullptr;
+  std::vector<hipFunction_t> kernels;
+  uint32_t* d_params = nullptr;  // device: [n_global globals][n_mix mix][4*n_pow mixpow][4 inv_van]
+};
+

@@ -1,0 +1,257 @@
+// Context, device buffers, error strings, constant tables.
+// Replaces the host-side glue of risc0-zkp 3.0.4 hal/{cuda,metal}.rs (`alloc_elem`, `copy_from_*`, buffer slicing) and
+// risc0-sys 1.5.0's C-string error convention.
+#include <stdarg.h>
+
+#include <exception>
+
+#include "../../include/r0hip_poseidon2_consts.h"
+#include "internal.hpp"
+
+namespace r0h {
+
+const char* make_error(const char* fmt, ...) {
+  char tmp[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tmp, sizeof tmp, fmt, ap);
+  va_end(ap);
+  char* out = (char*)malloc(strlen(tmp) + 1);
+  if (!out) return "r0hip: out of memory while formatting an error";
+  strcpy(out, tmp);
+  return out;
+}
+
+static void fill_p2(P2Consts& k, const uint32_t* rc, const uint32_t* diag) {
+  int fr = 0, pr = 0;
+  for (int r = 0; r < P2_ROUNDS; r++) {
+    bool full = r < P2_HALF_FULL || r >= P2_HALF_FULL + P2_PARTIAL;
+    if (full) {
+      for (int i = 0; i < P2_CELLS; i++) k.rc_full[fr][i] = enc(rc[r * P2_CELLS + i]);
+      fr++;
+    } else {
+      k.rc_partial[pr++] = enc(rc[r * P2_CELLS]);
+    }
+  }
+  for (int i = 0; i < P2_CELLS; i++) k.diag[i] = enc(diag[i]);
+}
+
+static inline uint32_t sbox7(uint32_t x) {
+  uint32_t x2 = mul(x, x), x4 = mul(x2, x2);
+  return mul(mul(x4, x2), x);
+}
+static void m_ext_host(uint32_t* c) {
+  uint32_t col[4] = {0, 0, 0, 0};
+  for (int k = 0; k < P2_CELLS; k += 4) {
+    uint32_t a = c[k], b = c[k + 1], d = c[k + 2], e = c[k + 3];
+    uint32_t t0 = add(a, b), t1 = add(d, e);
+    uint32_t t2 = add(add(b, b), t1), t3 = add(add(e, e), t0);
+    uint32_t t4 = add(add(add(t1, t1), add(t1, t1)), t3), t5 = add(add(add(t0, t0), add(t0, t0)), t2);
+    c[k] = add(t3, t5); c[k + 1] = t5; c[k + 2] = add(t2, t4); c[k + 3] = t4;
+    for (int j = 0; j < 4; j++) col[j] = add(col[j], c[k + j]);
+  }
+  for (int i = 0; i < P2_CELLS; i++) c[i] = add(c[i], col[i & 3]);
+}
+void p2_mix_host(const P2Consts& k, uint32_t* c) {
+  m_ext_host(c);
+  for (int r = 0; r < P2_HALF_FULL; r++) {
+    for (int i = 0; i < P2_CELLS; i++) c[i] = sbox7(add(c[i], k.rc_full[r][i]));
+    m_ext_host(c);
+  }
+  for (int r = 0; r < P2_PARTIAL; r++) {
+    c[0] = sbox7(add(c[0], k.rc_partial[r]));
+    uint32_t sum = 0;
+    for (int i = 0; i < P2_CELLS; i++) sum = add(sum, c[i]);
+    for (int i = 0; i < P2_CELLS; i++) c[i] = add(sum, mul(k.diag[i], c[i]));
+  }
+  for (int r = P2_HALF_FULL; r < 2 * P2_HALF_FULL; r++) {
+    for (int i = 0; i < P2_CELLS; i++) c[i] = sbox7(add(c[i], k.rc_full[r][i]));
+    m_ext_host(c);
+  }
+}
+void p2_hash_elems_host(const P2Consts& k, const uint32_t* elems, size_t n, uint32_t digest[8]) {
+  uint32_t st[P2_CELLS] = {0};
+  size_t used = 0;
+  for (size_t i = 0; i < n; i++) {
+    st[used++] = elems[i];
+    if (used == P2_RATE) { p2_mix_host(k, st); used = 0; }
+  }
+  if (used != 0 || n == 0) {
+    for (size_t i = used; i < P2_RATE; i++) st[i] = 0;
+    p2_mix_host(k, st);
+  }
+  memcpy(digest, st, 32);
+}
+
+const char* ensure_scratch(r0h_ctx* ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return nullptr;
+  if (ctx->scratch) {
+    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    R0H_TRY_HIP(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  R0H_TRY_HIP(hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return nullptr;
+}
+
+static const char* upload_pow_table(uint32_t** dst, uint32_t base, uint32_t n) {
+  std::vector<uint32_t> t(n);
+  uint32_t cur = ONE;
+  for (uint32_t i = 0; i < n; i++) { t[i] = cur; cur = mul(cur, base); }
+  R0H_TRY_HIP(hipMalloc((void**)dst, n * 4));
+  R0H_TRY_HIP(hipMemcpy(*dst, t.data(), n * 4, hipMemcpyHostToDevice));
+  return nullptr;
+}
+
+}  // namespace r0h
+
+using namespace r0h;
+
+extern "C" {
+
+void r0h_free_error(const char* msg) { free((void*)msg); }
+const char* r0h_version(void) { return "r0hip 0.1 (gfx950)"; }
+
+const char* r0h_ctx_create(int device, r0h_ctx** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(out, "r0h_ctx_create: out is NULL");
+  int n = 0;
+  R0H_TRY_HIP(hipGetDeviceCount(&n));
+  R0H_REQUIRE(device >= 0 && device < n, "r0h_ctx_create: device %d not present (%d visible); no CPU fallback exists", device, n);
+  R0H_TRY_HIP(hipSetDevice(device));
+  r0h_ctx* ctx = new r0h_ctx();
+  ctx->device = device;
+  R0H_TRY_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (int d = 0; d < 2; d++) {
+    uint32_t w22 = d == 0 ? rou_fwd(MAX_DOMAIN_PO2) : rou_rev(MAX_DOMAIN_PO2);
+    R0H_TRY(upload_pow_table(&ctx->tw_lo[d], w22, TW_SIZE));
+    R0H_TRY(upload_pow_table(&ctx->tw_hi[d], fpow(w22, TW_SIZE), TW_SIZE));
+    R0H_TRY(upload_pow_table(&ctx->tw12[d], d == 0 ? rou_fwd(12) : rou_rev(12), 2048));
+  }
+  R0H_TRY(upload_pow_table(&ctx->pow3_lo, enc(3), TW_SIZE));
+  R0H_TRY(upload_pow_table(&ctx->pow3_hi, fpow(enc(3), TW_SIZE), TW_SIZE));
+  R0H_TRY_HIP(hipMalloc((void**)&ctx->p2, sizeof(P2Consts)));
+  fill_p2(ctx->p2_host, R0H_P2_ROUND_CONSTANTS, R0H_P2_INT_DIAG_M1);
+  R0H_TRY_HIP(hipMemcpy(ctx->p2, &ctx->p2_host, sizeof(P2Consts), hipMemcpyHostToDevice));
+  ctx->pinned_bytes = 8u << 20;
+  R0H_TRY_HIP(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+  R0H_TRY(ensure_scratch(ctx, 4u << 20));
+  *out = ctx;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_ctx_destroy(r0h_ctx* ctx) {
+  if (!ctx) return nullptr;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (int d = 0; d < 2; d++) { hipFree(ctx->tw_lo[d]); hipFree(ctx->tw_hi[d]); hipFree(ctx->tw12[d]); }
+  hipFree(ctx->pow3_lo); hipFree(ctx->pow3_hi); hipFree(ctx->p2); hipFree(ctx->scratch);
+  hipHostFree(ctx->pinned);
+  for (hipEvent_t e : ctx->prof.events) hipEventDestroy(e);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return nullptr;
+}
+
+const char* r0h_sync(r0h_ctx* ctx) {
+  R0H_REQUIRE(ctx, "r0h_sync: ctx is NULL");
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  return nullptr;
+}
+
+const char* r0h_poseidon2_set_consts(r0h_ctx* ctx, const uint32_t* rc, const uint32_t* diag_m1) {
+  R0H_REQUIRE(ctx && rc && diag_m1, "r0h_poseidon2_set_consts: NULL argument");
+  for (int i = 0; i < P2_CELLS * P2_ROUNDS; i++) R0H_REQUIRE(rc[i] < P, "round constant %d not canonical", i);
+  for (int i = 0; i < P2_CELLS; i++) R0H_REQUIRE(diag_m1[i] < P, "diagonal word %d not canonical", i);
+  fill_p2(ctx->p2_host, rc, diag_m1);
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  R0H_TRY_HIP(hipMemcpy(ctx->p2, &ctx->p2_host, sizeof(P2Consts), hipMemcpyHostToDevice));
+  return nullptr;
+}
+
+const char* r0h_buf_alloc(r0h_ctx* ctx, size_t bytes, r0h_buf** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && out, "r0h_buf_alloc: NULL argument");
+  R0H_TRY_HIP(hipSetDevice(ctx->device));
+  r0h_buf* b = new r0h_buf();
+  b->ctx = ctx;
+  b->bytes = bytes;
+  hipError_t e = hipMalloc(&b->ptr, bytes ? bytes : 4);
+  if (e != hipSuccess) {
+    delete b;
+    return make_error("r0h_buf_alloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+  }
+  *out = b;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_buf_wrap(r0h_ctx* ctx, void* device_ptr, size_t bytes, r0h_buf** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && out && device_ptr, "r0h_buf_wrap: NULL argument");
+  r0h_buf* b = new r0h_buf();
+  b->ctx = ctx; b->ptr = device_ptr; b->bytes = bytes; b->owned = false;
+  *out = b;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_buf_slice(r0h_buf* parent, size_t off, size_t bytes, r0h_buf** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(parent && out, "r0h_buf_slice: NULL argument");
+  R0H_REQUIRE(off % 4 == 0 && off + bytes <= parent->bytes, "r0h_buf_slice: [%zu, +%zu) outside a %zu-byte buffer", off, bytes, parent->bytes);
+  r0h_buf* b = new r0h_buf();
+  b->ctx = parent->ctx; b->ptr = (char*)parent->ptr + off; b->bytes = bytes; b->parent = parent; b->owned = false;
+  parent->refs++;
+  *out = b;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_buf_free(r0h_buf* b) {
+  while (b) {
+    if (--b->refs > 0) break;
+    r0h_buf* parent = b->parent;
+    if (b->owned && b->ptr) {
+      hipSetDevice(b->ctx->device);
+      hipStreamSynchronize(b->ctx->stream);
+      hipError_t e = hipFree(b->ptr);
+      if (e != hipSuccess) return make_error("r0h_buf_free: %s", hipGetErrorString(e));
+    }
+    delete b;
+    b = parent;
+  }
+  return nullptr;
+}
+
+const char* r0h_buf_h2d(r0h_ctx* ctx, r0h_buf* dst, size_t off, const void* src, size_t bytes) {
+  R0H_REQUIRE(ctx && dst && (src || !bytes), "r0h_buf_h2d: NULL argument");
+  R0H_REQUIRE(off + bytes <= dst->bytes, "r0h_buf_h2d: [%zu, +%zu) outside a %zu-byte buffer", off, bytes, dst->bytes);
+  if (!bytes) return nullptr;
+  R0H_TRY_HIP(hipMemcpyAsync((char*)dst->ptr + off, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // src is pageable caller memory: do not outlive the call
+  return nullptr;
+}
+
+const char* r0h_buf_d2h(r0h_ctx* ctx, const r0h_buf* src, size_t off, void* dst, size_t bytes) {
+  R0H_REQUIRE(ctx && src && (dst || !bytes), "r0h_buf_d2h: NULL argument");
+  R0H_REQUIRE(off + bytes <= src->bytes, "r0h_buf_d2h: [%zu, +%zu) outside a %zu-byte buffer", off, bytes, src->bytes);
+  if (!bytes) return nullptr;
+  R0H_TRY_HIP(hipMemcpyAsync(dst, (const char*)src->ptr + off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  return nullptr;
+}
+
+const char* r0h_buf_zero(r0h_ctx* ctx, r0h_buf* buf) {
+  R0H_REQUIRE(ctx && buf, "r0h_buf_zero: NULL argument");
+  R0H_TRY_HIP(hipMemsetAsync(buf->ptr, 0, buf->bytes, ctx->stream));
+  return nullptr;
+}
+
+void* r0h_buf_device_ptr(const r0h_buf* buf) { return buf ? buf->ptr : nullptr; }
+size_t r0h_buf_bytes(const r0h_buf* buf) { return buf ? buf->bytes : 0; }
+
+}  // extern "C"

@@ -1,0 +1,453 @@
+// Streaming operations of the prover for gfx950: polynomial evaluation at extension points, FRI batching mix,
+// FRI fold, extension-field scans (running products, synthetic division) and the small element-wise helpers.
+// Replaces risc0-zkp 3.0.4 hal `batch_evaluate_any`, `mix_poly_coeffs`, `eltwise_{add,copy}_elem`,
+// `eltwise_sum_extelem`, `gather_sample`, `scatter`, `fri_fold`, `prefix_products` and core/poly.rs `poly_divide`
+// (which upstream runs on the host) -- SURVEY.md 8(a) a10, a12-a15.
+// All of these are HBM-bound streams: one pass over the operand, coalesced column reads, 16-byte extension accesses.
+#include <algorithm>
+#include <array>
+#include <map>
+
+#include "internal.hpp"
+
+namespace r0h {
+
+__device__ __forceinline__ Fp4 ld4(const uint32_t* p) {
+  uint4 v = *(const uint4*)p;
+  return Fp4{{v.x, v.y, v.z, v.w}};
+}
+__device__ __forceinline__ void st4(uint32_t* p, const Fp4& v) { *(uint4*)p = make_uint4(v.e[0], v.e[1], v.e[2], v.e[3]); }
+
+static const char* launch_ok(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return make_error("%s: launch failed: %s", what, hipGetErrorString(e));
+  return nullptr;
+}
+
+// ------------------------------------------------------------------ batch_evaluate_any
+// sum_i c[i] x^i = sum_hi B[hi] * (sum_lo c[hi*RL + lo] * A[lo]),  A[lo] = x^lo, B[hi] = x^(hi*RL).
+// A wave owns a row of RL coefficients: each lane keeps its 16 A-values in registers, multiplies base-field
+// coefficients into them (4 products per coefficient), the wave reduces, lane 0 folds in B[hi].
+constexpr uint32_t EVAL_RL_LOG = 10;
+constexpr uint32_t EVAL_BLOCKS = 64;  // partial sums per evaluation
+
+__global__ void eval_tables_kernel(uint32_t* __restrict__ tab, Fp4 x, uint32_t rl, uint32_t rows) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rl) st4(tab + 4 * (size_t)i, fp4_pow(x, i));
+  else if (i < rl + rows) st4(tab + 4 * (size_t)i, fp4_pow(x, (uint64_t)(i - rl) * rl));
+}
+
+__global__ __launch_bounds__(256) void eval_rows_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
+                                                         const uint32_t* __restrict__ which, const uint32_t* __restrict__ tab,
+                                                         uint32_t po2, uint32_t rl_log) {
+  const uint32_t rl = 1u << rl_log, rows = 1u << (po2 - rl_log);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t* poly = coeffs + ((size_t)which[blockIdx.y] << po2);
+  Fp4 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    uint32_t lo = lane + 64 * k;
+    a[k] = lo < rl ? ld4(tab + 4 * (size_t)lo) : fp4_zero();
+  }
+  Fp4 tot = fp4_zero();
+  for (uint32_t hi = blockIdx.x * 4 + wave; hi < rows; hi += gridDim.x * 4) {
+    const uint32_t* row = poly + ((size_t)hi << rl_log);
+    Fp4 s = fp4_zero();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      uint32_t lo = lane + 64 * k;
+      if (lo < rl) s = s + scale(a[k], row[lo]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      Fp4 o;
+#pragma unroll
+      for (int q = 0; q < 4; q++) o.e[q] = __shfl_xor(s.e[q], off);
+      s = s + o;
+    }
+    if (lane == 0) tot = tot + s * ld4(tab + 4 * (size_t)(rl + hi));
+  }
+  __shared__ uint32_t red[4][4];
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[wave][q] = tot.e[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fp4 r = fp4_zero();
+    for (int w = 0; w < 4; w++) r = r + Fp4{{red[w][0], red[w][1], red[w][2], red[w][3]}};
+    st4(partial + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x), r);
+  }
+}
+
+__global__ void eval_reduce_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ partial,
+                                   const uint32_t* __restrict__ dest, uint32_t n_partial, uint32_t n) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  Fp4 r = fp4_zero();
+  for (uint32_t b = 0; b < n_partial; b++) r = r + ld4(partial + 4 * ((size_t)k * n_partial + b));
+  st4(out + 4 * (size_t)dest[k], r);
+}
+
+// ------------------------------------------------------------------ mix_poly_coeffs
+// combos[combo][i] += sum_{c in combo} mixpow[c] * input[c][i]; columns arrive sorted by combo.
+__global__ __launch_bounds__(256) void mix_poly_kernel(uint32_t* __restrict__ combos, const uint32_t* __restrict__ input,
+                                                        const uint32_t* __restrict__ params, uint32_t n_groups, uint32_t po2) {
+  // params: [n_groups+1 group starts][per sorted column: col index][per group: combo id][per sorted column: 4 words mixpow]
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t* start = params;
+  const uint32_t total = start[n_groups];
+  const uint32_t* cols = params + n_groups + 1;
+  const uint32_t* combo_id = cols + total;
+  const uint32_t* pw = combo_id + n_groups;
+  for (uint32_t g = 0; g < n_groups; g++) {
+    Fp4 acc = fp4_zero();
+    for (uint32_t k = start[g]; k < start[g + 1]; k++) {
+      Fp4 m = Fp4{{pw[4 * k], pw[4 * k + 1], pw[4 * k + 2], pw[4 * k + 3]}};
+      acc = acc + scale(m, input[((size_t)cols[k] << po2) + i]);
+    }
+    uint32_t* dst = combos + 4 * (((size_t)combo_id[g] << po2) + i);
+    st4(dst, ld4(dst) + acc);
+  }
+}
+
+// ------------------------------------------------------------------ small element-wise kernels
+__global__ void add_elem_kernel(uint32_t* out, const uint32_t* a, const uint32_t* b, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = add(a[i], b[i]);
+}
+__global__ void copy_elem_kernel(uint32_t* out, const uint32_t* in, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void sum_extelem_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint32_t count, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp4 tot = fp4_zero();
+  for (uint32_t c = 0; c < count; c++) tot = tot + ld4(in + 4 * ((size_t)c * n + i));
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[(size_t)k * n + i] = tot.e[k];
+}
+__global__ void gather_sample_kernel(uint32_t* dst, const uint32_t* src, uint32_t idx, uint32_t size, uint32_t stride) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < size) dst[i] = src[(size_t)i * stride + idx];
+}
+__global__ void scatter_kernel(uint32_t* into, const uint32_t* offsets, const uint32_t* values, uint32_t begin, uint32_t end) {
+  uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < end) into[offsets[k]] = values[k];
+}
+
+// ------------------------------------------------------------------ fri_fold
+__global__ void fri_fold_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, Fp4 mix, uint32_t n_out) {
+  uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_out) return;
+  const size_t n_in = (size_t)n_out * R0H_FRI_FOLD;
+  Fp4 tot = fp4_zero(), cur = fp4_one();
+#pragma unroll
+  for (uint32_t j = 0; j < R0H_FRI_FOLD; j++) {
+    size_t src = (size_t)(__brev(j) >> 28) * n_out + idx;
+    Fp4 v = Fp4{{in[src], in[n_in + src], in[2 * n_in + src], in[3 * n_in + src]}};
+    tot = tot + cur * v;
+    cur = cur * mix;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[(size_t)k * n_out + idx] = tot.e[k];
+}
+
+// ------------------------------------------------------------------ extension-field scans
+// Both scans use chunks of `threads * E` elements: per-chunk summary, a serial pass over the (few) chunk summaries,
+// then the in-chunk pass with a Hillis-Steele scan across the block's threads.
+struct ScanGeom {
+  uint32_t threads, E, chunk, n_chunks;
+};
+static ScanGeom scan_geom(uint32_t n) {
+  ScanGeom g;
+  g.threads = n < 256 ? n : 256;
+  g.chunk = n < 4096 ? n : 4096;
+  g.E = g.chunk / g.threads;
+  g.n_chunks = n / g.chunk;
+  return g;
+}
+
+// running product: io[i] = prod_{j<=i} io[j]
+__global__ void prefix_chunk_prod_kernel(uint32_t* __restrict__ chunk_prod, const uint32_t* __restrict__ io, uint32_t E) {
+  extern __shared__ uint32_t sh[];
+  const uint32_t t = threadIdx.x, nt = blockDim.x;
+  const uint32_t* p = io + 4 * ((size_t)blockIdx.x * nt * E + (size_t)t * E);
+  Fp4 v = fp4_one();
+  for (uint32_t k = 0; k < E; k++) v = v * ld4(p + 4 * k);
+  st4(sh + 4 * t, v);
+  __syncthreads();
+  for (uint32_t s = nt / 2; s >= 1; s >>= 1) {
+    if (t < s) st4(sh + 4 * t, ld4(sh + 4 * t) * ld4(sh + 4 * (t + s)));
+    __syncthreads();
+  }
+  if (t == 0) st4(chunk_prod + 4 * (size_t)blockIdx.x, ld4(sh));
+}
+__global__ void prefix_chunk_scan_kernel(uint32_t* chunk_prod, uint32_t n_chunks) {
+  if (blockIdx.x || threadIdx.x) return;
+  Fp4 cur = fp4_one();
+  for (uint32_t b = 0; b < n_chunks; b++) {  // exclusive scan in place
+    Fp4 v = ld4(chunk_prod + 4 * (size_t)b);
+    st4(chunk_prod + 4 * (size_t)b, cur);
+    cur = cur * v;
+  }
+}
+__global__ void prefix_apply_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ chunk_excl, uint32_t E) {
+  extern __shared__ uint32_t sh[];
+  const uint32_t t = threadIdx.x, nt = blockDim.x;
+  uint32_t* p = io + 4 * ((size_t)blockIdx.x * nt * E + (size_t)t * E);
+  Fp4 v = fp4_one();
+  for (uint32_t k = 0; k < E; k++) v = v * ld4(p + 4 * k);
+  st4(sh + 4 * t, v);
+  __syncthreads();
+  for (uint32_t s = 1; s < nt; s <<= 1) {  // inclusive scan over threads
+    Fp4 o = t >= s ? ld4(sh + 4 * (t - s)) : fp4_one();
+    __syncthreads();
+    if (t >= s) st4(sh + 4 * t, ld4(sh + 4 * t) * o);
+    __syncthreads();
+  }
+  Fp4 cur = ld4(chunk_excl + 4 * (size_t)blockIdx.x);
+  if (t > 0) cur = cur * ld4(sh + 4 * (t - 1));
+  for (uint32_t k = 0; k < E; k++) {
+    cur = cur * ld4(p + 4 * k);
+    st4(p + 4 * k, cur);
+  }
+}
+
+// synthetic division by (x - z): q[i] = sum_{j>i} p[j] z^(j-i-1), remainder = sum_j p[j] z^j
+struct DivPowers {
+  Fp4 z, zE, zChunk;  // z, z^E, z^chunk
+};
+__global__ void divide_chunk_sum_kernel(uint32_t* __restrict__ chunk_val, const uint32_t* __restrict__ poly, DivPowers pw, uint32_t E) {
+  extern __shared__ uint32_t sh[];
+  const uint32_t t = threadIdx.x, nt = blockDim.x;
+  const uint32_t* p = poly + 4 * ((size_t)blockIdx.x * nt * E + (size_t)t * E);
+  Fp4 v = fp4_zero();
+  for (uint32_t k = E; k-- > 0;) v = v * pw.z + ld4(p + 4 * k);  // sum_k p[k] z^k
+  st4(sh + 4 * t, v);
+  __syncthreads();
+  // V = sum_t v_t z^(E t): pairwise combine with growing powers
+  Fp4 step = pw.zE;
+  for (uint32_t s = 1; s < nt; s <<= 1) {
+    if ((t & (2 * s - 1)) == 0) st4(sh + 4 * t, ld4(sh + 4 * t) + ld4(sh + 4 * (t + s)) * step);
+    step = step * step;
+    __syncthreads();
+  }
+  if (t == 0) st4(chunk_val + 4 * (size_t)blockIdx.x, ld4(sh));
+}
+// carry[b] = sum_{b' > b} S_b' z^((b'-b-1)*chunk), serial from the top
+__global__ void divide_chunk_carry_kernel(uint32_t* chunk_val, DivPowers pw, uint32_t n_chunks) {
+  if (blockIdx.x || threadIdx.x) return;
+  Fp4 cur = fp4_zero();
+  for (uint32_t b = n_chunks; b-- > 0;) {
+    Fp4 s = ld4(chunk_val + 4 * (size_t)b);
+    st4(chunk_val + 4 * (size_t)b, cur);
+    cur = cur * pw.zChunk + s;
+  }
+  st4(chunk_val + 4 * (size_t)n_chunks, cur);  // remainder
+}
+__global__ void divide_apply_kernel(uint32_t* __restrict__ poly, const uint32_t* __restrict__ chunk_carry, DivPowers pw, uint32_t E) {
+  extern __shared__ uint32_t sh[];
+  const uint32_t t = threadIdx.x, nt = blockDim.x;
+  uint32_t* p = poly + 4 * ((size_t)blockIdx.x * nt * E + (size_t)t * E);
+  Fp4 v = fp4_zero();
+  for (uint32_t k = E; k-- > 0;) v = v * pw.z + ld4(p + 4 * k);
+  st4(sh + 4 * t, v);
+  __syncthreads();
+  // suffix scan over threads: after it sh[t] = sum_{t' >= t} v_t' z^(E (t'-t))
+  Fp4 step = pw.zE;
+  for (uint32_t s = 1; s < nt; s <<= 1) {
+    Fp4 o = t + s < nt ? ld4(sh + 4 * (t + s)) : fp4_zero();
+    __syncthreads();
+    if (t + s < nt) st4(sh + 4 * t, ld4(sh + 4 * t) + o * step);
+    step = step * step;
+    __syncthreads();
+  }
+  // carry entering this thread's range from above: threads above it, then the chunks above the block
+  Fp4 zpow = fp4_pow(pw.zE, nt - 1 - t);
+  Fp4 cur = ld4(chunk_carry + 4 * (size_t)blockIdx.x) * zpow;
+  if (t + 1 < nt) cur = cur + ld4(sh + 4 * (t + 1));
+  for (uint32_t k = E; k-- > 0;) {
+    Fp4 next = cur * pw.z + ld4(p + 4 * k);
+    st4(p + 4 * k, cur);
+    cur = next;
+  }
+}
+
+static Fp4 host_fp4(const uint32_t v[4]) { return Fp4{{v[0], v[1], v[2], v[3]}}; }
+
+}  // namespace r0h
+
+using namespace r0h;
+
+extern "C" {
+
+const char* r0h_batch_evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, const uint32_t* which,
+                                   const uint32_t* xs, uint32_t n_eval, r0h_buf* out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && coeffs && out && (n_eval == 0 || (which && xs)), "r0h_batch_evaluate_any: NULL argument");
+  R0H_REQUIRE(po2 <= MAX_DOMAIN_PO2, "r0h_batch_evaluate_any: po2 %u too large", po2);
+  R0H_REQUIRE((size_t)n_eval * 16 <= out->bytes, "r0h_batch_evaluate_any: %u results exceed the output buffer", n_eval);
+  if (!n_eval) return nullptr;
+  const size_t n_polys = coeffs->bytes >> (po2 + 2);
+  // group evaluations by their point: the power tables are shared by every polynomial evaluated at the same x
+  std::map<std::array<uint32_t, 4>, std::vector<uint32_t>> groups;
+  for (uint32_t k = 0; k < n_eval; k++) {
+    R0H_REQUIRE(which[k] < n_polys, "r0h_batch_evaluate_any: which[%u] = %u but the buffer holds %zu polynomials", k, which[k], n_polys);
+    for (int q = 0; q < 4; q++) R0H_REQUIRE(xs[4 * k + q] < P, "r0h_batch_evaluate_any: xs[%u] not canonical", k);
+    groups[{xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]}].push_back(k);
+  }
+  const uint32_t rl_log = po2 < EVAL_RL_LOG ? po2 : EVAL_RL_LOG, rl = 1u << rl_log, rows = 1u << (po2 - rl_log);
+  uint32_t blocks = (rows + 3) / 4;
+  if (blocks > EVAL_BLOCKS) blocks = EVAL_BLOCKS;
+  const size_t tab_words = 4 * (size_t)(rl + rows), idx_words = 2 * (size_t)n_eval, part_words = 4 * (size_t)n_eval * blocks;
+  R0H_TRY(ensure_scratch(ctx, (tab_words + idx_words + part_words) * 4));
+  uint32_t* tab = (uint32_t*)ctx->scratch;
+  uint32_t* idx = tab + tab_words;
+  uint32_t* part = idx + idx_words;
+  for (auto& g : groups) {
+    const uint32_t ng = (uint32_t)g.second.size();
+    std::vector<uint32_t> host(2 * ng);
+    for (uint32_t k = 0; k < ng; k++) { host[k] = which[g.second[k]]; host[ng + k] = g.second[k]; }
+    R0H_TRY_HIP(hipMemcpyAsync(idx, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    Fp4 x = Fp4{{g.first[0], g.first[1], g.first[2], g.first[3]}};
+    hipLaunchKernelGGL(eval_tables_kernel, dim3((rl + rows + 255) / 256), dim3(256), 0, ctx->stream, tab, x, rl, rows);
+    hipLaunchKernelGGL(eval_rows_kernel, dim3(blocks, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log);
+    hipLaunchKernelGGL(eval_reduce_kernel, dim3((ng + 63) / 64), dim3(64), 0, ctx->stream, u32(out), part, idx + ng, blocks, ng);
+    R0H_TRY(launch_ok("batch_evaluate_any kernels"));
+    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // host vectors and the shared scratch are reused per group
+  }
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_mix_poly_coeffs(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mix_start[4], const uint32_t mix[4],
+                                const r0h_buf* input, const uint32_t* combo_of, uint32_t input_count, uint32_t po2) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && combos && input && mix_start && mix && (combo_of || !input_count), "r0h_mix_poly_coeffs: NULL argument");
+  R0H_REQUIRE(po2 <= MAX_DOMAIN_PO2, "r0h_mix_poly_coeffs: po2 %u too large", po2);
+  R0H_REQUIRE(((size_t)input_count << po2) * 4 <= input->bytes, "r0h_mix_poly_coeffs: %u columns exceed the input buffer", input_count);
+  if (!input_count) return nullptr;
+  std::vector<uint32_t> order(input_count);
+  for (uint32_t c = 0; c < input_count; c++) {
+    R0H_REQUIRE((((size_t)combo_of[c] + 1) << po2) * 16 <= combos->bytes, "r0h_mix_poly_coeffs: combo %u outside the combos buffer", combo_of[c]);
+    order[c] = c;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return combo_of[a] < combo_of[b]; });
+  std::vector<Fp4> pw(input_count);
+  Fp4 cur = host_fp4(mix_start), m = host_fp4(mix);
+  for (uint32_t c = 0; c < input_count; c++) { pw[c] = cur; cur = cur * m; }
+  std::vector<uint32_t> starts, ids;
+  for (uint32_t k = 0; k < input_count; k++)
+    if (k == 0 || combo_of[order[k]] != combo_of[order[k - 1]]) { starts.push_back(k); ids.push_back(combo_of[order[k]]); }
+  const uint32_t n_groups = (uint32_t)ids.size();
+  starts.push_back(input_count);
+  std::vector<uint32_t> params;
+  params.insert(params.end(), starts.begin(), starts.end());
+  params.insert(params.end(), order.begin(), order.end());
+  params.insert(params.end(), ids.begin(), ids.end());
+  for (uint32_t k = 0; k < input_count; k++)
+    for (int q = 0; q < 4; q++) params.push_back(pw[order[k]].e[q]);
+  R0H_TRY(ensure_scratch(ctx, params.size() * 4));
+  R0H_TRY_HIP(hipMemcpyAsync(ctx->scratch, params.data(), params.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t n = 1u << po2, threads = n < 256 ? n : 256;
+  hipLaunchKernelGGL(mix_poly_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(combos), u32(input), (const uint32_t*)ctx->scratch, n_groups, po2);
+  R0H_TRY(launch_ok("mix_poly_kernel"));
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // params live in shared scratch and a host vector
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_eltwise_add_elem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* a, const r0h_buf* b, uint32_t n) {
+  R0H_REQUIRE(ctx && out && a && b, "r0h_eltwise_add_elem: NULL argument");
+  R0H_REQUIRE((size_t)n * 4 <= out->bytes && (size_t)n * 4 <= a->bytes && (size_t)n * 4 <= b->bytes, "r0h_eltwise_add_elem: n %u exceeds a buffer", n);
+  if (!n) return nullptr;
+  hipLaunchKernelGGL(add_elem_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, u32(out), u32(a), u32(b), n);
+  return launch_ok("add_elem_kernel");
+}
+const char* r0h_eltwise_copy_elem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t n) {
+  R0H_REQUIRE(ctx && out && in, "r0h_eltwise_copy_elem: NULL argument");
+  R0H_REQUIRE((size_t)n * 4 <= out->bytes && (size_t)n * 4 <= in->bytes, "r0h_eltwise_copy_elem: n %u exceeds a buffer", n);
+  if (!n) return nullptr;
+  hipLaunchKernelGGL(copy_elem_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, u32(out), u32(in), n);
+  return launch_ok("copy_elem_kernel");
+}
+const char* r0h_eltwise_sum_extelem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t count, uint32_t n) {
+  R0H_REQUIRE(ctx && out && in, "r0h_eltwise_sum_extelem: NULL argument");
+  R0H_REQUIRE((size_t)n * 16 <= out->bytes && (size_t)n * count * 16 <= in->bytes, "r0h_eltwise_sum_extelem: sizes exceed a buffer");
+  if (!n) return nullptr;
+  hipLaunchKernelGGL(sum_extelem_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, u32(out), u32(in), count, n);
+  return launch_ok("sum_extelem_kernel");
+}
+const char* r0h_gather_sample(r0h_ctx* ctx, r0h_buf* dst, const r0h_buf* src, uint32_t idx, uint32_t size, uint32_t stride) {
+  R0H_REQUIRE(ctx && dst && src, "r0h_gather_sample: NULL argument");
+  R0H_REQUIRE((size_t)size * 4 <= dst->bytes, "r0h_gather_sample: size %u exceeds dst", size);
+  R0H_REQUIRE(size == 0 || ((size_t)(size - 1) * stride + idx + 1) * 4 <= src->bytes, "r0h_gather_sample: reads past src");
+  if (!size) return nullptr;
+  hipLaunchKernelGGL(gather_sample_kernel, dim3((size + 255) / 256), dim3(256), 0, ctx->stream, u32(dst), u32(src), idx, size, stride);
+  return launch_ok("gather_sample_kernel");
+}
+const char* r0h_scatter(r0h_ctx* ctx, r0h_buf* into, const r0h_buf* index, const r0h_buf* offsets, const r0h_buf* values, uint32_t n_index) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && into && index && offsets && values, "r0h_scatter: NULL argument");
+  if (n_index < 2) return nullptr;
+  R0H_REQUIRE((size_t)n_index * 4 <= index->bytes, "r0h_scatter: n_index exceeds the index buffer");
+  std::vector<uint32_t> idx(n_index);
+  R0H_TRY(r0h_buf_d2h(ctx, index, 0, idx.data(), (size_t)n_index * 4));
+  uint32_t begin = idx[0], end = idx[n_index - 1];
+  R0H_REQUIRE(begin <= end && (size_t)end * 4 <= offsets->bytes && (size_t)end * 4 <= values->bytes, "r0h_scatter: index range [%u, %u) outside offsets/values", begin, end);
+  std::vector<uint32_t> offs(end - begin);
+  if (end > begin) {
+    R0H_TRY(r0h_buf_d2h(ctx, offsets, (size_t)begin * 4, offs.data(), (size_t)(end - begin) * 4));
+    for (uint32_t o : offs) R0H_REQUIRE((size_t)o * 4 < into->bytes, "r0h_scatter: offset %u outside the destination", o);
+    hipLaunchKernelGGL(scatter_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, ctx->stream, u32(into), u32(offsets), u32(values), begin, end);
+  }
+  return launch_ok("scatter_kernel");
+  R0H_GUARD_END
+}
+
+const char* r0h_fri_fold(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, const uint32_t mix[4], uint32_t n_out) {
+  R0H_REQUIRE(ctx && out && in && mix, "r0h_fri_fold: NULL argument");
+  R0H_REQUIRE((size_t)n_out * 16 <= out->bytes && (size_t)n_out * 16 * R0H_FRI_FOLD <= in->bytes, "r0h_fri_fold: n_out %u exceeds a buffer", n_out);
+  if (!n_out) return nullptr;
+  hipLaunchKernelGGL(fri_fold_kernel, dim3((n_out + 255) / 256), dim3(256), 0, ctx->stream, u32(out), u32(in), host_fp4(mix), n_out);
+  return launch_ok("fri_fold_kernel");
+}
+
+const char* r0h_prefix_products(r0h_ctx* ctx, r0h_buf* io, uint32_t n) {
+  R0H_REQUIRE(ctx && io, "r0h_prefix_products: NULL argument");
+  R0H_REQUIRE(n && (n & (n - 1)) == 0, "r0h_prefix_products: n %u is not a power of two", n);
+  R0H_REQUIRE((size_t)n * 16 <= io->bytes, "r0h_prefix_products: n %u exceeds the buffer", n);
+  const ScanGeom g = scan_geom(n);
+  R0H_TRY(ensure_scratch(ctx, (size_t)(g.n_chunks + 1) * 16));
+  uint32_t* cp = (uint32_t*)ctx->scratch;
+  hipLaunchKernelGGL(prefix_chunk_prod_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, cp, u32(io), g.E);
+  hipLaunchKernelGGL(prefix_chunk_scan_kernel, dim3(1), dim3(1), 0, ctx->stream, cp, g.n_chunks);
+  hipLaunchKernelGGL(prefix_apply_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, u32(io), cp, g.E);
+  return launch_ok("prefix_products kernels");
+}
+
+const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint32_t z[4], uint32_t remainder[4]) {
+  R0H_REQUIRE(ctx && poly && z, "r0h_poly_divide: NULL argument");
+  R0H_REQUIRE(n && (n & (n - 1)) == 0, "r0h_poly_divide: n %u is not a power of two", n);
+  R0H_REQUIRE((size_t)n * 16 <= poly->bytes, "r0h_poly_divide: n %u exceeds the buffer", n);
+  const ScanGeom g = scan_geom(n);
+  DivPowers pw;
+  pw.z = host_fp4(z);
+  pw.zE = fp4_pow(pw.z, g.E);
+  pw.zChunk = fp4_pow(pw.z, g.chunk);
+  R0H_TRY(ensure_scratch(ctx, (size_t)(g.n_chunks + 1) * 16));
+  uint32_t* cv = (uint32_t*)ctx->scratch;
+  hipLaunchKernelGGL(divide_chunk_sum_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, cv, u32(poly), pw, g.E);
+  hipLaunchKernelGGL(divide_chunk_carry_kernel, dim3(1), dim3(1), 0, ctx->stream, cv, pw, g.n_chunks);
+  hipLaunchKernelGGL(divide_apply_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, u32(poly), cv, pw, g.E);
+  R0H_TRY(launch_ok("poly_divide kernels"));
+  if (remainder) {
+    R0H_TRY_HIP(hipMemcpyAsync(remainder, cv + 4 * (size_t)g.n_chunks, 16, hipMemcpyDeviceToHost, ctx->stream));
+    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return nullptr;
+}
+
+}  // extern "C"

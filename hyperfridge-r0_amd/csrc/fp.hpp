@@ -1,0 +1,118 @@
+// BabyBear (p = 15*2^27 + 1) in Montgomery form and its quartic extension, for host and gfx950 device code.
+// Replaces risc0-sys 1.5.0 `fp.h` / `fpext.h` and risc0-zkp 3.0.4 `field/baby_bear.rs`.
+// 31-bit modular integer work on the VALU: one v_mad_u64_u32 for a*b, one v_mul_lo_u32 for the Montgomery
+// quotient, one v_mad_u64_u32 for the reduction, then a branch-free conditional subtract (v_sub + v_min).
+#pragma once
+#include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define R0H_HD __host__ __device__ __forceinline__
+#else
+#define R0H_HD inline
+#endif
+
+namespace r0h {
+
+constexpr uint32_t P = 2013265921u;
+constexpr uint32_t NPINV = 0x77ffffffu;  // -p^-1 mod 2^32
+constexpr uint32_t R2 = 1172168163u;     // 2^64 mod p
+constexpr uint32_t ONE = 268435454u;     // 2^32 mod p
+constexpr uint32_t ROU_GEN = 137u;       // primitive 2^27-th root (canonical)
+constexpr uint32_t BETA_CANON = 11u;
+
+R0H_HD uint32_t reduce1(uint32_t x) {  // x < 2p  ->  x mod p
+  uint32_t y = x - P;
+  return y < x ? y : x;  // min as unsigned: x-P wraps above x when x < P
+}
+R0H_HD uint32_t add(uint32_t a, uint32_t b) { return reduce1(a + b); }
+R0H_HD uint32_t sub(uint32_t a, uint32_t b) {
+  uint32_t d = a - b;
+  return a < b ? d + P : d;
+}
+R0H_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
+R0H_HD uint32_t mul(uint32_t a, uint32_t b) {
+  uint64_t t = (uint64_t)a * b;
+  uint32_t m = (uint32_t)t * NPINV;
+  uint64_t u = t + (uint64_t)m * P;
+  return reduce1((uint32_t)(u >> 32));
+}
+R0H_HD uint32_t enc(uint32_t canonical) { return mul(canonical % P, R2); }
+R0H_HD uint32_t dec(uint32_t a) { return mul(a, 1u); }
+R0H_HD uint32_t fpow(uint32_t a, uint64_t n) {
+  uint32_t r = ONE;
+  while (n) {
+    if (n & 1) r = mul(r, a);
+    a = mul(a, a);
+    n >>= 1;
+  }
+  return r;
+}
+R0H_HD uint32_t inv(uint32_t a) { return fpow(a, P - 2); }
+// 11 in Montgomery form: 11 * 2^32 mod p
+constexpr uint32_t BETA_M = (uint32_t)((11ull << 32) % P);
+
+struct Fp4 {
+  uint32_t e[4];
+};
+R0H_HD Fp4 fp4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return Fp4{{a, b, c, d}}; }
+R0H_HD Fp4 fp4_zero() { return Fp4{{0, 0, 0, 0}}; }
+R0H_HD Fp4 fp4_one() { return Fp4{{ONE, 0, 0, 0}}; }
+R0H_HD bool operator==(const Fp4& a, const Fp4& b) {
+  return a.e[0] == b.e[0] && a.e[1] == b.e[1] && a.e[2] == b.e[2] && a.e[3] == b.e[3];
+}
+R0H_HD Fp4 operator+(const Fp4& a, const Fp4& b) {
+  return Fp4{{add(a.e[0], b.e[0]), add(a.e[1], b.e[1]), add(a.e[2], b.e[2]), add(a.e[3], b.e[3])}};
+}
+R0H_HD Fp4 operator-(const Fp4& a, const Fp4& b) {
+  return Fp4{{sub(a.e[0], b.e[0]), sub(a.e[1], b.e[1]), sub(a.e[2], b.e[2]), sub(a.e[3], b.e[3])}};
+}
+R0H_HD Fp4 scale(const Fp4& a, uint32_t s) { return Fp4{{mul(a.e[0], s), mul(a.e[1], s), mul(a.e[2], s), mul(a.e[3], s)}}; }
+R0H_HD Fp4 operator*(const Fp4& a, const Fp4& b) {
+  // (a0 + a1 x + a2 x^2 + a3 x^3)(b0 + ...), x^4 = 11
+  uint32_t c0 = mul(a.e[0], b.e[0]);
+  uint32_t c1 = add(mul(a.e[0], b.e[1]), mul(a.e[1], b.e[0]));
+  uint32_t c2 = add(add(mul(a.e[0], b.e[2]), mul(a.e[1], b.e[1])), mul(a.e[2], b.e[0]));
+  uint32_t c3 = add(add(mul(a.e[0], b.e[3]), mul(a.e[1], b.e[2])), add(mul(a.e[2], b.e[1]), mul(a.e[3], b.e[0])));
+  uint32_t c4 = add(add(mul(a.e[1], b.e[3]), mul(a.e[2], b.e[2])), mul(a.e[3], b.e[1]));
+  uint32_t c5 = add(mul(a.e[2], b.e[3]), mul(a.e[3], b.e[2]));
+  uint32_t c6 = mul(a.e[3], b.e[3]);
+  return Fp4{{add(c0, mul(BETA_M, c4)), add(c1, mul(BETA_M, c5)), add(c2, mul(BETA_M, c6)), c3}};
+}
+R0H_HD Fp4 fp4_pow(Fp4 a, uint64_t n) {
+  Fp4 r = fp4_one();
+  while (n) {
+    if (n & 1) r = r * a;
+    a = a * a;
+    n >>= 1;
+  }
+  return r;
+}
+// inverse through the tower Fp2[y]/(y^2 - x) over Fp[x]/(x^2 - 11): a = A + yB, a^-1 = (A - yB)/(A^2 - x B^2)
+R0H_HD Fp4 fp4_inv(const Fp4& a) {
+  uint32_t A0 = a.e[0], A1 = a.e[2], B0 = a.e[1], B1 = a.e[3];
+  uint32_t A2_0 = add(mul(A0, A0), mul(BETA_M, mul(A1, A1))), A2_1 = mul(add(A0, A0), A1);
+  uint32_t B2_0 = add(mul(B0, B0), mul(BETA_M, mul(B1, B1))), B2_1 = mul(add(B0, B0), B1);
+  uint32_t D0 = sub(A2_0, mul(BETA_M, B2_1)), D1 = sub(A2_1, B2_0);
+  uint32_t n = inv(sub(mul(D0, D0), mul(BETA_M, mul(D1, D1))));
+  uint32_t I0 = mul(D0, n), I1 = neg(mul(D1, n));
+  Fp4 r;
+  r.e[0] = add(mul(A0, I0), mul(BETA_M, mul(A1, I1)));
+  r.e[2] = add(mul(A0, I1), mul(A1, I0));
+  r.e[1] = neg(add(mul(B0, I0), mul(BETA_M, mul(B1, I1))));
+  r.e[3] = neg(add(mul(B0, I1), mul(B1, I0)));
+  return r;
+}
+
+R0H_HD uint32_t bitrev(uint32_t x, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return bits ? __brev(x) >> (32 - bits) : 0u;
+#else
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+  return r;
+#endif
+}
+inline uint32_t rou_fwd(uint32_t po2) { return fpow(enc(ROU_GEN), 1ull << (27 - po2)); }
+inline uint32_t rou_rev(uint32_t po2) { return inv(rou_fwd(po2)); }
+
+}  // namespace r0h

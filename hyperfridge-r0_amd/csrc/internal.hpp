@@ -1,0 +1,93 @@
+// Internal definitions shared by the translation units of libr0hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/r0hip.h"
+#include "fp.hpp"
+
+namespace r0h {
+
+const char* make_error(const char* fmt, ...);
+
+#define R0H_TRY_HIP(expr)                                                                              \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess) return r0h::make_error("%s:%d: %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+  } while (0)
+#define R0H_TRY(expr)                \
+  do {                               \
+    const char* m__ = (expr);        \
+    if (m__) return m__;             \
+  } while (0)
+#define R0H_REQUIRE(cond, ...)                        \
+  do {                                                \
+    if (!(cond)) return r0h::make_error(__VA_ARGS__); \
+  } while (0)
+#define R0H_GUARD_BEGIN try {
+#define R0H_GUARD_END \
+  }                   \
+  catch (const std::exception& ex) { return r0h::make_error("exception: %s", ex.what()); } \
+  catch (...) { return r0h::make_error("unknown exception"); }
+
+constexpr int P2_CELLS = 24, P2_RATE = 16, P2_OUT = 8, P2_HALF_FULL = 4, P2_PARTIAL = 21, P2_ROUNDS = 29;
+constexpr uint32_t TW_BITS = 11;            // two-level twiddle tables of 2^11 entries each
+constexpr uint32_t TW_SIZE = 1u << TW_BITS;
+constexpr uint32_t MAX_DOMAIN_PO2 = 22;     // 2^R0H_MAX_PO2 rows x INV_RATE
+
+// Device-resident Poseidon2 tables (Montgomery form).
+struct P2Consts {
+  uint32_t rc_full[2 * P2_HALF_FULL][P2_CELLS];
+  uint32_t rc_partial[P2_PARTIAL];
+  uint32_t diag[P2_CELLS];
+};
+
+struct Profile {
+  std::vector<const char*> names;
+  std::vector<float> ms;
+  std::vector<hipEvent_t> events;  // events[i], events[i+1] bracket phase i
+};
+
+}  // namespace r0h
+
+struct r0h_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // twiddles: tw_lo[d][i] = w^i, tw_hi[d][i] = w^(i*2^11) with w = ROU_{FWD,REV}[22]; d = 0 forward, 1 inverse
+  uint32_t* tw_lo[2] = {nullptr, nullptr};
+  uint32_t* tw_hi[2] = {nullptr, nullptr};
+  // local table: tw12[d][i] = ROU[12]^i for i < 2048
+  uint32_t* tw12[2] = {nullptr, nullptr};
+  uint32_t* pow3_lo = nullptr;  // 3^i, i < 2^11
+  uint32_t* pow3_hi = nullptr;  // 3^(i*2^11), i < 2^11 (covers exponents < 2^22)
+  r0h::P2Consts* p2 = nullptr;  // device
+  r0h::P2Consts p2_host;
+  void* scratch = nullptr;      // small device scratch for scans / partial sums
+  size_t scratch_bytes = 0;
+  void* pinned = nullptr;       // pinned host staging
+  size_t pinned_bytes = 0;
+  r0h::Profile prof;
+};
+
+struct r0h_buf {
+  r0h_ctx* ctx = nullptr;
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  r0h_buf* parent = nullptr;  // slices keep their parent alive
+  int refs = 1;
+  bool owned = true;
+};
+
+namespace r0h {
+inline uint32_t* u32(const r0h_buf* b) { return (uint32_t*)b->ptr; }
+const char* ensure_scratch(r0h_ctx* ctx, size_t bytes);
+// host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table
+void p2_mix_host(const P2Consts& k, uint32_t* cells);
+void p2_hash_elems_host(const P2Consts& k, const uint32_t* elems, size_t n, uint32_t digest[8]);
+}  // namespace r0h

@@ -1,0 +1,153 @@
+// Poseidon2 (BabyBear, t=24, rate 16, x^7, 4+21+4 rounds) row hashing and Merkle folding for gfx950.
+// Replaces risc0-zkp 3.0.4 hal `hash_rows` / `hash_fold` with the poseidon2 hash suite (CUDA side: risc0-sys 1.5.0
+// poseidon2 kernels) -- SURVEY.md 8(a) a6-a8.
+//
+// One lane owns one row (hash_rows) or one parent node (hash_fold): the 24-word state lives in VGPRs, the round
+// constants are wave-uniform and come in through scalar loads, and consecutive lanes read consecutive rows of each
+// column so every column access of a wave is one contiguous 256-byte run.  This kernel is VALU-integer bound
+// (about 1.36k Montgomery products per permutation), not HBM bound: see DESIGN.md for the arithmetic.
+#include "internal.hpp"
+
+namespace r0h {
+
+__device__ __forceinline__ uint32_t sbox7(uint32_t x) {
+  uint32_t x2 = mul(x, x), x4 = mul(x2, x2);
+  return mul(mul(x4, x2), x);
+}
+
+__device__ __forceinline__ void m_ext(uint32_t (&c)[P2_CELLS]) {
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+  for (int k = 0; k < P2_CELLS; k += 4) {
+    uint32_t a = c[k], b = c[k + 1], d = c[k + 2], e = c[k + 3];
+    uint32_t t0 = add(a, b), t1 = add(d, e);
+    uint32_t t2 = add(add(b, b), t1), t3 = add(add(e, e), t0);
+    uint32_t t1x2 = add(t1, t1), t0x2 = add(t0, t0);
+    uint32_t t4 = add(add(t1x2, t1x2), t3), t5 = add(add(t0x2, t0x2), t2);
+    c[k] = add(t3, t5); c[k + 1] = t5; c[k + 2] = add(t2, t4); c[k + 3] = t4;
+    s0 = add(s0, c[k]); s1 = add(s1, c[k + 1]); s2 = add(s2, c[k + 2]); s3 = add(s3, c[k + 3]);
+  }
+#pragma unroll
+  for (int k = 0; k < P2_CELLS; k += 4) {
+    c[k] = add(c[k], s0); c[k + 1] = add(c[k + 1], s1); c[k + 2] = add(c[k + 2], s2); c[k + 3] = add(c[k + 3], s3);
+  }
+}
+
+__device__ __forceinline__ void p2_mix(uint32_t (&c)[P2_CELLS], const P2Consts* __restrict__ k) {
+  m_ext(c);
+#pragma unroll 1
+  for (int r = 0; r < P2_HALF_FULL; r++) {
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; i++) c[i] = sbox7(add(c[i], k->rc_full[r][i]));
+    m_ext(c);
+  }
+#pragma unroll 1
+  for (int r = 0; r < P2_PARTIAL; r++) {
+    c[0] = sbox7(add(c[0], k->rc_partial[r]));
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; i++) sum = add(sum, c[i]);
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; i++) c[i] = add(sum, mul(k->diag[i], c[i]));
+  }
+#pragma unroll 1
+  for (int r = P2_HALF_FULL; r < 2 * P2_HALF_FULL; r++) {
+#pragma unroll
+    for (int i = 0; i < P2_CELLS; i++) c[i] = sbox7(add(c[i], k->rc_full[r][i]));
+    m_ext(c);
+  }
+}
+
+__global__ __launch_bounds__(256) void hash_rows_kernel(uint32_t* __restrict__ digests, const uint32_t* __restrict__ matrix,
+                                                         uint32_t rows, uint32_t cols, const P2Consts* __restrict__ k) {
+  uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  uint32_t c[P2_CELLS];
+#pragma unroll
+  for (int i = 0; i < P2_CELLS; i++) c[i] = 0;
+  const uint32_t* src = matrix + row;
+  uint32_t full = cols / P2_RATE, rem = cols % P2_RATE;
+  for (uint32_t blk = 0; blk < full; blk++) {
+#pragma unroll
+    for (int i = 0; i < P2_RATE; i++) c[i] = src[(size_t)(blk * P2_RATE + i) * rows];
+    p2_mix(c, k);
+  }
+  if (rem != 0 || cols == 0) {
+#pragma unroll
+    for (int i = 0; i < P2_RATE; i++) c[i] = (uint32_t)i < rem ? src[(size_t)(full * P2_RATE + i) * rows] : 0u;
+    p2_mix(c, k);
+  }
+  uint4* dst = (uint4*)(digests + (size_t)row * 8);
+  dst[0] = make_uint4(c[0], c[1], c[2], c[3]);
+  dst[1] = make_uint4(c[4], c[5], c[6], c[7]);
+}
+
+// nodes[i] = H(nodes[2i] || nodes[2i+1]), output_size <= i < 2*output_size
+__global__ __launch_bounds__(256) void hash_fold_kernel(uint32_t* __restrict__ nodes, uint32_t output_size,
+                                                         const P2Consts* __restrict__ k) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= output_size) return;
+  uint32_t i = output_size + t;
+  const uint4* src = (const uint4*)(nodes + (size_t)2 * i * 8);
+  uint32_t c[P2_CELLS];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    uint4 v = src[q];
+    c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int q = 16; q < P2_CELLS; q++) c[q] = 0;
+  p2_mix(c, k);
+  uint4* dst = (uint4*)(nodes + (size_t)i * 8);
+  dst[0] = make_uint4(c[0], c[1], c[2], c[3]);
+  dst[1] = make_uint4(c[4], c[5], c[6], c[7]);
+}
+
+}  // namespace r0h
+
+using namespace r0h;
+
+extern "C" {
+
+const char* r0h_hash_rows(r0h_ctx* ctx, r0h_buf* digests, const r0h_buf* matrix, uint32_t rows, uint32_t cols) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && digests && matrix, "r0h_hash_rows: NULL argument");
+  R0H_REQUIRE((size_t)rows * cols * 4 <= matrix->bytes, "r0h_hash_rows: %u x %u matrix exceeds the buffer", rows, cols);
+  R0H_REQUIRE((size_t)rows * 32 <= digests->bytes, "r0h_hash_rows: %u digests exceed the output buffer", rows);
+  R0H_REQUIRE(((uintptr_t)digests->ptr & 15) == 0, "r0h_hash_rows: digest buffer must be 16-byte aligned");
+  if (!rows) return nullptr;
+  hipLaunchKernelGGL(hash_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, u32(digests), u32(matrix), rows, cols, ctx->p2);
+  hipError_t e = hipGetLastError();
+  R0H_REQUIRE(e == hipSuccess, "hash_rows_kernel: %s", hipGetErrorString(e));
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_hash_fold(r0h_ctx* ctx, r0h_buf* nodes, uint32_t output_size) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && nodes, "r0h_hash_fold: NULL argument");
+  R0H_REQUIRE((size_t)output_size * 4 * 32 <= nodes->bytes, "r0h_hash_fold: output_size %u needs %zu bytes of nodes", output_size, (size_t)output_size * 128);
+  R0H_REQUIRE(((uintptr_t)nodes->ptr & 15) == 0, "r0h_hash_fold: node buffer must be 16-byte aligned");
+  if (!output_size) return nullptr;
+  hipLaunchKernelGGL(hash_fold_kernel, dim3((output_size + 255) / 256), dim3(256), 0, ctx->stream, u32(nodes), output_size, ctx->p2);
+  hipError_t e = hipGetLastError();
+  R0H_REQUIRE(e == hipSuccess, "hash_fold_kernel: %s", hipGetErrorString(e));
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_merkle_build(r0h_ctx* ctx, r0h_buf* nodes, const r0h_buf* matrix, uint32_t rows, uint32_t cols) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && nodes && matrix, "r0h_merkle_build: NULL argument");
+  R0H_REQUIRE(rows && (rows & (rows - 1)) == 0, "r0h_merkle_build: rows %u is not a power of two", rows);
+  R0H_REQUIRE((size_t)rows * 2 * 32 <= nodes->bytes, "r0h_merkle_build: node buffer too small for %u rows", rows);
+  r0h_buf leaves = *nodes;
+  leaves.ptr = (char*)nodes->ptr + (size_t)rows * 32;
+  leaves.bytes = (size_t)rows * 32;
+  R0H_TRY(r0h_hash_rows(ctx, &leaves, matrix, rows, cols));
+  for (uint32_t sz = rows / 2; sz >= 1; sz /= 2) R0H_TRY(r0h_hash_fold(ctx, nodes, sz));
+  return nullptr;
+  R0H_GUARD_END
+}
+
+}  // extern "C"

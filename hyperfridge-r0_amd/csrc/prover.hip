@@ -1,0 +1,494 @@
+// The segment-proof sequencer: owns the Fiat-Shamir transcript on the host and drives the device operations.
+// Replaces risc0-circuit-rv32im 4.0.4 prove/hal/mod.rs (`SegmentProver::prove`: seed transcript, commit CODE and DATA,
+// draw the accumulation mix, accumulate, finalize) and risc0-zkp 3.0.4 prove/{prover.rs, poly_group.rs, merkle.rs,
+// fri.rs, write_iop.rs} + core/hash/poseidon2/rng.rs -- SURVEY.md 3.4 steps 3-13, 8(a) a8, a15-a17.
+// This is what host/src/main.rs:423 (`prover.prove(env, HYPERFRIDGE_ELF)`) spends its time in, once per segment.
+//
+// Device-resident throughout: witness, coefficients, evaluations, Merkle nodes, combos.  What crosses to the host per
+// segment: Merkle tops + roots (<= 2 KB each), ~500 tap evaluations, the FRI final polynomial (4 KB) and the 50
+// query openings (gathered on the device into one packed buffer per tree).  Upstream pulls the combos back to the
+// host for the DEEP division; here the division is a device scan (r0h_poly_divide).
+#include "circuit.hpp"
+
+namespace r0h {
+
+// flat view of the circuit tables the sequencer walks
+struct CircuitView {
+  uint32_t group_size[3];
+  uint32_t n_taps, n_regs, n_combos, n_global, n_mix;
+  std::vector<uint32_t> tap_offset, tap_back, reg_group, reg_offset, reg_first, reg_size, reg_combo;
+  const uint32_t* combo_begin; const uint32_t* combo_backs;
+  uint32_t group_tap_begin[4];
+  const uint32_t* blob; size_t blob_words;
+};
+static void circuit_view(const r0h_circuit* c, CircuitView* v) {
+  memcpy(v->group_size, c->group_size, sizeof v->group_size);
+  v->n_taps = (uint32_t)c->taps.size(); v->n_regs = (uint32_t)c->regs.size(); v->n_combos = (uint32_t)c->combo_begin.size() - 1;
+  v->n_global = c->n_global; v->n_mix = c->n_mix;
+  for (const Tap& t : c->taps) { v->tap_offset.push_back(t.offset); v->tap_back.push_back(t.back); }
+  for (const Reg& r : c->regs) {
+    v->reg_group.push_back(r.group); v->reg_offset.push_back(r.offset); v->reg_first.push_back(r.first_tap);
+    v->reg_size.push_back(r.size); v->reg_combo.push_back(r.combo);
+  }
+  v->combo_begin = c->combo_begin.data(); v->combo_backs = c->combo_backs.data();
+  memcpy(v->group_tap_begin, c->group_tap_begin, sizeof v->group_tap_begin);
+  v->blob = c->blob.data(); v->blob_words = c->blob.size();
+}
+
+static unsigned log2u(size_t x) { unsigned n = 0; while (((size_t)1 << n) < x) n++; return n; }
+
+// ------------------------------------------------------------------ transcript
+struct Rng {
+  const P2Consts* k;
+  uint32_t cells[P2_CELLS];
+  uint32_t pool_used;
+  explicit Rng(const P2Consts* kk) : k(kk), pool_used(0) { memset(cells, 0, sizeof cells); }
+  void mix(const uint32_t digest[8]) {
+    if (pool_used != 0) { p2_mix_host(*k, cells); pool_used = 0; }
+    for (int i = 0; i < 8; i++) cells[i] = add(cells[i], digest[i] % P);
+    p2_mix_host(*k, cells);
+  }
+  uint32_t elem() {
+    if (pool_used == P2_RATE) { p2_mix_host(*k, cells); pool_used = 0; }
+    return cells[pool_used++];
+  }
+  Fp4 ext() { Fp4 r; for (int i = 0; i < 4; i++) r.e[i] = elem(); return r; }
+  uint32_t bits(uint32_t n) {
+    uint32_t val = dec(elem());
+    for (int i = 0; i < 3; i++) { uint32_t nv = dec(elem()); if (val == 0) val = nv; }
+    return val & (uint32_t)(((uint64_t)1 << n) - 1);
+  }
+};
+struct WriteIop {
+  std::vector<uint32_t> proof;
+  Rng rng;
+  explicit WriteIop(const P2Consts* k) : rng(k) {}
+  void write(const uint32_t* w, size_t n) { proof.insert(proof.end(), w, w + n); }
+  void commit(const uint32_t digest[8]) { rng.mix(digest); }
+};
+
+// ------------------------------------------------------------------ Merkle
+struct MerkleParams {
+  size_t row_size, col_size, layers, top_layer, top_size;
+  MerkleParams(size_t rows, size_t cols) : row_size(rows), col_size(cols) {
+    layers = log2u(rows);
+    top_layer = 0;
+    for (size_t i = 1; i < layers; i++) {
+      if (((size_t)1 << i) > R0H_QUERIES) break;
+      top_layer = i;
+    }
+    top_size = (size_t)1 << top_layer;
+  }
+  size_t path_digests() const { return layers - top_layer; }
+  size_t opening_words() const { return col_size + 8 * path_digests(); }
+};
+
+// out[q] = column values at row idx[q] followed by the sibling digests up to (excluding) the top layer
+__global__ void merkle_open_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix, const uint32_t* __restrict__ nodes,
+                                   const uint32_t* __restrict__ idx, uint32_t row_size, uint32_t col_size, uint32_t n_path) {
+  const uint32_t q = blockIdx.x, row = idx[q];
+  uint32_t* dst = out + (size_t)q * (col_size + 8 * n_path);
+  for (uint32_t i = threadIdx.x; i < col_size; i += blockDim.x) dst[i] = matrix[(size_t)i * row_size + row];
+  for (uint32_t w = threadIdx.x; w < 8 * n_path; w += blockDim.x) {
+    uint32_t level = w >> 3, node = ((row + row_size) >> level) ^ 1u;
+    dst[col_size + w] = nodes[(size_t)node * 8 + (w & 7)];
+  }
+}
+
+struct Tree {
+  MerkleParams mp;
+  r0h_buf* nodes = nullptr;
+  const r0h_buf* matrix = nullptr;
+  Tree(size_t rows, size_t cols) : mp(rows, cols) {}
+};
+
+struct Scope {  // frees device buffers on every exit path
+  std::vector<r0h_buf*> bufs;
+  ~Scope() { for (r0h_buf* b : bufs) r0h_buf_free(b); }
+  const char* alloc(r0h_ctx* ctx, size_t bytes, r0h_buf** out) {
+    R0H_TRY(r0h_buf_alloc(ctx, bytes, out));
+    bufs.push_back(*out);
+    return nullptr;
+  }
+  void release(r0h_buf* b) {
+    for (size_t i = 0; i < bufs.size(); i++)
+      if (bufs[i] == b) { bufs.erase(bufs.begin() + i); r0h_buf_free(b); return; }
+  }
+};
+
+static void phase(r0h_ctx* ctx, const char* name) {
+  Profile& p = ctx->prof;
+  size_t i = p.names.size();
+  if (p.events.size() <= i) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    p.events.push_back(e);
+  }
+  hipEventRecord(p.events[i], ctx->stream);
+  p.names.push_back(name);
+}
+
+static const char* tree_build(r0h_ctx* ctx, Scope& sc, Tree& t, const r0h_buf* matrix) {
+  t.matrix = matrix;
+  R0H_TRY(sc.alloc(ctx, t.mp.row_size * 2 * 32, &t.nodes));
+  return r0h_merkle_build(ctx, t.nodes, matrix, (uint32_t)t.mp.row_size, (uint32_t)t.mp.col_size);
+}
+static const char* tree_commit(r0h_ctx* ctx, Tree& t, WriteIop& io) {
+  std::vector<uint32_t> host(2 * t.mp.top_size * 8);
+  R0H_TRY(r0h_buf_d2h(ctx, t.nodes, 32, host.data() + 8, (2 * t.mp.top_size - 1) * 32));
+  io.write(host.data() + t.mp.top_size * 8, t.mp.top_size * 8);
+  io.commit(host.data() + 8);
+  return nullptr;
+}
+// open `n_q` rows: returns packed openings on the host
+static const char* tree_open(r0h_ctx* ctx, Scope& sc, const Tree& t, const r0h_buf* d_idx, uint32_t n_q, std::vector<uint32_t>& host) {
+  r0h_buf* packed = nullptr;
+  const size_t words = t.mp.opening_words();
+  R0H_TRY(sc.alloc(ctx, (size_t)n_q * words * 4, &packed));
+  hipLaunchKernelGGL(merkle_open_kernel, dim3(n_q), dim3(256), 0, ctx->stream, u32(packed), u32(t.matrix), u32(t.nodes), u32(d_idx),
+                     (uint32_t)t.mp.row_size, (uint32_t)t.mp.col_size, (uint32_t)t.mp.path_digests());
+  hipError_t e = hipGetLastError();
+  R0H_REQUIRE(e == hipSuccess, "merkle_open_kernel: %s", hipGetErrorString(e));
+  host.resize((size_t)n_q * words);
+  R0H_TRY(r0h_buf_d2h(ctx, packed, 0, host.data(), host.size() * 4));
+  sc.release(packed);
+  return nullptr;
+}
+
+// ------------------------------------------------------------------ poly groups
+struct Group {
+  r0h_buf* coeffs = nullptr;     // natural order once finished
+  r0h_buf* evaluated = nullptr;  // [count][4N]
+  uint32_t count = 0;
+  Tree tree;
+  Group(uint32_t cnt, size_t domain) : count(cnt), tree(domain, cnt) {}
+};
+// coeffs hold bit-reversed, zk-shifted coefficients: evaluate on 4N, commit, flip coeffs to natural order
+static const char* group_finish(r0h_ctx* ctx, Scope& sc, Group& g, uint32_t po2) {
+  R0H_TRY(sc.alloc(ctx, ((size_t)g.count << (po2 + 2)) * 4, &g.evaluated));
+  R0H_TRY(r0h_batch_expand_into_evaluate_ntt(ctx, g.evaluated, g.coeffs, g.count, po2, 2));
+  R0H_TRY(r0h_batch_bit_reverse(ctx, g.coeffs, g.count, po2));
+  return tree_build(ctx, sc, g.tree, g.evaluated);
+}
+static const char* group_from_witness(r0h_ctx* ctx, Scope& sc, Group& g, const r0h_buf* witness, uint32_t po2) {
+  const size_t bytes = ((size_t)g.count << po2) * 4;
+  R0H_REQUIRE(bytes <= witness->bytes, "prove_segment: witness buffer holds fewer than %u columns of 2^%u", g.count, po2);
+  R0H_TRY(sc.alloc(ctx, bytes, &g.coeffs));
+  R0H_TRY_HIP(hipMemcpyAsync(g.coeffs->ptr, witness->ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  R0H_TRY(r0h_batch_interpolate_ntt(ctx, g.coeffs, g.count, po2));
+  R0H_TRY(r0h_zk_shift(ctx, g.coeffs, g.count, po2));
+  return group_finish(ctx, sc, g, po2);
+}
+
+// Lagrange interpolation of a handful of extension points (host; a register has at most a few taps)
+static void poly_interpolate(Fp4* out, const Fp4* xs, const Fp4* ys, uint32_t n) {
+  std::vector<Fp4> acc(n, fp4_zero()), basis(n + 1);
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t deg = 0;
+    basis[0] = fp4_one();
+    Fp4 denom = fp4_one();
+    for (uint32_t j = 0; j < n; j++) {
+      if (j == i) continue;
+      basis[deg + 1] = fp4_zero();
+      for (uint32_t k = deg + 1; k-- > 0;) {
+        basis[k + 1] = basis[k + 1] + basis[k];
+        basis[k] = fp4_zero() - basis[k] * xs[j];
+      }
+      deg++;
+      denom = denom * (xs[i] - xs[j]);
+    }
+    Fp4 s = ys[i] * fp4_inv(denom);
+    for (uint32_t k = 0; k < n; k++) acc[k] = acc[k] + basis[k] * s;
+  }
+  for (uint32_t k = 0; k < n; k++) out[k] = acc[k];
+}
+
+// combos[row 0..size) of one combo -= cur * coeff_u (tiny host-driven fix-up of the first few coefficients)
+__global__ void sub_head_kernel(uint32_t* __restrict__ combos, const uint32_t* __restrict__ fix /* (word index, value) pairs */, uint32_t n) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) combos[fix[2 * k]] = sub(combos[fix[2 * k]], fix[2 * k + 1]);
+}
+
+static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
+                         const uint32_t* global, std::vector<uint32_t>& seal) {
+  CircuitView cv;
+  circuit_view(circ, &cv);
+  const size_t n = (size_t)1 << po2, domain = n * R0H_INV_RATE;
+  Scope sc;
+  ctx->prof.names.clear();
+  WriteIop io(&ctx->p2_host);
+
+  phase(ctx, "transcript_seed");
+  {
+    static const char info[] = "r0hip.stark.v1";
+    uint32_t e[32], d[8];
+    size_t len = strlen(info);
+    for (size_t i = 0; i < len; i++) e[i] = enc((uint8_t)info[i]);
+    p2_hash_elems_host(ctx->p2_host, e, len, d);
+    io.commit(d);
+    std::vector<uint32_t> be(cv.blob_words);
+    for (size_t i = 0; i < cv.blob_words; i++) be[i] = enc(cv.blob[i] % P);
+    p2_hash_elems_host(ctx->p2_host, be.data(), be.size(), d);
+    io.commit(d);
+    std::vector<uint32_t> gv(global, global + cv.n_global);
+    for (uint32_t w : gv) R0H_REQUIRE(w < P, "prove_segment: global word not canonical");
+    gv.push_back(enc(po2));
+    p2_hash_elems_host(ctx->p2_host, gv.data(), gv.size(), d);
+    io.commit(d);
+    io.write(gv.data(), gv.size());
+  }
+
+  Group g_accum(cv.group_size[R0H_GROUP_ACCUM], domain), g_code(cv.group_size[R0H_GROUP_CODE], domain),
+      g_data(cv.group_size[R0H_GROUP_DATA], domain), g_check(R0H_CHECK_SIZE, domain);
+  Group* grp[3] = {&g_accum, &g_code, &g_data};
+
+  phase(ctx, "commit_code");
+  R0H_TRY(group_from_witness(ctx, sc, g_code, code, po2));
+  R0H_TRY(tree_commit(ctx, g_code.tree, io));
+  phase(ctx, "commit_data");
+  R0H_TRY(group_from_witness(ctx, sc, g_data, data, po2));
+  R0H_TRY(tree_commit(ctx, g_data.tree, io));
+
+  phase(ctx, "accum");
+  std::vector<uint32_t> mix(cv.n_mix);
+  for (uint32_t i = 0; i < cv.n_mix; i++) mix[i] = io.rng.elem();
+  {
+    r0h_buf* accum = nullptr;
+    R0H_TRY(sc.alloc(ctx, ((size_t)g_accum.count << po2) * 4, &accum));
+    R0H_TRY(r0h_accum(ctx, circ, po2, code, data, mix.data(), accum));
+    phase(ctx, "commit_accum");
+    R0H_TRY(group_from_witness(ctx, sc, g_accum, accum, po2));
+    sc.release(accum);
+  }
+  R0H_TRY(tree_commit(ctx, g_accum.tree, io));
+
+  phase(ctx, "eval_check");
+  Fp4 poly_mix = io.rng.ext();
+  R0H_TRY(sc.alloc(ctx, domain * 16, &g_check.coeffs));
+  R0H_TRY(r0h_eval_check(ctx, circ, po2, g_accum.evaluated, g_code.evaluated, g_data.evaluated, global, mix.data(), poly_mix.e, g_check.coeffs));
+  phase(ctx, "commit_check");
+  R0H_TRY(r0h_batch_interpolate_ntt(ctx, g_check.coeffs, 4, po2 + 2));  // 4 polys of 4N == 16 polys of N (bit-reversed)
+  R0H_TRY(group_finish(ctx, sc, g_check, po2));
+  R0H_TRY(tree_commit(ctx, g_check.tree, io));
+
+  phase(ctx, "evaluate_at_z");
+  const Fp4 z = io.rng.ext(), z4 = fp4_pow(z, 4);
+  const uint32_t back_one = rou_rev(po2);
+  const uint32_t n_u = cv.n_taps + R0H_CHECK_SIZE;
+  std::vector<Fp4> all_xs(n_u), coeff_u(n_u);
+  std::vector<uint32_t> which(n_u);
+  r0h_buf* d_eval = nullptr;
+  R0H_TRY(sc.alloc(ctx, (size_t)n_u * 16, &d_eval));
+  for (uint32_t t = 0; t < cv.n_taps; t++) {
+    all_xs[t] = scale(z, fpow(back_one, cv.tap_back[t]));
+    which[t] = cv.tap_offset[t];
+  }
+  for (uint32_t i = 0; i < R0H_CHECK_SIZE; i++) { all_xs[cv.n_taps + i] = z4; which[cv.n_taps + i] = i; }
+  for (int g = 0; g < 3; g++) {
+    uint32_t b = cv.group_tap_begin[g], e = cv.group_tap_begin[g + 1];
+    if (e == b) continue;
+    r0h_buf view = *d_eval;
+    view.ptr = (char*)d_eval->ptr + (size_t)b * 16;
+    view.bytes = (size_t)(e - b) * 16;
+    R0H_TRY(r0h_batch_evaluate_any(ctx, grp[g]->coeffs, po2, which.data() + b, (const uint32_t*)(all_xs.data() + b), e - b, &view));
+  }
+  {
+    r0h_buf view = *d_eval;
+    view.ptr = (char*)d_eval->ptr + (size_t)cv.n_taps * 16;
+    view.bytes = (size_t)R0H_CHECK_SIZE * 16;
+    R0H_TRY(r0h_batch_evaluate_any(ctx, g_check.coeffs, po2, which.data() + cv.n_taps, (const uint32_t*)(all_xs.data() + cv.n_taps), R0H_CHECK_SIZE, &view));
+  }
+  std::vector<Fp4> eval_u(n_u);
+  R0H_TRY(r0h_buf_d2h(ctx, d_eval, 0, eval_u.data(), (size_t)n_u * 16));
+  for (uint32_t r = 0; r < cv.n_regs; r++) {
+    uint32_t p = cv.reg_first[r];
+    poly_interpolate(&coeff_u[p], &all_xs[p], &eval_u[p], cv.reg_size[r]);
+  }
+  for (uint32_t i = 0; i < R0H_CHECK_SIZE; i++) coeff_u[cv.n_taps + i] = eval_u[cv.n_taps + i];
+  io.write((const uint32_t*)coeff_u.data(), 4 * (size_t)n_u);
+  {
+    uint32_t d[8];
+    p2_hash_elems_host(ctx->p2_host, (const uint32_t*)coeff_u.data(), 4 * (size_t)n_u, d);
+    io.commit(d);
+  }
+
+  phase(ctx, "mix_combos");
+  const Fp4 mixv = io.rng.ext();
+  const uint32_t n_combos = cv.n_combos;
+  r0h_buf* combos = nullptr;
+  R0H_TRY(sc.alloc(ctx, (size_t)(n_combos + 1) * n * 16, &combos));
+  R0H_TRY(r0h_buf_zero(ctx, combos));
+  Fp4 cur = fp4_one();
+  for (int g = 0; g < 3; g++) {
+    uint32_t gs = cv.group_size[g];
+    std::vector<uint32_t> combo_of(gs);
+    for (uint32_t r = 0; r < cv.n_regs; r++)
+      if (cv.reg_group[r] == (uint32_t)g) combo_of[cv.reg_offset[r]] = cv.reg_combo[r];
+    R0H_TRY(r0h_mix_poly_coeffs(ctx, combos, cur.e, mixv.e, grp[g]->coeffs, combo_of.data(), gs, po2));
+    cur = cur * fp4_pow(mixv, gs);
+  }
+  {
+    uint32_t combo_of[R0H_CHECK_SIZE];
+    for (int i = 0; i < R0H_CHECK_SIZE; i++) combo_of[i] = n_combos;
+    R0H_TRY(r0h_mix_poly_coeffs(ctx, combos, cur.e, mixv.e, g_check.coeffs, combo_of, R0H_CHECK_SIZE, po2));
+  }
+  // subtract the interpolants: only the first few coefficients of each combo change
+  {
+    std::vector<Fp4> head((size_t)(n_combos + 1) * 64, fp4_zero());
+    std::vector<uint32_t> head_len(n_combos + 1, 0);
+    cur = fp4_one();
+    for (uint32_t r = 0; r < cv.n_regs; r++) {
+      R0H_REQUIRE(cv.reg_size[r] <= 64, "prove_segment: register with more than 64 taps");
+      for (uint32_t i = 0; i < cv.reg_size[r]; i++) {
+        Fp4& h = head[(size_t)cv.reg_combo[r] * 64 + i];
+        h = h + cur * coeff_u[cv.reg_first[r] + i];
+      }
+      if (cv.reg_size[r] > head_len[cv.reg_combo[r]]) head_len[cv.reg_combo[r]] = cv.reg_size[r];
+      cur = cur * mixv;
+    }
+    for (uint32_t i = 0; i < R0H_CHECK_SIZE; i++) {
+      head[(size_t)n_combos * 64] = head[(size_t)n_combos * 64] + cur * coeff_u[cv.n_taps + i];
+      cur = cur * mixv;
+    }
+    head_len[n_combos] = 1;
+    std::vector<uint32_t> fix;
+    for (uint32_t k = 0; k <= n_combos; k++)
+      for (uint32_t i = 0; i < head_len[k]; i++)
+        for (uint32_t q = 0; q < 4; q++) {
+          fix.push_back((uint32_t)((((size_t)k << po2) + i) * 4 + q));
+          fix.push_back(head[(size_t)k * 64 + i].e[q]);
+        }
+    R0H_REQUIRE(((size_t)(n_combos + 1) << po2) * 4 < ((size_t)1 << 32), "prove_segment: combos buffer exceeds 32-bit word indexing");
+    r0h_buf* d_fix = nullptr;
+    R0H_TRY(sc.alloc(ctx, fix.size() * 4, &d_fix));
+    R0H_TRY(r0h_buf_h2d(ctx, d_fix, 0, fix.data(), fix.size() * 4));
+    uint32_t nf = (uint32_t)(fix.size() / 2);
+    hipLaunchKernelGGL(sub_head_kernel, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, u32(combos), u32(d_fix), nf);
+    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    sc.release(d_fix);
+  }
+  phase(ctx, "deep_divide");
+  for (uint32_t k = 0; k <= n_combos; k++) {
+    r0h_buf view = *combos;
+    view.ptr = (char*)combos->ptr + ((size_t)k << po2) * 16;
+    view.bytes = n * 16;
+    if (k < n_combos) {
+      for (uint32_t b = cv.combo_begin[k]; b < cv.combo_begin[k + 1]; b++) {
+        Fp4 pt = scale(z, fpow(back_one, cv.combo_backs[b])), rem;
+        R0H_TRY(r0h_poly_divide(ctx, &view, (uint32_t)n, pt.e, rem.e));
+        R0H_REQUIRE(rem == fp4_zero(), "prove_segment: DEEP quotient of combo %u has a non-zero remainder (witness violates the taps?)", k);
+      }
+    } else {
+      Fp4 rem;
+      R0H_TRY(r0h_poly_divide(ctx, &view, (uint32_t)n, z4.e, rem.e));
+      R0H_REQUIRE(rem == fp4_zero(), "prove_segment: check quotient has a non-zero remainder");
+    }
+  }
+  r0h_buf* fri_coeffs = nullptr;
+  R0H_TRY(sc.alloc(ctx, n * 16, &fri_coeffs));
+  R0H_TRY(r0h_eltwise_sum_extelem(ctx, fri_coeffs, combos, n_combos + 1, (uint32_t)n));
+  R0H_TRY(r0h_batch_bit_reverse(ctx, fri_coeffs, 4, po2));
+  sc.release(combos);
+
+  // ---- FRI
+  phase(ctx, "fri_commit");
+  struct Round { Tree tree; r0h_buf* evaluated; size_t domain; };
+  std::vector<Round> rounds;
+  size_t deg = n;
+  while (deg > R0H_FRI_MIN_DEGREE) {
+    Round rd{Tree(deg * R0H_INV_RATE / R0H_FRI_FOLD, R0H_FRI_FOLD * 4), nullptr, deg * R0H_INV_RATE};
+    R0H_TRY(sc.alloc(ctx, rd.domain * 16, &rd.evaluated));
+    R0H_TRY(r0h_batch_expand_into_evaluate_ntt(ctx, rd.evaluated, fri_coeffs, 4, log2u(deg), 2));
+    R0H_TRY(tree_build(ctx, sc, rd.tree, rd.evaluated));
+    R0H_TRY(tree_commit(ctx, rd.tree, io));
+    Fp4 fold_mix = io.rng.ext();
+    r0h_buf* folded = nullptr;
+    R0H_TRY(sc.alloc(ctx, deg / R0H_FRI_FOLD * 16, &folded));
+    R0H_TRY(r0h_fri_fold(ctx, folded, fri_coeffs, fold_mix.e, (uint32_t)(deg / R0H_FRI_FOLD)));
+    sc.release(fri_coeffs);
+    fri_coeffs = folded;
+    deg /= R0H_FRI_FOLD;
+    rounds.push_back(rd);
+  }
+  R0H_TRY(r0h_batch_bit_reverse(ctx, fri_coeffs, 4, log2u(deg)));
+  {
+    std::vector<uint32_t> fc(4 * deg);
+    R0H_TRY(r0h_buf_d2h(ctx, fri_coeffs, 0, fc.data(), fc.size() * 4));
+    io.write(fc.data(), fc.size());
+    uint32_t d[8];
+    p2_hash_elems_host(ctx->p2_host, fc.data(), fc.size(), d);
+    io.commit(d);
+  }
+
+  phase(ctx, "queries");
+  {
+    // the query positions depend only on the transcript state, not on the openings: draw all of them, then open each
+    // tree for all queries in one kernel + one copy
+    const uint32_t nq = R0H_QUERIES, n_trees = 4 + (uint32_t)rounds.size();
+    std::vector<uint32_t> idx((size_t)n_trees * nq);
+    for (uint32_t q = 0; q < nq; q++) {
+      size_t pos = io.rng.bits(log2u(domain)) % domain;
+      for (uint32_t t = 0; t < 4; t++) idx[(size_t)t * nq + q] = (uint32_t)pos;
+      for (size_t r = 0; r < rounds.size(); r++) {
+        pos = pos % (rounds[r].domain / R0H_FRI_FOLD);
+        idx[(size_t)(4 + r) * nq + q] = (uint32_t)pos;
+      }
+    }
+    r0h_buf* d_idx = nullptr;
+    R0H_TRY(sc.alloc(ctx, idx.size() * 4, &d_idx));
+    R0H_TRY(r0h_buf_h2d(ctx, d_idx, 0, idx.data(), idx.size() * 4));
+    std::vector<const Tree*> trees = {&g_accum.tree, &g_code.tree, &g_data.tree, &g_check.tree};
+    for (Round& rd : rounds) trees.push_back(&rd.tree);
+    std::vector<std::vector<uint32_t>> opened(n_trees);
+    for (uint32_t t = 0; t < n_trees; t++) {
+      r0h_buf view = *d_idx;
+      view.ptr = (char*)d_idx->ptr + (size_t)t * nq * 4;
+      view.bytes = (size_t)nq * 4;
+      R0H_TRY(tree_open(ctx, sc, *trees[t], &view, nq, opened[t]));
+    }
+    for (uint32_t q = 0; q < nq; q++)
+      for (uint32_t t = 0; t < n_trees; t++) {
+        size_t w = trees[t]->mp.opening_words();
+        io.write(opened[t].data() + (size_t)q * w, w);
+      }
+  }
+  phase(ctx, "end");
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  Profile& pf = ctx->prof;
+  pf.ms.assign(pf.names.size(), 0.f);
+  for (size_t i = 0; i + 1 < pf.names.size(); i++) hipEventElapsedTime(&pf.ms[i], pf.events[i], pf.events[i + 1]);
+  seal.swap(io.proof);
+  return nullptr;
+}
+
+}  // namespace r0h
+
+using namespace r0h;
+
+extern "C" {
+
+const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
+                              const uint32_t* global, uint32_t* seal_out, size_t seal_cap, size_t* seal_words_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && c && code && data && seal_words_out, "r0h_prove_segment: NULL argument");
+  R0H_REQUIRE(global || r0h_circuit_n_global(c) == 0, "r0h_prove_segment: global is NULL");
+  R0H_REQUIRE(po2 >= 9 && po2 <= R0H_MAX_PO2, "r0h_prove_segment: po2 %u outside [9, %u]", po2, R0H_MAX_PO2);
+  R0H_TRY_HIP(hipSetDevice(ctx->device));
+  std::vector<uint32_t> seal;
+  R0H_TRY(prove(ctx, c, po2, code, data, global, seal));
+  *seal_words_out = seal.size();
+  R0H_REQUIRE(seal.size() <= seal_cap || !seal_out, "r0h_prove_segment: seal needs %zu words, capacity is %zu", seal.size(), seal_cap);
+  if (seal_out) memcpy(seal_out, seal.data(), seal.size() * 4);
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out) {
+  R0H_REQUIRE(ctx && names_out && ms_out && n_out, "r0h_last_profile: NULL argument");
+  *names_out = ctx->prof.names.data();
+  *ms_out = ctx->prof.ms.data();
+  *n_out = ctx->prof.names.empty() ? 0 : (uint32_t)ctx->prof.names.size() - 1;
+  return nullptr;
+}
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+"""Import shim: the package directory is named `hyperfridge-r0_amd` (not a valid module name), so
+`import hyperfridge_r0_amd` from the repo root loads it from there."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hyperfridge-r0_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,135 @@
+/* r0hip -- C ABI of the MI355X-native RISC Zero segment prover (hot path only: prove_segment).
+ *
+ * This is the drop-in boundary for the path the reference reaches through
+ *     host/src/main.rs:420   let prover = default_prover();
+ *     host/src/main.rs:423   prover.prove(env, HYPERFRIDGE_ELF)
+ * i.e. (inside the un-vendored risc0 crates pinned in Cargo.lock:3195-3197, 3121-3123, 3174-3176) the
+ * `risc0_zkp::hal::Hal` + `CircuitHal` operations that a native backend implements and that risc0's own
+ * CUDA/Metal backends bind as `extern "C"` launchers from risc0-sys / risc0-circuit-rv32im-sys.
+ * A Rust `HipHal` would bind exactly these entry points (INTEGRATION.md shows the stub).
+ *
+ * Conventions (mirroring risc0-sys's launcher convention):
+ *   - every function returns `const char*`: NULL on success, otherwise a heap-allocated message the caller
+ *     releases with r0h_free_error().  Nothing aborts or throws across the ABI.
+ *   - field elements are uint32_t BabyBear words in Montgomery form (R = 2^32), always < p = 2013265921;
+ *     extension elements are 4 consecutive words (x^4 = 11); digests are 8 words.
+ *   - matrices are column-major: column c of a [count][size] buffer starts at word c*size.
+ *   - a context is bound to one device and one stream and is not re-entrant; different contexts are independent.
+ *     Operations are stream-ordered; only r0h_buf_d2h, r0h_sync and the functions that return host data block.
+ *   - the caller owns host memory; the library owns device memory behind r0h_buf handles.
+ */
+#ifndef R0HIP_H
+#define R0HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R0H_P 2013265921u
+#define R0H_INV_RATE 4
+#define R0H_QUERIES 50
+#define R0H_FRI_FOLD 16
+#define R0H_FRI_MIN_DEGREE 256
+#define R0H_CHECK_SIZE 16
+#define R0H_DIGEST_WORDS 8
+#define R0H_GROUP_ACCUM 0
+#define R0H_GROUP_CODE 1
+#define R0H_GROUP_DATA 2
+#define R0H_MAX_PO2 20 /* trace rows; the evaluation domain is 4x that */
+
+typedef struct r0h_ctx r0h_ctx;
+typedef struct r0h_buf r0h_buf;
+typedef struct r0h_circuit r0h_circuit;
+
+void r0h_free_error(const char* msg);
+const char* r0h_version(void);
+
+/* ---- context and buffers: Hal::alloc_*, copy_from_*, Buffer::{slice, view} ---- */
+const char* r0h_ctx_create(int device, r0h_ctx** out);
+const char* r0h_ctx_destroy(r0h_ctx* ctx);
+const char* r0h_sync(r0h_ctx* ctx);
+const char* r0h_buf_alloc(r0h_ctx* ctx, size_t bytes, r0h_buf** out);
+const char* r0h_buf_wrap(r0h_ctx* ctx, void* device_ptr, size_t bytes, r0h_buf** out); /* memory owned elsewhere */
+const char* r0h_buf_slice(r0h_buf* parent, size_t offset_bytes, size_t bytes, r0h_buf** out);
+const char* r0h_buf_free(r0h_buf* buf);
+const char* r0h_buf_h2d(r0h_ctx* ctx, r0h_buf* dst, size_t offset_bytes, const void* src, size_t bytes);
+const char* r0h_buf_d2h(r0h_ctx* ctx, const r0h_buf* src, size_t offset_bytes, void* dst, size_t bytes);
+const char* r0h_buf_zero(r0h_ctx* ctx, r0h_buf* buf);
+void* r0h_buf_device_ptr(const r0h_buf* buf);
+size_t r0h_buf_bytes(const r0h_buf* buf);
+
+/* ---- Hal: NTT family (risc0-zkp hal `batch_interpolate_ntt`, `batch_expand_into_evaluate_ntt`,
+ *      `batch_bit_reverse`, `zk_shift`) ---- */
+/* count columns of 2^po2 natural-order evaluations -> bit-reversed coefficients, in place */
+const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
+/* count columns of 2^in_po2 bit-reversed coefficients -> natural-order evaluations on the 2^(in_po2+expand_bits) domain */
+const char* r0h_batch_expand_into_evaluate_ntt(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t count,
+                                               uint32_t in_po2, uint32_t expand_bits);
+const char* r0h_batch_bit_reverse(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
+/* coefficient at bit-reversed position i is multiplied by 3^brev(i): f(x) -> f(3x) */
+const char* r0h_zk_shift(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
+
+/* ---- Hal: Poseidon2 Merkle commitment (`hash_rows`, `hash_fold`; prove/merkle.rs) ---- */
+/* rc: 24*29 canonical round constants, diag_m1: 24 canonical (mu_i - 1); the default table is compiled in */
+const char* r0h_poseidon2_set_consts(r0h_ctx* ctx, const uint32_t* rc, const uint32_t* diag_m1);
+/* digests[r] = sponge(matrix[0][r], matrix[1][r], ..., matrix[cols-1][r]) for r < rows */
+const char* r0h_hash_rows(r0h_ctx* ctx, r0h_buf* digests, const r0h_buf* matrix, uint32_t rows, uint32_t cols);
+/* nodes[i] = H(nodes[2i] || nodes[2i+1]) for output_size <= i < 2*output_size (digest units) */
+const char* r0h_hash_fold(r0h_ctx* ctx, r0h_buf* nodes, uint32_t output_size);
+/* nodes has 2*rows digests: leaves at [rows, 2rows), root at index 1 */
+const char* r0h_merkle_build(r0h_ctx* ctx, r0h_buf* nodes, const r0h_buf* matrix, uint32_t rows, uint32_t cols);
+
+/* ---- Hal: streaming ops (`batch_evaluate_any`, `mix_poly_coeffs`, `eltwise_*`, `gather_sample`, `scatter`,
+ *      `fri_fold`, `prefix_products`; core/poly.rs `poly_divide`) ---- */
+/* out[k] = poly which[k] (2^po2 natural-order coefficients) evaluated at the extension point xs[4k..4k+4);
+ * which / xs are small host arrays (upstream uploads them from the host as well) */
+const char* r0h_batch_evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, const uint32_t* which_host,
+                                   const uint32_t* xs_host, uint32_t n_eval, r0h_buf* out);
+const char* r0h_mix_poly_coeffs(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mix_start[4], const uint32_t mix[4],
+                                const r0h_buf* input, const uint32_t* combo_of_host, uint32_t input_count,
+                                uint32_t po2);
+const char* r0h_eltwise_add_elem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* a, const r0h_buf* b, uint32_t n);
+const char* r0h_eltwise_copy_elem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t n);
+const char* r0h_eltwise_sum_extelem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t count, uint32_t n);
+const char* r0h_gather_sample(r0h_ctx* ctx, r0h_buf* dst, const r0h_buf* src, uint32_t idx, uint32_t size,
+                              uint32_t stride);
+const char* r0h_scatter(r0h_ctx* ctx, r0h_buf* into, const r0h_buf* index, const r0h_buf* offsets,
+                        const r0h_buf* values, uint32_t n_index);
+const char* r0h_fri_fold(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, const uint32_t mix[4], uint32_t n_out);
+const char* r0h_prefix_products(r0h_ctx* ctx, r0h_buf* io, uint32_t n);
+/* in-place synthetic division of an extension-coefficient polynomial (AoS, natural order) by (x - z) */
+const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint32_t z[4], uint32_t remainder[4]);
+
+/* ---- CircuitHal: circuit blob (format: r0hip_circuit.h), witness generation, accumulation, eval_check ---- */
+/* Pure host: emit the HIP source of the circuit's eval_check kernels (caller frees with r0h_free_error). */
+const char* r0h_circuit_emit_hip(const uint32_t* blob, size_t n_words, char** source_out);
+/* code_object_path: a gfx950 code object built from r0h_circuit_emit_hip's output, or NULL to compile in-process. */
+const char* r0h_circuit_load(r0h_ctx* ctx, const uint32_t* blob, size_t n_words, const char* code_object_path,
+                             r0h_circuit** out);
+const char* r0h_circuit_free(r0h_circuit* c);
+uint32_t r0h_circuit_group_size(const r0h_circuit* c, uint32_t group);
+uint32_t r0h_circuit_n_global(const r0h_circuit* c);
+uint32_t r0h_circuit_n_mix(const r0h_circuit* c);
+uint32_t r0h_circuit_n_taps(const r0h_circuit* c);
+const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, r0h_buf* code, r0h_buf* data,
+                       uint32_t* global_out_host);
+const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
+                      const uint32_t* mix_host, r0h_buf* accum);
+const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* eval_accum,
+                           const r0h_buf* eval_code, const r0h_buf* eval_data, const uint32_t* global_host,
+                           const uint32_t* mix_host, const uint32_t poly_mix[4], r0h_buf* check);
+
+/* ---- the sequencer: risc0-circuit-rv32im `SegmentProver::prove` + risc0-zkp `Prover::{commit_group, finalize}` ---- */
+/* code/data: witness columns resident in device memory ([group_size][2^po2]); global: host words.
+ * seal_out receives *seal_words_out words (error if it exceeds seal_capacity_words). */
+const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code,
+                              const r0h_buf* data, const uint32_t* global_host, uint32_t* seal_out,
+                              size_t seal_capacity_words, size_t* seal_words_out);
+/* Per-phase device time of the last r0h_prove_segment on this context (ms), for bench.py; names are static strings. */
+const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

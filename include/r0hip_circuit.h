@@ -1,0 +1,43 @@
+/* Circuit blob consumed by r0h_circuit_load / r0h_circuit_emit_hip.
+ *
+ * Everything circuit-specific in the reference's prover is machine-generated data compiled into
+ * risc0-circuit-rv32im 4.0.4 (tap table `TAPSET`, constraint program `POLY_EXT`, step functions); here it crosses
+ * the C ABI as one little-endian u32 stream so that a real circuit can be dropped in without touching the kernels.
+ *
+ *   word 0  magic 0x31433052 ("R0C1")      word 1  version (1)      word 2  number of sections
+ *   section = [tag, n_words, payload...]
+ *
+ *   GROUPS  (1): size of tap groups ACCUM(0), CODE(1), DATA(2) in columns
+ *   TAPS    (2): n_taps, then (group, offset, back) sorted ascending; a register = all taps of one (group, offset);
+ *                every column must own a tap with back 0; combos (distinct back lists) are derived on load
+ *   GLOBALS (3): n_global, n_mix, then n_global DATA column indices (global k = that column at row 0)
+ *   POLY    (4): n_steps, ret (mix var), then (op, a, b, c):
+ *                  0 CONST a=canonical value      2 GET a=tap index       3 GET_GLOBAL a=0 global | 1 mix, b=offset
+ *                  4 ADD / 5 SUB / 6 MUL a,b=fp vars                      7 TRUE
+ *                  8 AND_EQZ a=mix var, b=fp var                          9 AND_COND a=mix var, b=fp var, c=inner mix var
+ *                fp vars and mix vars are numbered separately in creation order (risc0-zkp adapter.rs PolyExtStep)
+ *   WITGEN  (5): n_code, (kind, param) per CODE column: 0 first-row flag, 1 last-row flag, 2 row counter, 3 fixed random;
+ *                n_data, (kind, a, b, c, e) per DATA column: 0 seeded random, 1 a*b+e, 2 a*b*c+e with refs
+ *                ref = group<<28 | back<<20 | column (group 1 or 2; DATA refs point at lower-numbered columns)
+ *   ACCUM   (6): n_acc, (first_code_col, a_data_col, b_data_col): extension column j (ACCUM columns 4j..4j+3) is the
+ *                running product of (mix[8j..8j+4) + a + mix[8j+4..8j+8) * b) from row 0
+ */
+#ifndef R0HIP_CIRCUIT_H
+#define R0HIP_CIRCUIT_H
+#define R0H_BLOB_MAGIC 0x31433052u
+#define R0H_SEC_GROUPS 1
+#define R0H_SEC_TAPS 2
+#define R0H_SEC_GLOBALS 3
+#define R0H_SEC_POLY 4
+#define R0H_SEC_WITGEN 5
+#define R0H_SEC_ACCUM 6
+#define R0H_OP_CONST 0
+#define R0H_OP_GET 2
+#define R0H_OP_GET_GLOBAL 3
+#define R0H_OP_ADD 4
+#define R0H_OP_SUB 5
+#define R0H_OP_MUL 6
+#define R0H_OP_TRUE 7
+#define R0H_OP_AND_EQZ 8
+#define R0H_OP_AND_COND 9
+#endif

@@ -1,0 +1,230 @@
+"""GPU parity: every C-ABI operation of libr0hip.so against the CPU oracle on the same seeded inputs, bit-exact
+(all arithmetic on this path is integer: BabyBear words, digests, indices -- no tolerance anywhere).
+Runs only on a real MI355X (`-m gpu`); nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+from conftest import circuit_path
+
+pytestmark = pytest.mark.gpu
+P = 2013265921
+
+
+def rnd(rng, n):
+    return rng.integers(0, P, size=n, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("po2,count", [(1, 3), (4, 2), (9, 5), (12, 3), (13, 2), (14, 4), (17, 3), (20, 2)])
+def test_interpolate_ntt(hal, orc, po2, count):
+    rng = np.random.default_rng(100 + po2)
+    x = rnd(rng, count << po2)
+    buf = hal.copy_from(x)
+    hal.batch_interpolate_ntt(buf, count, po2)
+    assert np.array_equal(buf.to_host(), orc.batch_interpolate_ntt(x, count, po2))
+
+
+@pytest.mark.parametrize("in_po2,expand,count", [(3, 0, 2), (5, 2, 3), (10, 2, 4), (12, 0, 2), (11, 2, 3), (14, 2, 2), (16, 2, 3), (20, 2, 1), (18, 0, 2)])
+def test_expand_into_evaluate_ntt(hal, orc, in_po2, expand, count):
+    rng = np.random.default_rng(200 + in_po2)
+    x = rnd(rng, count << in_po2)
+    out = hal.alloc(count << (in_po2 + expand))
+    hal.batch_expand_into_evaluate_ntt(out, hal.copy_from(x), count, in_po2, expand)
+    assert np.array_equal(out.to_host(), orc.batch_expand_into_evaluate_ntt(x, count, in_po2, expand))
+
+
+@pytest.mark.parametrize("po2,count", [(0, 3), (1, 2), (7, 3), (13, 5), (20, 2)])
+def test_bit_reverse_and_zk_shift(hal, orc, po2, count):
+    rng = np.random.default_rng(300 + po2)
+    x = rnd(rng, count << po2)
+    buf = hal.copy_from(x)
+    hal.batch_bit_reverse(buf, count, po2)
+    assert np.array_equal(buf.to_host(), orc.batch_bit_reverse(x, count, po2))
+    hal.batch_bit_reverse(buf, count, po2)
+    assert np.array_equal(buf.to_host(), x)  # involution
+    hal.zk_shift(buf, count, po2)
+    assert np.array_equal(buf.to_host(), orc.zk_shift(x, count, po2))
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 1), (256, 15), (256, 16), (300, 17), (1024, 48), (4096, 192), (512, 64), (1, 5)])
+def test_hash_rows(hal, orc, rows, cols):
+    rng = np.random.default_rng(rows + cols)
+    m = rnd(rng, rows * cols)
+    dig = hal.alloc(rows * 8)
+    hal.hash_rows(dig, hal.copy_from(m), rows, cols)
+    assert np.array_equal(dig.to_host(), orc.hash_rows(m, rows, cols))
+
+
+def test_hash_rows_of_an_empty_matrix_is_one_permutation_of_zero(hal, orc):
+    dig = hal.alloc(8 * 4)
+    hal.hash_rows(dig, hal.alloc(4), 4, 0)
+    want = orc.hash_elem_slice(np.zeros(0, np.uint32))
+    assert np.array_equal(dig.to_host().reshape(4, 8), np.tile(want, (4, 1)))
+
+
+@pytest.mark.parametrize("rows,cols", [(2, 3), (64, 16), (2048, 20), (1 << 14, 64)])
+def test_hash_fold_and_merkle_build(hal, orc, rows, cols):
+    rng = np.random.default_rng(rows)
+    m = rnd(rng, rows * cols)
+    nodes = hal.alloc(rows * 2 * 8)
+    hal.zero(nodes)
+    hal.merkle_build(nodes, hal.copy_from(m), rows, cols)
+    want = orc.merkle_build(m, rows, cols)
+    assert np.array_equal(nodes.to_host()[8:], want[8:])
+    # one explicit fold level through the Hal entry point
+    lvl = rnd(rng, rows * 2 * 8)
+    nb = hal.copy_from(lvl)
+    hal.hash_fold(nb, rows // 2)
+    assert np.array_equal(nb.to_host(), orc.hash_fold(lvl, rows // 2))
+
+
+def test_poseidon2_set_consts_changes_the_hash_and_default_table_matches_oracle(hal, orc):
+    rng = np.random.default_rng(5)
+    m = rnd(rng, 64 * 16)
+    rc, diag = orc.poseidon2_consts()
+    dig = hal.alloc(64 * 8)
+    hal.hash_rows(dig, hal.copy_from(m), 64, 16)
+    base = dig.to_host()
+    rc2 = rc.copy()
+    rc2[0] = (int(rc2[0]) + 1) % P
+    hal.poseidon2_set_consts(rc2, diag)
+    hal.hash_rows(dig, hal.copy_from(m), 64, 16)
+    assert not np.array_equal(dig.to_host(), base)
+    hal.poseidon2_set_consts(rc, diag)
+    hal.hash_rows(dig, hal.copy_from(m), 64, 16)
+    assert np.array_equal(dig.to_host(), base) and np.array_equal(base, orc.hash_rows(m, 64, 16))
+
+
+@pytest.mark.parametrize("po2,cols", [(4, 3), (9, 6), (10, 4), (13, 7), (16, 5)])
+def test_batch_evaluate_any(hal, orc, po2, cols):
+    rng = np.random.default_rng(po2)
+    coeffs = rnd(rng, cols << po2)
+    xa, xb = rnd(rng, 4), rnd(rng, 4)
+    which = rng.integers(0, cols, 9).astype(np.uint32)
+    xs = np.concatenate([xa if k % 3 else xb for k in range(9)])
+    out = hal.alloc(4 * 9)
+    hal.batch_evaluate_any(hal.copy_from(coeffs), po2, which, xs, out)
+    assert np.array_equal(out.to_host(), orc.batch_evaluate_any(coeffs, po2, which, xs))
+
+
+@pytest.mark.parametrize("po2,cols,n_combo", [(5, 4, 2), (10, 12, 3), (14, 40, 5)])
+def test_mix_poly_coeffs_and_sum(hal, orc, po2, cols, n_combo):
+    rng = np.random.default_rng(po2 + cols)
+    n = 1 << po2
+    inp = rnd(rng, cols * n)
+    combo_of = rng.integers(0, n_combo, cols).astype(np.uint32)
+    start, mix = rnd(rng, 4), rnd(rng, 4)
+    init = rnd(rng, 4 * n_combo * n)
+    combos = hal.copy_from(init)
+    hal.mix_poly_coeffs(combos, start, mix, hal.copy_from(inp), combo_of, po2)
+    want = orc.mix_poly_coeffs(init, start, mix, inp, combo_of, po2)
+    assert np.array_equal(combos.to_host(), want)
+    out = hal.alloc(4 * n)
+    hal.eltwise_sum_extelem(out, combos, n_combo, n)
+    assert np.array_equal(out.to_host(), orc.eltwise_sum_extelem(want, n_combo, n))
+
+
+@pytest.mark.parametrize("n_out", [1, 16, 256, 1 << 16])
+def test_fri_fold(hal, orc, n_out):
+    rng = np.random.default_rng(n_out)
+    inp, mix = rnd(rng, 4 * 16 * n_out), rnd(rng, 4)
+    out = hal.alloc(4 * n_out)
+    hal.fri_fold(out, hal.copy_from(inp), mix, n_out)
+    assert np.array_equal(out.to_host(), orc.fri_fold(inp, mix, n_out))
+
+
+@pytest.mark.parametrize("n", [1, 2, 64, 256, 4096, 1 << 13, 1 << 17])
+def test_prefix_products_and_poly_divide(hal, orc, n):
+    rng = np.random.default_rng(n)
+    v = rnd(rng, 4 * n)
+    buf = hal.copy_from(v)
+    hal.prefix_products(buf, n)
+    assert np.array_equal(buf.to_host(), orc.prefix_products(v, n))
+    z = rnd(rng, 4)
+    buf = hal.copy_from(v)
+    rem = hal.poly_divide(buf, n, z)
+    q, want_rem = orc.poly_divide(v, n, z)
+    assert np.array_equal(rem, want_rem) and np.array_equal(buf.to_host(), q)
+
+
+def test_small_eltwise_ops(hal, orc):
+    rng = np.random.default_rng(77)
+    a, b = rnd(rng, 1000), rnd(rng, 1000)
+    out = hal.alloc(1000)
+    hal.eltwise_add_elem(out, hal.copy_from(a), hal.copy_from(b), 1000)
+    assert np.array_equal(out.to_host().astype(np.int64), (a.astype(np.int64) + b) % P)
+    hal.eltwise_copy_elem(out, hal.copy_from(b), 1000)
+    assert np.array_equal(out.to_host(), b)
+    g = hal.alloc(100)
+    hal.gather_sample(g, hal.copy_from(a), 3, 100, 9)
+    assert np.array_equal(g.to_host(), a[3::9][:100])
+    into = hal.copy_from(np.zeros(50, np.uint32))
+    offsets = np.array([4, 9, 2, 30, 31], np.uint32)
+    vals = rnd(rng, 5)
+    hal.scatter(into, hal.copy_from(np.array([0, 2, 5], np.uint32)), hal.copy_from(offsets), hal.copy_from(vals), 3)
+    want = np.zeros(50, np.uint32)
+    want[offsets] = vals
+    assert np.array_equal(into.to_host(), want)
+
+
+def test_argument_errors_are_reported_not_crashed(hal):
+    import hyperfridge_r0_amd as r0
+    small = hal.alloc(16)
+    with pytest.raises(r0.R0HipError):
+        hal.batch_interpolate_ntt(small, 4, 10)  # buffer too small
+    with pytest.raises(r0.R0HipError):
+        hal.batch_interpolate_ntt(small, 1, 30)  # size beyond the two-adicity the tables cover
+    with pytest.raises(r0.R0HipError):
+        hal.prefix_products(small, 3)
+    with pytest.raises(r0.R0HipError):
+        hal.load_circuit(np.zeros(10, np.uint32))
+
+
+@pytest.mark.parametrize("name,po2", [("tiny", 9), ("small", 11)])
+def test_witgen_accum_eval_check(hal, orc, name, po2):
+    blob = np.fromfile(circuit_path(name), dtype=np.uint32)
+    oc = orc.circuit(blob)
+    gc = hal.load_circuit(blob)  # eval_check compiled in-process (hipRTC)
+    assert gc.group_size == oc.group_size and gc.n_taps == oc.n_taps
+    code, data, glob = hal.witgen(gc, po2, seed=5)
+    ocode, odata, oglob = oc.witgen(po2, seed=5)
+    assert np.array_equal(code.to_host(), ocode) and np.array_equal(data.to_host(), odata) and np.array_equal(glob, oglob)
+    rng = np.random.default_rng(1)
+    mix = rnd(rng, oc.n_mix)
+    accum = hal.accum(gc, po2, code, data, mix)
+    oaccum = oc.accum(po2, ocode, odata, mix)
+    assert np.array_equal(accum.to_host(), oaccum)
+    # eval_check on arbitrary (not even low-degree) group evaluations: pure arithmetic parity
+    dom = 4 << po2
+    ea, ec, ed = (rnd(rng, oc.group_size[g] * dom) for g in range(3))
+    pm = rnd(rng, 4)
+    check = hal.eval_check(gc, po2, hal.copy_from(ea), hal.copy_from(ec), hal.copy_from(ed), glob, mix, pm)
+    assert np.array_equal(check.to_host(), oc.eval_check(po2, ea, ec, ed, glob, mix, pm))
+
+
+@pytest.mark.parametrize("name,po2,seed", [("tiny", 9, 1), ("tiny", 12, 2), ("small", 10, 3), ("small", 13, 4)])
+def test_prove_segment_seal_is_bit_identical_to_the_oracle_and_verifies(hal, orc, name, po2, seed):
+    blob = np.fromfile(circuit_path(name), dtype=np.uint32)
+    oc = orc.circuit(blob)
+    gc = hal.load_circuit(blob)
+    code, data, glob = hal.witgen(gc, po2, seed)
+    seal = hal.prove_segment(gc, po2, code, data, glob)
+    assert oc.verify(seal) == (0, "ok")
+    want = oc.prove(po2, code.to_host(), data.to_host(), glob)
+    assert seal.size == want.size and np.array_equal(seal, want)
+    prof = hal.last_profile()
+    assert [n for n, _ in prof][:3] == ["transcript_seed", "commit_code", "commit_data"]
+
+
+def test_prove_segment_rejects_a_witness_that_breaks_the_taps(hal, orc):
+    import hyperfridge_r0_amd as r0
+    blob = np.fromfile(circuit_path("tiny"), dtype=np.uint32)
+    oc = orc.circuit(blob)
+    gc = hal.load_circuit(blob)
+    code, data, glob = hal.witgen(gc, 9, 1)
+    bad = data.to_host()
+    bad[-1] = (int(bad[-1]) + 1) % P
+    data.upload(bad)
+    # the DEEP quotients still divide (they only depend on consistency of openings), so a seal comes out --
+    # but the constraint identity at z fails and the verifier must say so
+    seal = hal.prove_segment(gc, 9, code, data, glob)
+    assert oc.verify(seal)[0] == 4
