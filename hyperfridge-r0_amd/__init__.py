@@ -69,6 +69,8 @@ _SIGNATURES = {
     "r0h_accum": [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
     "r0h_eval_check": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "r0h_prove_segment": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)],
+    "r0h_kernel_timing": [_vp, _c.c_int],
+    "r0h_kernel_stats": [_vp, _vp, _sz],
     "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],
 }
 _PLAIN = {
@@ -329,6 +331,15 @@ class Hal:
         _check(lib().r0h_prove_segment(self.ctx, circuit.handle, po2, code.handle, data.handle, pg,
                                        seal.ctypes.data_as(_vp), seal.size, ctypes.byref(n)))
         return seal[:n.value].copy()
+
+    def kernel_timing(self, enable=True):
+        _check(lib().r0h_kernel_timing(self.ctx, 1 if enable else 0))
+
+    def kernel_stats(self):
+        import json
+        buf = ctypes.create_string_buffer(1 << 16)
+        _check(lib().r0h_kernel_stats(self.ctx, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def last_profile(self):
         names = _c.POINTER(_cp)()

@@ -175,12 +175,17 @@ static uint32_t flatten(const r0h_circuit* c, uint32_t m, uint32_t base_pow, std
   return pow - base_pow;
 }
 
+static uint32_t tunable_budget() {
+  const char* v = getenv("R0H_EC_BUDGET");
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : 5000u;
+}
+
 static void make_plan(r0h_circuit* c) {
   Plan& pl = c->plan;
   std::vector<uint32_t> gates;
   pl.n_pow = flatten(c, c->ret, 0, gates, pl.terms);
   // cut into kernels of bounded arithmetic: cost of a term = its not-yet-emitted expression nodes + 8
-  const uint32_t budget = 2500;
+  const uint32_t budget = tunable_budget();
   std::vector<uint32_t> stamp(c->fp_step.size(), UINT32_MAX);
   uint32_t kernel = 0, cost = 0;
   pl.cut.assign(1, 0);
@@ -272,21 +277,42 @@ static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& don
   }
 }
 
+// Code-generation tunables (environment overrides exist for experiments; defaults are the measured best):
+//   R0H_EC_BUDGET  expression nodes per kernel          R0H_EC_SCOPE  terms per register scope (0 = one scope)
+//   R0H_EC_WAVES   __launch_bounds__ waves/SIMD hint (0 = none)
+static uint32_t tunable(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
 static std::string emit_source(const r0h_circuit* c) {
   const Plan& pl = c->plan;
+  const uint32_t scope_terms = tunable("R0H_EC_SCOPE", 0), waves = tunable("R0H_EC_WAVES", 0);
   std::ostringstream os;
   os << PRELUDE;
   os << "// terms: " << pl.terms.size() << ", powers of poly_mix: " << pl.n_pow << ", kernels: " << pl.cut.size() - 1 << "\n";
   for (size_t k = 0; k + 1 < pl.cut.size(); k++) {
-    os << "extern \"C\" __global__ __launch_bounds__(256) void eval_check_" << k
+    os << "extern \"C\" __global__ __launch_bounds__(256";
+    if (waves) os << ", " << waves;
+    os << ") void eval_check_" << k
        << "(u32* __restrict__ check, const u32* __restrict__ g0, const u32* __restrict__ g1, const u32* __restrict__ g2,\n"
           "    const u32* __restrict__ glob, const u32* __restrict__ mix, const u32* __restrict__ mixpow,\n"
           "    const u32* __restrict__ inv_van, u32 po2, u32 accumulate) {\n"
           "  const u32 domain = 4u << po2, mask = domain - 1u;\n"
           "  const u32 i = blockIdx.x * 256u + threadIdx.x;\n"
           "  u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;\n";
+    // Terms are emitted in register scopes: every scope re-loads the taps and re-derives the sub-expressions it needs, and
+    // a scheduling barrier keeps the compiler from hoisting the next scope's loads, so the live set is bounded by the
+    // scope, not by the circuit.
     std::vector<bool> done(c->fp_step.size(), false);
+    uint32_t in_scope = 0;
+    os << "  {\n";
     for (uint32_t t = pl.cut[k]; t < pl.cut[k + 1]; t++) {
+      if (scope_terms && in_scope == scope_terms) {
+        os << "  }\n  __builtin_amdgcn_sched_barrier(0);\n  {\n";
+        std::fill(done.begin(), done.end(), false);
+        in_scope = 0;
+      }
       const Term& tm = pl.terms[t];
       emit_var(c, tm.v, done, os);
       for (uint32_t g : tm.conds) emit_var(c, g, done, os);
@@ -295,7 +321,9 @@ static std::string emit_source(const r0h_circuit* c) {
       os << "v" << tm.v;
       for (size_t g = 0; g < tm.conds.size(); g++) os << ")";
       os << ");\n";
+      in_scope++;
     }
+    os << "  }\n";
     os << "  const u32 iv = inv_van[i & 3u];\n"
           "  t0 = fmul(t0, iv); t1 = fmul(t1, iv); t2 = fmul(t2, iv); t3 = fmul(t3, iv);\n"
           "  if (accumulate) {\n"
@@ -427,21 +455,23 @@ const char* r0h_circuit_load(r0h_ctx* ctx, const uint32_t* blob, size_t n_words,
   }
   hipError_t e = hipModuleLoadData(&c->module, code.data());
   if (e != hipSuccess) { delete c; return make_error("r0h_circuit_load: hipModuleLoadData: %s", hipGetErrorString(e)); }
-  for (size_t k = 0; k + 1 < c->plan.cut.size(); k++) {
+  for (size_t k = 0;; k++) {  // the code object decides into how many kernels the program was cut
     char name[64];
     snprintf(name, sizeof name, "eval_check_%zu", k);
     hipFunction_t fn;
-    e = hipModuleGetFunction(&fn, c->module, name);
-    if (e != hipSuccess) {
-      hipModuleUnload(c->module);
-      delete c;
-      return make_error("r0h_circuit_load: the code object lacks %s (built from another blob?): %s", name, hipGetErrorString(e));
-    }
+    if (hipModuleGetFunction(&fn, c->module, name) != hipSuccess) break;
     c->kernels.push_back(fn);
+  }
+  (void)hipGetLastError();
+  if (c->kernels.empty() && !c->plan.terms.empty()) {
+    hipModuleUnload(c->module);
+    delete c;
+    return make_error("r0h_circuit_load: the code object has no eval_check_0 (built from another source?)");
   }
   size_t words = c->n_global + c->n_mix + 4 * (size_t)c->plan.n_pow + 4;
   e = hipMalloc((void**)&c->d_params, words * 4);
   if (e != hipSuccess) { hipModuleUnload(c->module); delete c; return make_error("r0h_circuit_load: hipMalloc: %s", hipGetErrorString(e)); }
+  ctx_retain(ctx);
   *out = c;
   return nullptr;
   R0H_GUARD_END
@@ -449,11 +479,13 @@ const char* r0h_circuit_load(r0h_ctx* ctx, const uint32_t* blob, size_t n_words,
 
 const char* r0h_circuit_free(r0h_circuit* c) {
   if (!c) return nullptr;
-  hipSetDevice(c->ctx->device);
-  hipStreamSynchronize(c->ctx->stream);
-  if (c->d_params) hipFree(c->d_params);
-  if (c->module) hipModuleUnload(c->module);
+  r0h_ctx* ctx = c->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (c->d_params) (void)hipFree(c->d_params);
+  if (c->module) (void)hipModuleUnload(c->module);
   delete c;
+  ctx_release(ctx);
   return nullptr;
 }
 
@@ -548,6 +580,9 @@ const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, con
   uint32_t* d_check = u32(check);
   const uint32_t *g0 = u32(g[0]), *g1 = u32(g[1]), *g2 = u32(g[2]);
   const uint32_t *d_glob = c->d_params, *d_mix = d_glob + c->n_global, *d_pow = d_mix + c->n_mix, *d_van = d_pow + 4 * (size_t)c->plan.n_pow;
+  double alg = (double)domain * 16;
+  for (int k = 0; k < 3; k++) alg += (double)domain * c->group_size[k] * 4;
+  KScope ks(ctx, "eval_check", alg);
   for (size_t k = 0; k < c->kernels.size(); k++) {
     uint32_t accumulate = k ? 1u : 0u;
     void* args[] = {&d_check, &g0, &g1, &g2, &d_glob, &d_mix, &d_pow, &d_van, &po2, &accumulate};

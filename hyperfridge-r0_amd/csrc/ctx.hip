@@ -96,6 +96,21 @@ const char* ensure_scratch(r0h_ctx* ctx, size_t bytes) {
   return nullptr;
 }
 
+void ctx_retain(r0h_ctx* ctx) { ctx->refs++; }
+void ctx_release(r0h_ctx* ctx) {
+  if (--ctx->refs > 0) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int d = 0; d < 2; d++) { (void)hipFree(ctx->tw_lo[d]); (void)hipFree(ctx->tw_hi[d]); (void)hipFree(ctx->tw12[d]); }
+  (void)hipFree(ctx->pow3_lo); (void)hipFree(ctx->pow3_hi); (void)hipFree(ctx->p2); (void)hipFree(ctx->scratch);
+  (void)hipHostFree(ctx->pinned);
+  for (hipEvent_t e : ctx->prof.events) (void)hipEventDestroy(e);
+  for (auto& kv : ctx->ktimers)
+    for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
 static const char* upload_pow_table(uint32_t** dst, uint32_t base, uint32_t n) {
   std::vector<uint32_t> t(n);
   uint32_t cur = ONE;
@@ -145,14 +160,9 @@ const char* r0h_ctx_create(int device, r0h_ctx** out) {
 
 const char* r0h_ctx_destroy(r0h_ctx* ctx) {
   if (!ctx) return nullptr;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  for (int d = 0; d < 2; d++) { hipFree(ctx->tw_lo[d]); hipFree(ctx->tw_hi[d]); hipFree(ctx->tw12[d]); }
-  hipFree(ctx->pow3_lo); hipFree(ctx->pow3_hi); hipFree(ctx->p2); hipFree(ctx->scratch);
-  hipHostFree(ctx->pinned);
-  for (hipEvent_t e : ctx->prof.events) hipEventDestroy(e);
-  hipStreamDestroy(ctx->stream);
-  delete ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx_release(ctx);  // buffers and circuits still alive keep the device state until they are freed
   return nullptr;
 }
 
@@ -184,6 +194,7 @@ const char* r0h_buf_alloc(r0h_ctx* ctx, size_t bytes, r0h_buf** out) {
     delete b;
     return make_error("r0h_buf_alloc(%zu bytes): %s", bytes, hipGetErrorString(e));
   }
+  ctx_retain(ctx);
   *out = b;
   return nullptr;
   R0H_GUARD_END
@@ -194,6 +205,7 @@ const char* r0h_buf_wrap(r0h_ctx* ctx, void* device_ptr, size_t bytes, r0h_buf**
   R0H_REQUIRE(ctx && out && device_ptr, "r0h_buf_wrap: NULL argument");
   r0h_buf* b = new r0h_buf();
   b->ctx = ctx; b->ptr = device_ptr; b->bytes = bytes; b->owned = false;
+  ctx_retain(ctx);
   *out = b;
   return nullptr;
   R0H_GUARD_END
@@ -206,6 +218,7 @@ const char* r0h_buf_slice(r0h_buf* parent, size_t off, size_t bytes, r0h_buf** o
   r0h_buf* b = new r0h_buf();
   b->ctx = parent->ctx; b->ptr = (char*)parent->ptr + off; b->bytes = bytes; b->parent = parent; b->owned = false;
   parent->refs++;
+  ctx_retain(parent->ctx);
   *out = b;
   return nullptr;
   R0H_GUARD_END
@@ -221,7 +234,9 @@ const char* r0h_buf_free(r0h_buf* b) {
       hipError_t e = hipFree(b->ptr);
       if (e != hipSuccess) return make_error("r0h_buf_free: %s", hipGetErrorString(e));
     }
+    r0h_ctx* ctx = b->ctx;
     delete b;
+    ctx_release(ctx);
     b = parent;
   }
   return nullptr;
@@ -249,6 +264,40 @@ const char* r0h_buf_zero(r0h_ctx* ctx, r0h_buf* buf) {
   R0H_REQUIRE(ctx && buf, "r0h_buf_zero: NULL argument");
   R0H_TRY_HIP(hipMemsetAsync(buf->ptr, 0, buf->bytes, ctx->stream));
   return nullptr;
+}
+
+const char* r0h_kernel_timing(r0h_ctx* ctx, int enable) {
+  R0H_REQUIRE(ctx, "r0h_kernel_timing: ctx is NULL");
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->ktime_on = enable != 0;
+  for (auto& kv : ctx->ktimers) { kv.second.used = 0; kv.second.alg_bytes = 0; }
+  return nullptr;
+}
+
+const char* r0h_kernel_stats(r0h_ctx* ctx, char* json_out, size_t capacity) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && json_out && capacity, "r0h_kernel_stats: NULL argument");
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  std::string js = "{";
+  bool first = true;
+  for (auto& kv : ctx->ktimers) {
+    double total = 0;
+    for (size_t i = 0; i + 1 < kv.second.used; i += 2) {
+      float ms = 0;
+      R0H_TRY_HIP(hipEventElapsedTime(&ms, kv.second.ev[i], kv.second.ev[i + 1]));
+      total += ms;
+    }
+    char item[256];
+    snprintf(item, sizeof item, "%s\"%s\": {\"launches\": %zu, \"total_ms\": %.6f, \"alg_bytes\": %.0f}", first ? "" : ", ",
+             kv.first.c_str(), kv.second.used / 2, total, kv.second.alg_bytes);
+    js += item;
+    first = false;
+  }
+  js += "}";
+  R0H_REQUIRE(js.size() + 1 <= capacity, "r0h_kernel_stats: need %zu bytes", js.size() + 1);
+  memcpy(json_out, js.c_str(), js.size() + 1);
+  return nullptr;
+  R0H_GUARD_END
 }
 
 void* r0h_buf_device_ptr(const r0h_buf* buf) { return buf ? buf->ptr : nullptr; }

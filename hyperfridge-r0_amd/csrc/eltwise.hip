@@ -312,6 +312,7 @@ const char* r0h_batch_evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t
     for (uint32_t k = 0; k < ng; k++) { host[k] = which[g.second[k]]; host[ng + k] = g.second[k]; }
     R0H_TRY_HIP(hipMemcpyAsync(idx, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     Fp4 x = Fp4{{g.first[0], g.first[1], g.first[2], g.first[3]}};
+    KScope ks(ctx, "batch_evaluate_any", 4.0 * ng * (double)(1u << po2));
     hipLaunchKernelGGL(eval_tables_kernel, dim3((rl + rows + 255) / 256), dim3(256), 0, ctx->stream, tab, x, rl, rows);
     hipLaunchKernelGGL(eval_rows_kernel, dim3(blocks, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((ng + 63) / 64), dim3(64), 0, ctx->stream, u32(out), part, idx + ng, blocks, ng);
@@ -352,6 +353,7 @@ const char* r0h_mix_poly_coeffs(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mi
   R0H_TRY(ensure_scratch(ctx, params.size() * 4));
   R0H_TRY_HIP(hipMemcpyAsync(ctx->scratch, params.data(), params.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   uint32_t n = 1u << po2, threads = n < 256 ? n : 256;
+  KScope ks(ctx, "mix_poly_kernel", 4.0 * input_count * (double)n + 32.0 * n_groups * (double)n);
   hipLaunchKernelGGL(mix_poly_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(combos), u32(input), (const uint32_t*)ctx->scratch, n_groups, po2);
   R0H_TRY(launch_ok("mix_poly_kernel"));
   R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // params live in shared scratch and a host vector
@@ -439,6 +441,7 @@ const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint3
   pw.zChunk = fp4_pow(pw.z, g.chunk);
   R0H_TRY(ensure_scratch(ctx, (size_t)(g.n_chunks + 1) * 16));
   uint32_t* cv = (uint32_t*)ctx->scratch;
+  KScope ks(ctx, "poly_divide", 48.0 * n);
   hipLaunchKernelGGL(divide_chunk_sum_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, cv, u32(poly), pw, g.E);
   hipLaunchKernelGGL(divide_chunk_carry_kernel, dim3(1), dim3(1), 0, ctx->stream, cv, pw, g.n_chunks);
   hipLaunchKernelGGL(divide_apply_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, u32(poly), cv, pw, g.E);

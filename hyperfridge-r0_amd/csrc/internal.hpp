@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,13 @@ struct P2Consts {
   uint32_t diag[P2_CELLS];
 };
 
+// Optional per-kernel timing (HIP events on the context's stream around every launch of a named kernel family).
+struct KTimer {
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  size_t used = 0;
+  double alg_bytes = 0;        // algorithmic HBM bytes of the recorded launches
+};
+
 struct Profile {
   std::vector<const char*> names;
   std::vector<float> ms;
@@ -58,6 +66,8 @@ struct Profile {
 
 struct r0h_ctx {
   int device = 0;
+  int refs = 1;  // the handle itself + every live buffer / circuit: teardown happens when the last one goes
+
   hipStream_t stream = nullptr;
   // twiddles: tw_lo[d][i] = w^i, tw_hi[d][i] = w^(i*2^11) with w = ROU_{FWD,REV}[22]; d = 0 forward, 1 inverse
   uint32_t* tw_lo[2] = {nullptr, nullptr};
@@ -73,6 +83,8 @@ struct r0h_ctx {
   void* pinned = nullptr;       // pinned host staging
   size_t pinned_bytes = 0;
   r0h::Profile prof;
+  bool ktime_on = false;
+  std::map<std::string, r0h::KTimer> ktimers;
 };
 
 struct r0h_buf {
@@ -86,7 +98,32 @@ struct r0h_buf {
 
 namespace r0h {
 inline uint32_t* u32(const r0h_buf* b) { return (uint32_t*)b->ptr; }
+// RAII bracket around the launches of one kernel family; no-op unless r0h_kernel_timing(ctx, 1) was called
+struct KScope {
+  r0h_ctx* ctx;
+  KTimer* t = nullptr;
+  KScope(r0h_ctx* c, const char* name, double alg_bytes) : ctx(c) {
+    if (!c->ktime_on) return;
+    t = &c->ktimers[name];
+    if (t->ev.size() < t->used + 2) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      t->ev.push_back(a);
+      t->ev.push_back(b);
+    }
+    t->alg_bytes += alg_bytes;
+    (void)hipEventRecord(t->ev[t->used], c->stream);
+  }
+  ~KScope() {
+    if (!t) return;
+    (void)hipEventRecord(t->ev[t->used + 1], ctx->stream);
+    t->used += 2;
+  }
+};
 const char* ensure_scratch(r0h_ctx* ctx, size_t bytes);
+void ctx_retain(r0h_ctx* ctx);
+void ctx_release(r0h_ctx* ctx);
 // host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table
 void p2_mix_host(const P2Consts& k, uint32_t* cells);
 void p2_hash_elems_host(const P2Consts& k, const uint32_t* elems, size_t n, uint32_t digest[8]);

@@ -171,10 +171,12 @@ const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count,
   const uint32_t norm = inv(enc(1u << po2));
   TwTables tw{ctx->tw_lo[1], ctx->tw_hi[1], ctx->tw12[1]};
   if (sp.H) {
+    KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << po2));
     dim3 grid(1u << (sp.L - sp.tlog), count);
     hipLaunchKernelGGL(ntt_strided_kernel<1>, grid, dim3(512), (size_t)4 << (sp.H + sp.tlog), ctx->stream, u32(io), po2, sp.L, sp.H, sp.tlog, tw);
     R0H_TRY(launch_check("ntt_strided_kernel<inv>"));
   }
+  KScope ks(ctx, "ntt_local_kernel", 8.0 * count * (double)(1u << po2));
   dim3 grid(1u << (po2 - sp.L), count);
   hipLaunchKernelGGL(ntt_local_kernel<1>, grid, dim3(256), (size_t)4 << sp.L, ctx->stream, u32(io), u32(io), sp.L, po2, 0u, tw.tw12, norm);
   return launch_check("ntt_local_kernel<inv>");
@@ -195,9 +197,13 @@ const char* r0h_batch_expand_into_evaluate_ntt(r0h_ctx* ctx, r0h_buf* out, const
   R0H_REQUIRE(expand_bits < sp.L, "r0h_batch_expand_into_evaluate_ntt: expand_bits %u too large for size 2^%u", expand_bits, n);
   TwTables tw{ctx->tw_lo[0], ctx->tw_hi[0], ctx->tw12[0]};
   dim3 grid(1u << (n - sp.L), count);
-  hipLaunchKernelGGL(ntt_local_kernel<0>, grid, dim3(256), (size_t)4 << sp.L, ctx->stream, u32(out), u32(in), sp.L, n, expand_bits, tw.tw12, 0u);
+  {
+    KScope ks(ctx, "ntt_local_kernel", 4.0 * count * ((double)(1u << n) + (double)(1u << in_po2)));
+    hipLaunchKernelGGL(ntt_local_kernel<0>, grid, dim3(256), (size_t)4 << sp.L, ctx->stream, u32(out), u32(in), sp.L, n, expand_bits, tw.tw12, 0u);
+  }
   R0H_TRY(launch_check("ntt_local_kernel<fwd>"));
   if (sp.H) {
+    KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << n));
     dim3 grid2(1u << (sp.L - sp.tlog), count);
     hipLaunchKernelGGL(ntt_strided_kernel<0>, grid2, dim3(512), (size_t)4 << (sp.H + sp.tlog), ctx->stream, u32(out), n, sp.L, sp.H, sp.tlog, tw);
     R0H_TRY(launch_check("ntt_strided_kernel<fwd>"));
@@ -213,6 +219,7 @@ const char* r0h_batch_bit_reverse(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uin
   R0H_REQUIRE(((size_t)count << po2) * 4 <= io->bytes, "r0h_batch_bit_reverse: %u columns of 2^%u exceed the buffer", count, po2);
   if (!count || po2 == 0) return nullptr;
   uint32_t threads = po2 >= 8 ? 256 : (1u << po2);
+  KScope ks(ctx, "bit_reverse_kernel", 8.0 * count * (double)(1u << po2));
   dim3 grid((1u << po2) / threads, count);
   hipLaunchKernelGGL(bit_reverse_kernel, grid, dim3(threads), 0, ctx->stream, u32(io), po2);
   return launch_check("bit_reverse_kernel");
@@ -226,6 +233,7 @@ const char* r0h_zk_shift(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2
   R0H_REQUIRE(((size_t)count << po2) * 4 <= io->bytes, "r0h_zk_shift: %u columns of 2^%u exceed the buffer", count, po2);
   if (!count) return nullptr;
   uint32_t threads = po2 >= 8 ? 256 : (1u << po2);
+  KScope ks(ctx, "zk_shift_kernel", 8.0 * count * (double)(1u << po2));
   dim3 grid((1u << po2) / threads, count);
   hipLaunchKernelGGL(zk_shift_kernel, grid, dim3(threads), 0, ctx->stream, u32(io), po2, ctx->pow3_lo, ctx->pow3_hi);
   return launch_check("zk_shift_kernel");

@@ -116,6 +116,7 @@ const char* r0h_hash_rows(r0h_ctx* ctx, r0h_buf* digests, const r0h_buf* matrix,
   R0H_REQUIRE((size_t)rows * 32 <= digests->bytes, "r0h_hash_rows: %u digests exceed the output buffer", rows);
   R0H_REQUIRE(((uintptr_t)digests->ptr & 15) == 0, "r0h_hash_rows: digest buffer must be 16-byte aligned");
   if (!rows) return nullptr;
+  KScope ks(ctx, "hash_rows_kernel", (double)rows * cols * 4 + (double)rows * 32);
   hipLaunchKernelGGL(hash_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, u32(digests), u32(matrix), rows, cols, ctx->p2);
   hipError_t e = hipGetLastError();
   R0H_REQUIRE(e == hipSuccess, "hash_rows_kernel: %s", hipGetErrorString(e));
@@ -129,6 +130,7 @@ const char* r0h_hash_fold(r0h_ctx* ctx, r0h_buf* nodes, uint32_t output_size) {
   R0H_REQUIRE((size_t)output_size * 4 * 32 <= nodes->bytes, "r0h_hash_fold: output_size %u needs %zu bytes of nodes", output_size, (size_t)output_size * 128);
   R0H_REQUIRE(((uintptr_t)nodes->ptr & 15) == 0, "r0h_hash_fold: node buffer must be 16-byte aligned");
   if (!output_size) return nullptr;
+  KScope ks(ctx, "hash_fold_kernel", (double)output_size * 96);
   hipLaunchKernelGGL(hash_fold_kernel, dim3((output_size + 255) / 256), dim3(256), 0, ctx->stream, u32(nodes), output_size, ctx->p2);
   hipError_t e = hipGetLastError();
   R0H_REQUIRE(e == hipSuccess, "hash_fold_kernel: %s", hipGetErrorString(e));

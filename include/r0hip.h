@@ -129,6 +129,11 @@ const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, 
 /* Per-phase device time of the last r0h_prove_segment on this context (ms), for bench.py; names are static strings. */
 const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out);
 
+/* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
+ * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */
+const char* r0h_kernel_timing(r0h_ctx* ctx, int enable);
+const char* r0h_kernel_stats(r0h_ctx* ctx, char* json_out, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

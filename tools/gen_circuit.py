@@ -125,25 +125,33 @@ def fp4_mul_sym(b, x, y):
     return [b.add(c[0], b.mul(beta, c[4])), b.add(c[1], b.mul(beta, c[5])), b.add(c[2], b.mul(beta, c[6])), c[3]]
 
 
-def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5):
+def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5, comp=16):
+    """Columns are grouped into components of `comp` DATA columns (as a real circuit's registers belong to one
+    instruction/memory/... component): a derived column reads its own or the previous component, and a constraint
+    touches the taps of one component plus CODE selectors.  Constraints are emitted component by component."""
     rng = Rng(seed)
-    assert n_code >= 4 and n_free >= max(2, n_global) and n_data > n_free
+    n_comp = (n_data + comp - 1) // comp
+    free_per = max(1, n_free // n_comp)
+    assert n_code >= 4 and n_data > n_free and free_per < comp
     code_cols = [(0, 0), (1, 0), (2, 0)] + [(3, k) for k in range(3, n_code)]
+    is_free = [(k % comp) < free_per for k in range(n_data)]
+    assert sum(is_free) >= max(2, n_global)
     data_cols = []
     for k in range(n_data):
-        if k < n_free:
+        if is_free[k]:
             data_cols.append((0, 0, 0, 0, 0))
             continue
+        lo = max(0, (k // comp - 1) * comp)  # start of the previous component
 
         def pick_ref():
             if rng.below(100) < 85:
-                return ref(G_DATA, rng.below(k), rng.pick([0, 0, 0, 1, 1, 2]))
+                return ref(G_DATA, lo + rng.below(k - lo), rng.pick([0, 0, 0, 1, 1, 2]))
             return ref(G_CODE, rng.below(n_code), rng.pick([0, 0, 1]))
 
         kind = 2 if rng.below(3) == 0 else 1
         data_cols.append((kind, pick_ref(), pick_ref(), pick_ref() if kind == 2 else 0, pick_ref()))
     acc_cols = [(0, rng.below(n_data), rng.below(n_data)) for _ in range(n_acc)]
-    global_cols = list(range(n_global))
+    global_cols = [k for k in range(n_data) if is_free[k]][:n_global]
 
     b = Builder()
     for g, size in ((G_ACCUM, 4 * n_acc), (G_CODE, n_code), (G_DATA, n_data)):
@@ -155,15 +163,28 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5)
 
     one = b.const(1)
     first = b.get(G_CODE, 0, 0)
-    defects = []  # (fp var of (column - definition), degree): zero on every trace row
-    for k in range(n_free, n_data):
+    by_comp = [[] for _ in range(n_comp)]  # per component: (fp var that is zero on every trace row, degree)
+    defects = [[] for _ in range(n_comp)]
+    for k in range(n_data):
+        if is_free[k]:
+            continue
         kind, ra, rb, rc, re = data_cols[k]
         prod = b.mul(rget(ra), rget(rb))
         if kind == 2:
             prod = b.mul(prod, rget(rc))
-        defects.append((b.sub(b.get(G_DATA, k, 0), b.add(prod, rget(re))), kind + 1))
-    glob_defects = [(b.mul(first, b.sub(b.get(G_DATA, global_cols[k], 0), b.glob(0, k))), 2) for k in range(n_global)]
-    acc_defects = []
+        d = (b.sub(b.get(G_DATA, k, 0), b.add(prod, rget(re))), kind + 1)
+        defects[k // comp].append(d)
+        by_comp[k // comp].append(d)
+    for q in range(n_comp):
+        cols = range(q * comp, min(n_data, (q + 1) * comp))
+        pool = sorted(t for t in b.taps if (t[0] == G_DATA and t[1] in cols)) + [(G_CODE, c, 0) for c in range(n_code)]
+        share = n_pad // n_comp + (1 if q < n_pad % n_comp else 0)
+        for _ in range(share):
+            d, deg = rng.pick(defects[q])
+            t = [b.get(*rng.pick(pool)) for _ in range(7)]
+            g = b.add(b.add(b.add(b.add(b.mul(t[0], t[1]), b.mul(t[2], t[3])), t[4]), t[5]), t[6])
+            by_comp[q].append((b.mul(d, g), deg + 2))
+    tail = [(b.mul(first, b.sub(b.get(G_DATA, global_cols[k], 0), b.glob(0, k))), 2) for k in range(n_global)]
     not_first = b.sub(one, first)
     for j, (_, ca, cb) in enumerate(acc_cols):
         a, bb = b.get(G_DATA, ca, 0), b.get(G_DATA, cb, 0)
@@ -175,17 +196,9 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5)
         sel = [b.mul(not_first, prev[i]) for i in range(4)]
         sel[0] = b.add(sel[0], first)
         want = fp4_mul_sym(b, term, sel)
-        acc_defects.extend((b.sub(b.get(G_ACCUM, 4 * j + i, 0), want[i]), 3) for i in range(4))
+        tail.extend((b.sub(b.get(G_ACCUM, 4 * j + i, 0), want[i]), 3) for i in range(4))
 
-    pad = []
-    tap_pool = sorted(b.taps)
-    for _ in range(n_pad):
-        d, deg = rng.pick(defects)
-        t = [b.get(*rng.pick(tap_pool)) for _ in range(7)]
-        g = b.add(b.add(b.add(b.add(b.mul(t[0], t[1]), b.mul(t[2], t[3])), t[4]), t[5]), t[6])
-        pad.append((b.mul(d, g), deg + 2))
-
-    all_vals = defects + glob_defects + acc_defects + pad
+    all_vals = [v for q in range(n_comp) for v in by_comp[q]] + tail
     assert max(deg for _, deg in all_vals) <= 5  # check = C / (x^N - 1) must stay below degree 4N
     # constraint chain; every cond_every-th run of 8 constraints sits inside an AndCond gated by a CODE column.
     # The gate costs one degree, so only runs of degree <= 4 may be gated.
@@ -224,14 +237,14 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5)
     words += section(SEC_WITGEN, [n_code] + [w for cc in code_cols for w in cc] + [n_data] + [w for d in data_cols for w in d])
     words += section(SEC_ACCUM, [n_acc] + [w for a in acc_cols for w in a])
     info = {"taps": len(taps), "steps": len(steps), "constraints": len(all_vals), "mul_per_point": b.n_mul,
-            "addsub_per_point": b.n_add, "groups": [4 * n_acc, n_code, n_data]}
+            "addsub_per_point": b.n_add, "groups": [4 * n_acc, n_code, n_data], "components": n_comp}
     return words, info
 
 
 SHAPES = {
-    "tiny": dict(n_code=4, n_data=12, n_acc=2, n_free=4, n_pad=6, n_global=2, seed=1),
-    "small": dict(n_code=8, n_data=40, n_acc=4, n_free=8, n_pad=60, n_global=4, seed=2),
-    "bench": dict(n_code=16, n_data=192, n_acc=12, n_free=24, n_pad=2350, n_global=8, seed=3),
+    "tiny": dict(n_code=4, n_data=12, n_acc=2, n_free=4, n_pad=6, n_global=2, seed=1, comp=6),
+    "small": dict(n_code=8, n_data=40, n_acc=4, n_free=8, n_pad=60, n_global=4, seed=2, comp=10),
+    "bench": dict(n_code=16, n_data=192, n_acc=12, n_free=24, n_pad=2600, n_global=8, seed=3, comp=16),
 }
 
 
