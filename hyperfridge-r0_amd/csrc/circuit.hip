@@ -471,6 +471,11 @@ const char* r0h_circuit_load(r0h_ctx* ctx, const uint32_t* blob, size_t n_words,
   size_t words = c->n_global + c->n_mix + 4 * (size_t)c->plan.n_pow + 4;
   e = hipMalloc((void**)&c->d_params, words * 4);
   if (e != hipSuccess) { hipModuleUnload(c->module); delete c; return make_error("r0h_circuit_load: hipMalloc: %s", hipGetErrorString(e)); }
+  {  // transcript digest of the blob, cached: every segment proof commits to it
+    std::vector<uint32_t> be(c->blob.size());
+    for (size_t i = 0; i < be.size(); i++) be[i] = enc(c->blob[i] % P);
+    p2_hash_elems_host(ctx->p2_host, be.data(), be.size(), c->blob_digest);
+  }
   ctx_retain(ctx);
   *out = c;
   return nullptr;
@@ -504,7 +509,7 @@ const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_
   for (uint32_t k = 0; k < nc; k++) { kinds[2 * k] = c->code_cols[k].kind; kinds[2 * k + 1] = (1u << 16) | k; }
   for (uint32_t k = 0; k < nd; k++) { kinds[2 * (nc + k)] = c->data_cols[k].kind == 0 ? 3u : 99u; kinds[2 * (nc + k) + 1] = (2u << 16) | k; }
   R0H_TRY(ensure_scratch(ctx, kinds.size() * 4));
-  R0H_TRY_HIP(hipMemcpyAsync(ctx->scratch, kinds.data(), kinds.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  R0H_TRY(stage_h2d(ctx, ctx->scratch, kinds.data(), kinds.size() * 4));
   const uint32_t* dk = (const uint32_t*)ctx->scratch;
   hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nc), dim3(threads), 0, ctx->stream, u32(code), dk, po2, splitmix64_host(0xC0DEull));
   hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nd), dim3(threads), 0, ctx->stream, u32(data), dk + 2 * nc, po2, splitmix64_host(seed));
@@ -538,7 +543,7 @@ const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0
               "r0h_accum: buffers too small for 2^%u rows", po2);
   for (uint32_t i = 0; i < c->n_mix; i++) R0H_REQUIRE(mix[i] < P, "r0h_accum: mix[%u] not canonical", i);
   r0h_buf* term = nullptr;
-  R0H_TRY(r0h_buf_alloc(ctx, (size_t)n * 16, &term));
+  R0H_TRY(buf_alloc_pooled(ctx, (size_t)n * 16, &term));
   for (uint32_t j = 0; j < c->acc_cols.size(); j++) {
     Fp4 m0{{mix[8 * j], mix[8 * j + 1], mix[8 * j + 2], mix[8 * j + 3]}}, m1{{mix[8 * j + 4], mix[8 * j + 5], mix[8 * j + 6], mix[8 * j + 7]}};
     hipLaunchKernelGGL(accum_term_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(term), u32(data) + ((size_t)c->acc_cols[j].a << po2),
@@ -575,8 +580,7 @@ const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, con
     uint32_t three_n = fpow(enc(3), (uint64_t)1 << po2), w4 = rou_fwd(2), w = ONE;
     for (int k = 0; k < 4; k++) { *p++ = inv(sub(mul(three_n, w), ONE)); w = mul(w, w4); }
   }
-  R0H_TRY_HIP(hipMemcpyAsync(c->d_params, params.data(), params.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // params is a host temporary
+  R0H_TRY(stage_h2d(ctx, c->d_params, params.data(), params.size() * 4));
   uint32_t* d_check = u32(check);
   const uint32_t *g0 = u32(g[0]), *g1 = u32(g[1]), *g2 = u32(g[2]);
   const uint32_t *d_glob = c->d_params, *d_mix = d_glob + c->n_global, *d_pow = d_mix + c->n_mix, *d_van = d_pow + 4 * (size_t)c->plan.n_pow;

@@ -96,6 +96,45 @@ const char* ensure_scratch(r0h_ctx* ctx, size_t bytes) {
   return nullptr;
 }
 
+const char* stage_h2d(r0h_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return nullptr;
+  if (bytes > ctx->pinned_bytes / 2) {  // too large for the ring: plain blocking copy
+    R0H_TRY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return nullptr;
+  }
+  size_t need = (bytes + 255) & ~(size_t)255;
+  if (ctx->pinned_off + need > ctx->pinned_bytes) {
+    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // every earlier ring slot has been consumed
+    ctx->pinned_off = 0;
+  }
+  char* slot = (char*)ctx->pinned + ctx->pinned_off;
+  memcpy(slot, src, bytes);
+  ctx->pinned_off += need;
+  R0H_TRY_HIP(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return nullptr;
+}
+
+const char* buf_alloc_pooled(r0h_ctx* ctx, size_t bytes, r0h_buf** out) {
+  size_t sz = bytes ? (bytes + 255) & ~(size_t)255 : 256;
+  r0h_buf* b = new r0h_buf();
+  b->ctx = ctx; b->bytes = bytes; b->pooled = true;
+  auto it = ctx->pool.find(sz);
+  if (it != ctx->pool.end()) {
+    b->ptr = it->second;
+    ctx->pool.erase(it);
+  } else {
+    hipError_t e = hipMalloc(&b->ptr, sz);
+    if (e != hipSuccess) {
+      delete b;
+      return make_error("device allocation of %zu bytes failed: %s", sz, hipGetErrorString(e));
+    }
+  }
+  ctx_retain(ctx);
+  *out = b;
+  return nullptr;
+}
+
 void ctx_retain(r0h_ctx* ctx) { ctx->refs++; }
 void ctx_release(r0h_ctx* ctx) {
   if (--ctx->refs > 0) return;
@@ -104,6 +143,7 @@ void ctx_release(r0h_ctx* ctx) {
   for (int d = 0; d < 2; d++) { (void)hipFree(ctx->tw_lo[d]); (void)hipFree(ctx->tw_hi[d]); (void)hipFree(ctx->tw12[d]); }
   (void)hipFree(ctx->pow3_lo); (void)hipFree(ctx->pow3_hi); (void)hipFree(ctx->p2); (void)hipFree(ctx->scratch);
   (void)hipHostFree(ctx->pinned);
+  for (auto& kv : ctx->pool) (void)hipFree(kv.second);
   for (hipEvent_t e : ctx->prof.events) (void)hipEventDestroy(e);
   for (auto& kv : ctx->ktimers)
     for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
@@ -228,7 +268,10 @@ const char* r0h_buf_free(r0h_buf* b) {
   while (b) {
     if (--b->refs > 0) break;
     r0h_buf* parent = b->parent;
-    if (b->owned && b->ptr) {
+    if (b->pooled && b->ptr) {
+      // stream-ordered reuse: whoever takes this block next enqueues behind everything that used it
+      b->ctx->pool.emplace(b->bytes ? (b->bytes + 255) & ~(size_t)255 : 256, b->ptr);
+    } else if (b->owned && b->ptr) {
       hipSetDevice(b->ctx->device);
       hipStreamSynchronize(b->ctx->stream);
       hipError_t e = hipFree(b->ptr);

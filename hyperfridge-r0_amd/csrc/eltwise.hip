@@ -184,13 +184,25 @@ __global__ void prefix_chunk_prod_kernel(uint32_t* __restrict__ chunk_prod, cons
   }
   if (t == 0) st4(chunk_prod + 4 * (size_t)blockIdx.x, ld4(sh));
 }
-__global__ void prefix_chunk_scan_kernel(uint32_t* chunk_prod, uint32_t n_chunks) {
-  if (blockIdx.x || threadIdx.x) return;
-  Fp4 cur = fp4_one();
-  for (uint32_t b = 0; b < n_chunks; b++) {  // exclusive scan in place
-    Fp4 v = ld4(chunk_prod + 4 * (size_t)b);
-    st4(chunk_prod + 4 * (size_t)b, cur);
-    cur = cur * v;
+// exclusive running product over the chunk summaries, one block: serial per thread, Hillis-Steele across threads
+__global__ __launch_bounds__(256) void prefix_chunk_scan_kernel(uint32_t* chunk_prod, uint32_t n_chunks) {
+  __shared__ uint32_t sh[256 * 4];
+  const uint32_t t = threadIdx.x, per = (n_chunks + 255) / 256, b0 = t * per;
+  Fp4 v = fp4_one();
+  for (uint32_t k = 0; k < per && b0 + k < n_chunks; k++) v = v * ld4(chunk_prod + 4 * (size_t)(b0 + k));
+  st4(sh + 4 * t, v);
+  __syncthreads();
+  for (uint32_t s = 1; s < 256; s <<= 1) {
+    Fp4 o = t >= s ? ld4(sh + 4 * (t - s)) : fp4_one();
+    __syncthreads();
+    if (t >= s) st4(sh + 4 * t, ld4(sh + 4 * t) * o);
+    __syncthreads();
+  }
+  Fp4 cur = t ? ld4(sh + 4 * (t - 1)) : fp4_one();
+  for (uint32_t k = 0; k < per && b0 + k < n_chunks; k++) {
+    Fp4 x = ld4(chunk_prod + 4 * (size_t)(b0 + k));
+    st4(chunk_prod + 4 * (size_t)(b0 + k), cur);
+    cur = cur * x;
   }
 }
 __global__ void prefix_apply_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ chunk_excl, uint32_t E) {
@@ -236,16 +248,34 @@ __global__ void divide_chunk_sum_kernel(uint32_t* __restrict__ chunk_val, const 
   }
   if (t == 0) st4(chunk_val + 4 * (size_t)blockIdx.x, ld4(sh));
 }
-// carry[b] = sum_{b' > b} S_b' z^((b'-b-1)*chunk), serial from the top
-__global__ void divide_chunk_carry_kernel(uint32_t* chunk_val, DivPowers pw, uint32_t n_chunks) {
-  if (blockIdx.x || threadIdx.x) return;
-  Fp4 cur = fp4_zero();
-  for (uint32_t b = n_chunks; b-- > 0;) {
-    Fp4 s = ld4(chunk_val + 4 * (size_t)b);
-    st4(chunk_val + 4 * (size_t)b, cur);
-    cur = cur * pw.zChunk + s;
+// carry[b] = sum_{b' > b} S_b' z^((b'-b-1)*chunk); remainder = sum_b S_b z^(b*chunk) -> chunk_val[n_chunks].
+// One block: each thread owns `per` consecutive chunks, a suffix scan with growing powers links the threads.
+__global__ __launch_bounds__(256) void divide_chunk_carry_kernel(uint32_t* chunk_val, DivPowers pw, uint32_t n_chunks) {
+  __shared__ uint32_t sh[256 * 4];
+  const uint32_t t = threadIdx.x, per = (n_chunks + 255) / 256, b0 = t * per;
+  Fp4 v = fp4_zero();  // sum_k S[b0+k] zc^k
+  for (uint32_t k = per; k-- > 0;)
+    if (b0 + k < n_chunks) v = v * pw.zChunk + ld4(chunk_val + 4 * (size_t)(b0 + k));
+    else v = v * pw.zChunk;
+  st4(sh + 4 * t, v);
+  __syncthreads();
+  Fp4 step = fp4_pow(pw.zChunk, per);
+  for (uint32_t s = 1; s < 256; s <<= 1) {  // sh[t] = sum_{t' >= t} v_t' step^(t'-t)
+    Fp4 o = t + s < 256 ? ld4(sh + 4 * (t + s)) : fp4_zero();
+    __syncthreads();
+    if (t + s < 256) st4(sh + 4 * t, ld4(sh + 4 * t) + o * step);
+    step = step * step;
+    __syncthreads();
   }
-  st4(chunk_val + 4 * (size_t)n_chunks, cur);  // remainder
+  if (t == 0) st4(chunk_val + 4 * (size_t)n_chunks, ld4(sh));  // remainder (slot past the carries)
+  // carry entering this thread's top chunk from the threads above
+  Fp4 cur = t + 1 < 256 ? ld4(sh + 4 * (t + 1)) : fp4_zero();
+  for (uint32_t k = per; k-- > 0;) {
+    if (b0 + k >= n_chunks) { cur = cur * pw.zChunk; continue; }
+    Fp4 sv = ld4(chunk_val + 4 * (size_t)(b0 + k));
+    st4(chunk_val + 4 * (size_t)(b0 + k), cur);
+    cur = cur * pw.zChunk + sv;
+  }
 }
 __global__ void divide_apply_kernel(uint32_t* __restrict__ poly, const uint32_t* __restrict__ chunk_carry, DivPowers pw, uint32_t E) {
   extern __shared__ uint32_t sh[];
@@ -310,14 +340,13 @@ const char* r0h_batch_evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t
     const uint32_t ng = (uint32_t)g.second.size();
     std::vector<uint32_t> host(2 * ng);
     for (uint32_t k = 0; k < ng; k++) { host[k] = which[g.second[k]]; host[ng + k] = g.second[k]; }
-    R0H_TRY_HIP(hipMemcpyAsync(idx, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    R0H_TRY(stage_h2d(ctx, idx, host.data(), host.size() * 4));
     Fp4 x = Fp4{{g.first[0], g.first[1], g.first[2], g.first[3]}};
     KScope ks(ctx, "batch_evaluate_any", 4.0 * ng * (double)(1u << po2));
     hipLaunchKernelGGL(eval_tables_kernel, dim3((rl + rows + 255) / 256), dim3(256), 0, ctx->stream, tab, x, rl, rows);
     hipLaunchKernelGGL(eval_rows_kernel, dim3(blocks, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((ng + 63) / 64), dim3(64), 0, ctx->stream, u32(out), part, idx + ng, blocks, ng);
-    R0H_TRY(launch_ok("batch_evaluate_any kernels"));
-    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // host vectors and the shared scratch are reused per group
+    R0H_TRY(launch_ok("batch_evaluate_any kernels"));  // scratch reuse by the next group is ordered by the stream
   }
   return nullptr;
   R0H_GUARD_END
@@ -351,13 +380,11 @@ const char* r0h_mix_poly_coeffs(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mi
   for (uint32_t k = 0; k < input_count; k++)
     for (int q = 0; q < 4; q++) params.push_back(pw[order[k]].e[q]);
   R0H_TRY(ensure_scratch(ctx, params.size() * 4));
-  R0H_TRY_HIP(hipMemcpyAsync(ctx->scratch, params.data(), params.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  R0H_TRY(stage_h2d(ctx, ctx->scratch, params.data(), params.size() * 4));
   uint32_t n = 1u << po2, threads = n < 256 ? n : 256;
   KScope ks(ctx, "mix_poly_kernel", 4.0 * input_count * (double)n + 32.0 * n_groups * (double)n);
   hipLaunchKernelGGL(mix_poly_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(combos), u32(input), (const uint32_t*)ctx->scratch, n_groups, po2);
-  R0H_TRY(launch_ok("mix_poly_kernel"));
-  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // params live in shared scratch and a host vector
-  return nullptr;
+  return launch_ok("mix_poly_kernel");
   R0H_GUARD_END
 }
 
@@ -425,7 +452,7 @@ const char* r0h_prefix_products(r0h_ctx* ctx, r0h_buf* io, uint32_t n) {
   R0H_TRY(ensure_scratch(ctx, (size_t)(g.n_chunks + 1) * 16));
   uint32_t* cp = (uint32_t*)ctx->scratch;
   hipLaunchKernelGGL(prefix_chunk_prod_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, cp, u32(io), g.E);
-  hipLaunchKernelGGL(prefix_chunk_scan_kernel, dim3(1), dim3(1), 0, ctx->stream, cp, g.n_chunks);
+  hipLaunchKernelGGL(prefix_chunk_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, cp, g.n_chunks);
   hipLaunchKernelGGL(prefix_apply_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, u32(io), cp, g.E);
   return launch_ok("prefix_products kernels");
 }
@@ -443,7 +470,7 @@ const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint3
   uint32_t* cv = (uint32_t*)ctx->scratch;
   KScope ks(ctx, "poly_divide", 48.0 * n);
   hipLaunchKernelGGL(divide_chunk_sum_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, cv, u32(poly), pw, g.E);
-  hipLaunchKernelGGL(divide_chunk_carry_kernel, dim3(1), dim3(1), 0, ctx->stream, cv, pw, g.n_chunks);
+  hipLaunchKernelGGL(divide_chunk_carry_kernel, dim3(1), dim3(256), 0, ctx->stream, cv, pw, g.n_chunks);
   hipLaunchKernelGGL(divide_apply_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, u32(poly), cv, pw, g.E);
   R0H_TRY(launch_ok("poly_divide kernels"));
   if (remainder) {

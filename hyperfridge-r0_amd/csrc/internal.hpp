@@ -80,8 +80,9 @@ struct r0h_ctx {
   r0h::P2Consts p2_host;
   void* scratch = nullptr;      // small device scratch for scans / partial sums
   size_t scratch_bytes = 0;
-  void* pinned = nullptr;       // pinned host staging
-  size_t pinned_bytes = 0;
+  void* pinned = nullptr;       // pinned host staging ring for small parameter uploads
+  size_t pinned_bytes = 0, pinned_off = 0;
+  std::multimap<size_t, void*> pool;  // cached device allocations of the sequencer, by size (stream-ordered reuse)
   r0h::Profile prof;
   bool ktime_on = false;
   std::map<std::string, r0h::KTimer> ktimers;
@@ -94,6 +95,7 @@ struct r0h_buf {
   r0h_buf* parent = nullptr;  // slices keep their parent alive
   int refs = 1;
   bool owned = true;
+  bool pooled = false;  // memory returns to the context's pool instead of hipFree
 };
 
 namespace r0h {
@@ -122,6 +124,10 @@ struct KScope {
   }
 };
 const char* ensure_scratch(r0h_ctx* ctx, size_t bytes);
+// stream-ordered upload of a small host array through the pinned ring (the caller's memory may die on return)
+const char* stage_h2d(r0h_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+// device buffer from the context's pool: no hipMalloc / hipFree (and no implicit device sync) in steady state
+const char* buf_alloc_pooled(r0h_ctx* ctx, size_t bytes, r0h_buf** out);
 void ctx_retain(r0h_ctx* ctx);
 void ctx_release(r0h_ctx* ctx);
 // host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table

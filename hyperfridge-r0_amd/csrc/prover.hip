@@ -106,7 +106,7 @@ struct Scope {  // frees device buffers on every exit path
   std::vector<r0h_buf*> bufs;
   ~Scope() { for (r0h_buf* b : bufs) r0h_buf_free(b); }
   const char* alloc(r0h_ctx* ctx, size_t bytes, r0h_buf** out) {
-    R0H_TRY(r0h_buf_alloc(ctx, bytes, out));
+    R0H_TRY(buf_alloc_pooled(ctx, bytes, out));
     bufs.push_back(*out);
     return nullptr;
   }
@@ -226,10 +226,7 @@ static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, co
     for (size_t i = 0; i < len; i++) e[i] = enc((uint8_t)info[i]);
     p2_hash_elems_host(ctx->p2_host, e, len, d);
     io.commit(d);
-    std::vector<uint32_t> be(cv.blob_words);
-    for (size_t i = 0; i < cv.blob_words; i++) be[i] = enc(cv.blob[i] % P);
-    p2_hash_elems_host(ctx->p2_host, be.data(), be.size(), d);
-    io.commit(d);
+    io.commit(circ->blob_digest);
     std::vector<uint32_t> gv(global, global + cv.n_global);
     for (uint32_t w : gv) R0H_REQUIRE(w < P, "prove_segment: global word not canonical");
     gv.push_back(enc(po2));
@@ -361,10 +358,9 @@ static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, co
     R0H_REQUIRE(((size_t)(n_combos + 1) << po2) * 4 < ((size_t)1 << 32), "prove_segment: combos buffer exceeds 32-bit word indexing");
     r0h_buf* d_fix = nullptr;
     R0H_TRY(sc.alloc(ctx, fix.size() * 4, &d_fix));
-    R0H_TRY(r0h_buf_h2d(ctx, d_fix, 0, fix.data(), fix.size() * 4));
+    R0H_TRY(stage_h2d(ctx, d_fix->ptr, fix.data(), fix.size() * 4));
     uint32_t nf = (uint32_t)(fix.size() / 2);
     hipLaunchKernelGGL(sub_head_kernel, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, u32(combos), u32(d_fix), nf);
-    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
     sc.release(d_fix);
   }
   phase(ctx, "deep_divide");
@@ -436,7 +432,7 @@ static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, co
     }
     r0h_buf* d_idx = nullptr;
     R0H_TRY(sc.alloc(ctx, idx.size() * 4, &d_idx));
-    R0H_TRY(r0h_buf_h2d(ctx, d_idx, 0, idx.data(), idx.size() * 4));
+    R0H_TRY(stage_h2d(ctx, d_idx->ptr, idx.data(), idx.size() * 4));
     std::vector<const Tree*> trees = {&g_accum.tree, &g_code.tree, &g_data.tree, &g_check.tree};
     for (Round& rd : rounds) trees.push_back(&rd.tree);
     std::vector<std::vector<uint32_t>> opened(n_trees);
