@@ -115,6 +115,219 @@ __global__ __launch_bounds__(512) void ntt_strided_kernel(uint32_t* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------------ radix-16 register-blocked kernels
+// Sub-transforms of size 2^m (8 <= m <= 12) are done in rounds of four butterfly layers: every thread keeps 16 words
+// in VGPRs, runs the layers of one 4-bit index field on them, and the block exchanges through LDS between rounds
+// (2 LDS writes + 2 LDS reads per word per pass instead of 2 per layer).  Twiddles of a round are
+// ROU[l]^(low bits) -- one table word per layer and thread -- times a constant 16th root of unity.
+struct W16 {
+  uint32_t w[8];  // ROU[4]^k, k < 8 (forward or inverse)
+};
+
+// Layers of the field at bit B (width W) on 16 >> W independent sets; DIT when DIR == 0 (skipping layers below
+// LO_LAYER), DIF when DIR == 1.  rest0 = index of the thread's first set among the 2^(m-W) sets of the sub-transform.
+template <int W, int B, int DIR, int LO_LAYER>
+__device__ __forceinline__ void field_layers(uint32_t (&x)[16], uint32_t rest0, const uint32_t* __restrict__ tw12, const W16& c) {
+  constexpr int SETS = 16 >> W;
+#pragma unroll
+  for (int s = 0; s < SETS; s++) {
+    const uint32_t low = (rest0 + s) & ((1u << B) - 1u);
+#pragma unroll
+    for (int step = 0; step < W; step++) {
+      const int l = DIR == 0 ? step : W - 1 - step;
+      if (DIR == 0 && l < LO_LAYER) continue;
+      uint32_t a_tw = ONE;
+      if (B != 0) a_tw = tw12[low << (12 - (B + l + 1))];
+#pragma unroll
+      for (int j0 = 0; j0 < (1 << W); j0++) {
+        if (j0 & (1 << l)) continue;
+        const int j1 = j0 | (1 << l), cidx = (j0 & ((1 << l) - 1)) << (3 - l);
+        uint32_t& u = x[s * (1 << W) + j0];
+        uint32_t& v = x[s * (1 << W) + j1];
+        const bool trivial = B == 0 && cidx == 0;
+        uint32_t twd = cidx == 0 ? a_tw : (B == 0 ? c.w[cidx] : mul(a_tw, c.w[cidx]));
+        if (DIR == 0) {
+          uint32_t a = u, t = trivial ? v : mul(v, twd);
+          u = add(a, t);
+          v = sub(a, t);
+        } else {
+          uint32_t a = u, t = v;
+          u = add(a, t);
+          v = trivial ? sub(a, t) : mul(sub(a, t), twd);
+        }
+      }
+    }
+  }
+}
+
+// element index of word (set s, digit j) for the field at bit B of width W, thread's first set rest0
+template <int W, int B>
+__device__ __forceinline__ uint32_t field_index(uint32_t rest0, int s, int j) {
+  uint32_t r = rest0 + s;
+  return ((r >> B) << (B + W)) | ((uint32_t)j << B) | (r & ((1u << B) - 1u));
+}
+
+// [2^H][16] tile, H = 8 + WL: forward = DIT over the chunk index with the inter-pass twiddle on load,
+// inverse = DIF with the twiddle on store.  Block = 16 << (H - 4) threads.
+template <int WL, int DIR>
+__global__ __launch_bounds__(1024) void ntt_strided16_kernel(uint32_t* __restrict__ io, uint32_t n, uint32_t L, TwTables tw, W16 c) {
+  extern __shared__ uint32_t s[];
+  constexpr uint32_t H = 8 + WL;
+  const uint32_t t = threadIdx.x & 15, q = threadIdx.x >> 4, lo = (blockIdx.x << 4) + t;
+  uint32_t* col = io + ((size_t)blockIdx.y << n);
+  uint32_t x[16];
+  if (DIR == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      uint32_t e = q * 16 + j;
+      x[j] = mul(col[((size_t)e << L) + lo], omega_n(tw, bitrev(e, H) * lo, n));
+    }
+    field_layers<4, 0, 0, 0>(x, q, tw.tw12, c);
+#pragma unroll
+    for (int j = 0; j < 16; j++) s[(q * 16 + j) * 16 + t] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = s[field_index<4, 4>(q, 0, j) * 16 + t];
+    field_layers<4, 4, 0, 0>(x, q, tw.tw12, c);
+    if (WL == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) col[((size_t)field_index<4, 4>(q, 0, j) << L) + lo] = x[j];
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) s[field_index<4, 4>(q, 0, j) * 16 + t] = x[j];
+    __syncthreads();
+    constexpr int WLs = WL == 0 ? 1 : WL, SETS = 16 >> WLs;
+#pragma unroll
+    for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+      for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = s[field_index<WLs, 8>(q * SETS, ss, j) * 16 + t];
+    field_layers<WLs, 8, 0, 0>(x, q * SETS, tw.tw12, c);
+#pragma unroll
+    for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+      for (int j = 0; j < (1 << WLs); j++) col[((size_t)field_index<WLs, 8>(q * SETS, ss, j) << L) + lo] = x[ss * (1 << WLs) + j];
+  } else {
+    constexpr int WLs = WL == 0 ? 1 : WL, SETS = 16 >> WLs;
+    if (WL != 0) {
+#pragma unroll
+      for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+        for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = col[((size_t)field_index<WLs, 8>(q * SETS, ss, j) << L) + lo];
+      field_layers<WLs, 8, 1, 0>(x, q * SETS, tw.tw12, c);
+#pragma unroll
+      for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+        for (int j = 0; j < (1 << WLs); j++) s[field_index<WLs, 8>(q * SETS, ss, j) * 16 + t] = x[ss * (1 << WLs) + j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[j] = s[field_index<4, 4>(q, 0, j) * 16 + t];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[j] = col[((size_t)field_index<4, 4>(q, 0, j) << L) + lo];
+    }
+    field_layers<4, 4, 1, 0>(x, q, tw.tw12, c);
+#pragma unroll
+    for (int j = 0; j < 16; j++) s[field_index<4, 4>(q, 0, j) * 16 + t] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = s[(q * 16 + j) * 16 + t];
+    field_layers<4, 0, 1, 0>(x, q, tw.tw12, c);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      uint32_t e = q * 16 + j;
+      col[((size_t)e << L) + lo] = mul(x[j], omega_n(tw, bitrev(e, H) * lo, n));
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + (e >> 4); }
+
+// One contiguous chunk of 2^L words (L = 8 + WL) per block of 2^(L-4) threads.
+// Forward (DIR 0): DIT, optionally fed by an input EXP_BITS (0 or 2) times shorter (each word replicated 2^EXP_BITS times,
+// the first EXP_BITS layers skipped).  Inverse (DIR 1): DIF, result scaled by `scale`.
+template <int WL, int DIR, int EXP_BITS>
+__global__ __launch_bounds__(256) void ntt_local16_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint32_t n_out,
+                                                           const uint32_t* __restrict__ tw12, W16 c, uint32_t scale) {
+  extern __shared__ uint32_t s[];
+  constexpr uint32_t L = 8 + WL;
+  constexpr int WLs = WL == 0 ? 1 : WL, SETS = 16 >> WLs;
+  const uint32_t q = threadIdx.x;
+  const size_t colid = blockIdx.y;
+  const uint32_t base = blockIdx.x << L;
+  uint32_t* dst = out + (colid << n_out) + base;
+  uint32_t x[16];
+  if (DIR == 0) {
+    const uint32_t* src = in + (colid << (n_out - EXP_BITS)) + (base >> EXP_BITS);
+    if (EXP_BITS == 2) {
+      uint4 v = *(const uint4*)(src + q * 4);
+      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[j] = w4[j >> 2];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint4 v = *(const uint4*)(src + q * 16 + 4 * k);
+        x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+      }
+    }
+    field_layers<4, 0, 0, EXP_BITS>(x, q, tw12, c);
+#pragma unroll
+    for (int j = 0; j < 16; j++) s[lds_pad(q * 16 + j)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = s[lds_pad(field_index<4, 4>(q, 0, j))];
+    field_layers<4, 4, 0, 0>(x, q, tw12, c);
+    if (WL == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) dst[field_index<4, 4>(q, 0, j)] = x[j];
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) s[lds_pad(field_index<4, 4>(q, 0, j))] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+      for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = s[lds_pad(field_index<WLs, 8>(q * SETS, ss, j))];
+    field_layers<WLs, 8, 0, 0>(x, q * SETS, tw12, c);
+#pragma unroll
+    for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+      for (int j = 0; j < (1 << WLs); j++) dst[field_index<WLs, 8>(q * SETS, ss, j)] = x[ss * (1 << WLs) + j];
+  } else {
+    const uint32_t* src = in + (colid << n_out) + base;
+    if (WL != 0) {
+#pragma unroll
+      for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+        for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = src[field_index<WLs, 8>(q * SETS, ss, j)];
+      field_layers<WLs, 8, 1, 0>(x, q * SETS, tw12, c);
+#pragma unroll
+      for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+        for (int j = 0; j < (1 << WLs); j++) s[lds_pad(field_index<WLs, 8>(q * SETS, ss, j))] = x[ss * (1 << WLs) + j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[j] = s[lds_pad(field_index<4, 4>(q, 0, j))];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[j] = src[field_index<4, 4>(q, 0, j)];
+    }
+    field_layers<4, 4, 1, 0>(x, q, tw12, c);
+#pragma unroll
+    for (int j = 0; j < 16; j++) s[lds_pad(field_index<4, 4>(q, 0, j))] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = s[lds_pad(q * 16 + j)];
+    field_layers<4, 0, 1, 0>(x, q, tw12, c);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      *(uint4*)(dst + q * 16 + 4 * k) = make_uint4(mul(x[4 * k], scale), mul(x[4 * k + 1], scale), mul(x[4 * k + 2], scale), mul(x[4 * k + 3], scale));
+  }
+}
+
 __global__ void bit_reverse_kernel(uint32_t* io, uint32_t po2) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t* col = io + ((size_t)blockIdx.y << po2);
@@ -149,6 +362,52 @@ static Split split_for(uint32_t n) {
   return sp;
 }
 
+
+struct Split16 {
+  bool use16;       // radix-16 kernels apply
+  uint32_t L, H;    // contiguous chunk 2^L, strided 2^H (0 = single pass)
+};
+static Split16 split16_for(uint32_t n) {
+  Split16 sp{false, n, 0};
+  if (n >= 8 && n <= 12) { sp.use16 = true; return sp; }
+  if (n >= 16 && n <= MAX_DOMAIN_PO2) {
+    sp.use16 = true;
+    sp.L = n - 8 < 12 ? n - 8 : 12;
+    sp.H = n - sp.L;
+  }
+  return sp;
+}
+static W16 make_w16(bool inverse) {
+  W16 c;
+  uint32_t w = inverse ? rou_rev(4) : rou_fwd(4), cur = ONE;
+  for (int k = 0; k < 8; k++) { c.w[k] = cur; cur = mul(cur, w); }
+  return c;
+}
+static size_t local16_lds_bytes(uint32_t L) { return (((size_t)1 << L) + ((size_t)1 << (L - 4))) * 4; }
+
+template <int DIR, int EXP_BITS>
+static void launch_local16(r0h_ctx* ctx, uint32_t L, dim3 grid, uint32_t* out, const uint32_t* in, uint32_t n_out, const uint32_t* tw12, const W16& c, uint32_t scale) {
+  const size_t lds = local16_lds_bytes(L);
+  const dim3 block(1u << (L - 4));
+  switch (L) {
+    case 8: hipLaunchKernelGGL((ntt_local16_kernel<0, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
+    case 9: hipLaunchKernelGGL((ntt_local16_kernel<1, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
+    case 10: hipLaunchKernelGGL((ntt_local16_kernel<2, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
+    case 11: hipLaunchKernelGGL((ntt_local16_kernel<3, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
+    default: hipLaunchKernelGGL((ntt_local16_kernel<4, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
+  }
+}
+template <int DIR>
+static void launch_strided16(r0h_ctx* ctx, uint32_t H, dim3 grid, uint32_t* io, uint32_t n, uint32_t L, const TwTables& tw, const W16& c) {
+  const size_t lds = ((size_t)16 << H) * 4;
+  const dim3 block(16u << (H - 4));
+  switch (H) {
+    case 8: hipLaunchKernelGGL((ntt_strided16_kernel<0, DIR>), grid, block, lds, ctx->stream, io, n, L, tw, c); break;
+    case 9: hipLaunchKernelGGL((ntt_strided16_kernel<1, DIR>), grid, block, lds, ctx->stream, io, n, L, tw, c); break;
+    default: hipLaunchKernelGGL((ntt_strided16_kernel<2, DIR>), grid, block, lds, ctx->stream, io, n, L, tw, c); break;
+  }
+}
+
 static const char* launch_check(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return make_error("%s: launch failed: %s", what, hipGetErrorString(e));
@@ -167,9 +426,21 @@ const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count,
   R0H_REQUIRE(po2 >= 1 && po2 <= MAX_DOMAIN_PO2, "r0h_batch_interpolate_ntt: po2 %u outside [1, %u]", po2, MAX_DOMAIN_PO2);
   R0H_REQUIRE(((size_t)count << po2) * 4 <= io->bytes, "r0h_batch_interpolate_ntt: %u columns of 2^%u exceed the buffer", count, po2);
   if (!count) return nullptr;
-  const Split sp = split_for(po2);
   const uint32_t norm = inv(enc(1u << po2));
   TwTables tw{ctx->tw_lo[1], ctx->tw_hi[1], ctx->tw12[1]};
+  const Split16 s16 = split16_for(po2);
+  if (s16.use16) {
+    const W16 c = make_w16(true);
+    if (s16.H) {
+      KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << po2));
+      launch_strided16<1>(ctx, s16.H, dim3(1u << (s16.L - 4), count), u32(io), po2, s16.L, tw, c);
+      R0H_TRY(launch_check("ntt_strided16_kernel<inv>"));
+    }
+    KScope ks(ctx, "ntt_local_kernel", 8.0 * count * (double)(1u << po2));
+    launch_local16<1, 0>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), u32(io), po2, tw.tw12, c, norm);
+    return launch_check("ntt_local16_kernel<inv>");
+  }
+  const Split sp = split_for(po2);
   if (sp.H) {
     KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << po2));
     dim3 grid(1u << (sp.L - sp.tlog), count);
@@ -193,9 +464,26 @@ const char* r0h_batch_expand_into_evaluate_ntt(r0h_ctx* ctx, r0h_buf* out, const
               "r0h_batch_expand_into_evaluate_ntt: %u columns exceed the buffers", count);
   R0H_REQUIRE(out->ptr != in->ptr || expand_bits == 0, "r0h_batch_expand_into_evaluate_ntt: in-place expansion is not supported");
   if (!count) return nullptr;
+  TwTables tw{ctx->tw_lo[0], ctx->tw_hi[0], ctx->tw12[0]};
+  const Split16 s16 = split16_for(n);
+  if (s16.use16 && (expand_bits == 0 || expand_bits == 2)) {
+    const W16 c = make_w16(false);
+    {
+      KScope ks(ctx, "ntt_local_kernel", 4.0 * count * ((double)(1u << n) + (double)(1u << in_po2)));
+      dim3 grid(1u << (n - s16.L), count);
+      if (expand_bits == 2) launch_local16<0, 2>(ctx, s16.L, grid, u32(out), u32(in), n, tw.tw12, c, 0u);
+      else launch_local16<0, 0>(ctx, s16.L, grid, u32(out), u32(in), n, tw.tw12, c, 0u);
+    }
+    R0H_TRY(launch_check("ntt_local16_kernel<fwd>"));
+    if (s16.H) {
+      KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << n));
+      launch_strided16<0>(ctx, s16.H, dim3(1u << (s16.L - 4), count), u32(out), n, s16.L, tw, c);
+      R0H_TRY(launch_check("ntt_strided16_kernel<fwd>"));
+    }
+    return nullptr;
+  }
   const Split sp = split_for(n);
   R0H_REQUIRE(expand_bits < sp.L, "r0h_batch_expand_into_evaluate_ntt: expand_bits %u too large for size 2^%u", expand_bits, n);
-  TwTables tw{ctx->tw_lo[0], ctx->tw_hi[0], ctx->tw12[0]};
   dim3 grid(1u << (n - sp.L), count);
   {
     KScope ks(ctx, "ntt_local_kernel", 4.0 * count * ((double)(1u << n) + (double)(1u << in_po2)));
