@@ -231,15 +231,16 @@ __device__ __forceinline__ u32 fmul(u32 a, u32 b) {
   u64 u = t + (u64)m * FP_P;
   return fred((u32)(u >> 32));
 }
+// Montgomery reduction of a sum of up to four 62-bit products (any T < 2^64): hi(T) - hi(m*p) with m = lo(T) * p^-1
+__device__ __forceinline__ u32 fred64(u64 T) {
+  u32 m = (u32)T * 0x88000001u;
+  u32 q = __umulhi(m, FP_P);
+  u32 h = (u32)(T >> 32);
+  u32 r = h - q;
+  r = h < q ? r + FP_P : r;
+  return fred(fred(r));
+}
 #define TAP(g, col, back) g[(size_t)(col) * domain + ((i - 4u * (back)) & mask)]
-#define TERM(p, val)                                          \
-  do {                                                        \
-    u32 v_ = (val);                                           \
-    t0 = fadd(t0, fmul(mixpow[4 * (p) + 0], v_));             \
-    t1 = fadd(t1, fmul(mixpow[4 * (p) + 1], v_));             \
-    t2 = fadd(t2, fmul(mixpow[4 * (p) + 2], v_));             \
-    t3 = fadd(t3, fmul(mixpow[4 * (p) + 3], v_));             \
-  } while (0)
 )SRC";
 
 static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& done, std::ostringstream& os) {
@@ -285,6 +286,19 @@ static uint32_t tunable(const char* name, uint32_t dflt) {
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
+static void flush_terms(const Plan& pl, std::vector<uint32_t>& pending, std::ostringstream& os) {
+  if (pending.empty()) return;
+  for (int q = 0; q < 4; q++) {
+    os << "  t" << q << " = fadd(t" << q << ", fred64(";
+    for (size_t k = 0; k < pending.size(); k++) {
+      if (k) os << " + ";
+      os << "(u64)mixpow[" << 4 * (size_t)pl.terms[pending[k]].pow + q << "] * w" << pending[k];
+    }
+    os << "));\n";
+  }
+  pending.clear();
+}
+
 static std::string emit_source(const r0h_circuit* c) {
   const Plan& pl = c->plan;
   const uint32_t scope_terms = tunable("R0H_EC_SCOPE", 0), waves = tunable("R0H_EC_WAVES", 0);
@@ -305,6 +319,7 @@ static std::string emit_source(const r0h_circuit* c) {
     // a scheduling barrier keeps the compiler from hoisting the next scope's loads, so the live set is bounded by the
     // scope, not by the circuit.
     std::vector<bool> done(c->fp_step.size(), false);
+    std::vector<uint32_t> pending;
     uint32_t in_scope = 0;
     os << "  {\n";
     for (uint32_t t = pl.cut[k]; t < pl.cut[k + 1]; t++) {
@@ -316,12 +331,16 @@ static std::string emit_source(const r0h_circuit* c) {
       const Term& tm = pl.terms[t];
       emit_var(c, tm.v, done, os);
       for (uint32_t g : tm.conds) emit_var(c, g, done, os);
-      os << "  TERM(" << tm.pow << "u, ";
-      for (size_t g = 0; g < tm.conds.size(); g++) os << "fmul(v" << tm.conds[g] << ", ";
-      os << "v" << tm.v;
-      for (size_t g = 0; g < tm.conds.size(); g++) os << ")";
-      os << ");\n";
+      // value of the term: the constraint times its enclosing gates
+      std::ostringstream val;
+      for (size_t g = 0; g < tm.conds.size(); g++) val << "fmul(v" << tm.conds[g] << ", ";
+      val << "v" << tm.v;
+      for (size_t g = 0; g < tm.conds.size(); g++) val << ")";
+      os << "  const u32 w" << t << " = " << val.str() << ";\n";
+      pending.push_back(t);
       in_scope++;
+      // poly_mix^p * value products are summed four at a time in 64 bits and reduced once per component
+      if (pending.size() == 4 || t + 1 == pl.cut[k + 1] || (scope_terms && in_scope == scope_terms)) flush_terms(pl, pending, os);
     }
     os << "  }\n";
     os << "  const u32 iv = inv_van[i & 3u];\n"
