@@ -2,29 +2,45 @@
 """Headline benchmark: segments/sec at po2 = 20 through the C-ABI segment prover, one process per GPU.
 
 A step = one pass of the hot path (r0h_prove_segment: commit CODE/DATA/ACCUM, eval_check, DEEP, FRI, queries -> seal)
-over one synthetic segment whose witness is already resident in HBM.  Segments are independent, so ranks shard them
-with no data-path collective ("weak" scaling: every rank proves its own K segments); torch.distributed (RCCL) is used
-only for the barrier and the max-over-ranks reduction of the wall time.
+over one synthetic segment per in-flight context, witness already resident in HBM.  Segments are independent, so ranks
+shard them with no data-path collective ("weak" scaling: every rank proves its own segments); torch.distributed (RCCL)
+is used only for the barrier and the reductions of the timing.
 
 Workload (BASELINE.json configs[1] shape): the bundled camt53 trace does not exist as a file
 and cannot be produced without the risc0 3.0.5 executor (Rust, absent), so the segment is synthetic: circuit blob
-circuits/bench.r0c, W = (16 CODE, 192 DATA, 48 ACCUM) = 256 columns, 2^20 rows, ~18k mul + ~21k add/sub per point.
+circuits/bench.r0c, W = (16 CODE, 192 DATA, 48 ACCUM) = 256 columns, 2^20 rows, ~20k mul + ~22.6k add/sub per point.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel family (largest share of device time): algorithmic HBM bytes / its HIP-event time
-  cpu_baseline  the oracle (CPU restatement, OpenMP, all host cores) proving the same circuit at a reduced po2,
-                scaled to po2 = 20 by the row ratio ("port": the risc0 CPU prover itself cannot be built here)
+  roofline      dominant kernel family (largest share of device time): algorithmic HBM bytes / its HIP-event time,
+                `traffic` = PMC-measured HBM bytes per launch (profiles/*/pmc_traffic.json, separate rocprofv3 --pmc passes)
+  cpu_baseline  the oracle (CPU restatement, OpenMP) proving the same circuit at a reduced po2, scaled to po2 = 20 by the
+                row ratio ("port": the risc0 CPU prover itself cannot be built here); rank 0, N = 1 only
 """
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary, or None."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+        try:
+            k = json.load(open(path))["kernels"].get(kernel)
+        except Exception:
+            k = None
+        if k:
+            best = k["hbm_bytes_per_launch"]
+    return best
 
 
 def main():
@@ -34,7 +50,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--circuit", default="bench")
-    ap.add_argument("--cpu-po2", type=int, default=15, help="po2 of the bounded CPU-baseline sample (0 disables)")
+    ap.add_argument("--contexts", type=int, default=2, help="segments in flight per GPU (one context + host thread each)")
+    ap.add_argument("--cpu-po2", type=int, default=17, help="po2 of the bounded CPU-baseline sample (0 disables)")
     args = ap.parse_args()
 
     import numpy as np
@@ -42,102 +59,103 @@ def main():
 
     import __graft_entry__ as entry
     import hyperfridge_r0_amd as r0
+    from hyperfridge_r0_amd import driver
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    env = driver.DistEnv(backend="nccl", device=torch.device("cuda", local_rank))
+    if env.world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, env.world))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    hal = r0.Hal(local_rank)
+    po2, n_ctx = args.po2, max(1, args.contexts)
     blob = np.fromfile(entry.circuit_blob_path(args.circuit), dtype=np.uint32)
     co = entry.code_object_path(args.circuit)
-    circuit = hal.load_circuit(blob, co if os.path.exists(co) else None)
-    po2 = args.po2
-    # one resident witness per rank (distinct seed per rank): inputs are in HBM before the timed region starts
-    code, data, glob = hal.witgen(circuit, po2, seed=1000 + rank)
-    hal.sync()
+    lanes = []
+    for k in range(n_ctx):
+        hal = r0.Hal(local_rank)
+        circuit = hal.load_circuit(blob, co if os.path.exists(co) else None)
+        # one resident witness per context (distinct seed per rank and context): inputs are in HBM before timing starts
+        code, data, glob_ = hal.witgen(circuit, po2, seed=1000 + env.rank * 16 + k)
+        hal.sync()
+        lanes.append(dict(hal=hal, circuit=circuit, code=code, data=data, glob=glob_, seal_words=0))
 
-    seal_words = 0
-    for _ in range(args.warmup):
-        seal_words = hal.prove_segment(circuit, po2, code, data, glob).size
-    hal.kernel_timing(True)
-    barrier()
-    t0 = time.perf_counter()
+    def prove_on(lane):
+        lane["seal_words"] = lane["hal"].prove_segment(lane["circuit"], po2, lane["code"], lane["data"], lane["glob"]).size
+
+    def step(_i):
+        if n_ctx == 1:
+            prove_on(lanes[0])
+        else:  # ctypes releases the GIL inside the library: the contexts' streams overlap on the device
+            ts = [threading.Thread(target=prove_on, args=(ln,)) for ln in lanes]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        return n_ctx
+
+    def device_sync():
+        for ln in lanes:
+            ln["hal"].sync()
+        torch.cuda.synchronize()
+
+    elapsed, units = driver.run_timed(env, step, args.steps, args.warmup, device_sync)
+    # per-kernel accounting: HIP events around every launch, on one context running alone, over as many segments as were
+    # timed (outside the timed region, so the events neither perturb `value` nor see another context's kernels)
+    lanes[0]["hal"].kernel_timing(True)
     for _ in range(args.steps):
-        seal_words = hal.prove_segment(circuit, po2, code, data, glob).size
-    hal.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kstats = hal.kernel_stats()
-    phases = hal.last_profile()
-    hal.kernel_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        prove_on(lanes[0])
+    kstats = lanes[0]["hal"].kernel_stats()
+    phases = lanes[0]["hal"].last_profile()
+    lanes[0]["hal"].kernel_timing(False)
 
-    if rank == 0:
+    if env.rank == 0:
         steps = max(args.steps, 1)
-        value = world * steps / elapsed
-        # dominant kernel family by device time
+        value = units / elapsed
+        circuit = lanes[0]["circuit"]
         dom = max(kstats.items(), key=lambda kv: kv[1]["total_ms"]) if kstats else None
         roofline = None
         if dom:
             name, st = dom
             launches = max(st["launches"], 1)
-            avg_ms = st["total_ms"] / launches
             achieved = st["alg_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                        "launches_per_step": launches / steps, "avg_launch_ms": round(avg_ms, 4),
-                        "alg_bytes_per_launch": st["alg_bytes"] / launches,
-                        "share_of_step": round(st["total_ms"] / steps / (elapsed / steps * 1e3), 4),
-                        "note": "VALU-integer bound kernel (Poseidon2: ~1.36k Montgomery products per permutation); see DESIGN.md"}
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name),
+                        "launches_per_step": launches / steps, "avg_launch_ms": round(st["total_ms"] / launches, 4),
+                        "alg_bytes_per_launch": round(st["alg_bytes"] / launches),
+                        "share_of_device_time": round(st["total_ms"] / max(sum(v["total_ms"] for v in kstats.values()), 1e-9), 4),
+                        "note": "this kernel is VALU-integer bound (Poseidon2: ~1.36k Montgomery products per permutation, "
+                                "~3.3 G permutations/s chip ceiling); its HBM fraction is reported because the metric asks for it: DESIGN.md 6"}
         cols = sum(circuit.group_size)
-        seg_bytes = (68 * cols + 3132) * (1 << 20) * (1 << po2) / (1 << 20)  # Bytes(C) at po2=20, scaled by rows
-        cpu = None
-        if args.cpu_po2:
-            cpu = cpu_baseline(blob, args.cpu_po2, po2)
+        seg_bytes = (68 * cols + 3132) * (1 << po2)  # Bytes(C) = 68 MiB*C + 3132 MiB at 2^20 rows
         line = {
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
-            "value": round(value, 4), "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 4), "unit": "segments/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (BabyBear, Montgomery)", "data": "synthetic",
-            "config": {"workload": "configs[1] shape: one 2^%d-row segment per step per GPU, synthetic circuit %s.r0c "
-                                   "W=(%d code,%d data,%d accum), witness resident in HBM; no bundled camt53 trace exists" % (
-                                       po2, args.circuit, circuit.group_size[1], circuit.group_size[2], circuit.group_size[0]),
-                       "po2": po2, "columns": cols, "taps": circuit.n_taps, "seal_words": int(seal_words), "parallelism": "segment-parallel x%d" % world},
+            "config": {"workload": "configs[1] shape: 2^%d-row segments, synthetic circuit %s.r0c W=(%d code,%d data,%d accum), %d segment(s) "
+                                   "in flight per GPU, witness resident in HBM; no bundled camt53 trace exists (needs the risc0 executor)" % (
+                                       po2, args.circuit, circuit.group_size[1], circuit.group_size[2], circuit.group_size[0], n_ctx),
+                       "po2": po2, "columns": cols, "taps": circuit.n_taps, "seal_words": int(lanes[0]["seal_words"]),
+                       "segments_per_step_per_gpu": n_ctx, "parallelism": "segment-parallel x%d" % env.world},
             "roofline": roofline,
-            "cpu_baseline": cpu,
-            "segment_hbm_model": {"alg_bytes_per_segment": seg_bytes, "achieved_GBs": round(seg_bytes * value / world / 1e9, 2),
-                                  "frac_of_8TBs": round(seg_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
-            "phases_ms": {n: round(ms, 3) for n, ms in phases},
-            "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 3) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
+            "cpu_baseline": cpu_baseline(blob, args.cpu_po2, po2) if (args.cpu_po2 and env.world == 1) else None,
+            "segment_hbm_model": {"alg_bytes_per_segment": seg_bytes, "achieved_GBs_per_gpu": round(seg_bytes * value / env.world / 1e9, 2),
+                                  "frac_of_8TBs": round(seg_bytes * value / env.world / 1e9 / HBM_PEAK_GBS, 5)},
+            "phases_ms_last_segment": {n: round(ms, 3) for n, ms in phases},
+            "kernels_ms_per_segment": {k: round(v["total_ms"] / steps, 3) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
         }
         print(json.dumps(line))
-    for obj in (code, data, circuit):
-        obj.free()
-    hal.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    for ln in lanes:
+        for key in ("code", "data", "circuit"):
+            ln[key].free()
+        ln["hal"].close()
+    env.close()
 
 
 def cpu_baseline(blob, cpu_po2, po2):
-    """Oracle (CPU restatement) on a bounded sample: the same circuit at 2^cpu_po2 rows, all host cores."""
+    """Oracle (CPU restatement) on a bounded sample: the same circuit at 2^cpu_po2 rows on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc_binding
     orc = orc_binding.load()
@@ -149,14 +167,15 @@ def cpu_baseline(blob, cpu_po2, po2):
     cores = min(cores, 16)  # the GPU box's CPU share for one GPU
     orc.L.orc_set_threads(cores)
     oc = orc.circuit(blob)
-    code, data, glob = oc.witgen(cpu_po2, seed=1000)
+    code, data, glob_ = oc.witgen(cpu_po2, seed=1000)
     t0 = time.perf_counter()
-    seal = oc.prove(cpu_po2, code, data, glob)
+    seal = oc.prove(cpu_po2, code, data, glob_)
     dt = time.perf_counter() - t0
     scale = 1 << (po2 - cpu_po2)
     return {"value": round(1.0 / (dt * scale), 6), "unit": "segments/s", "cores": cores, "kind": "port",
-            "sample": "oracle/liborc.so (C, OpenMP) proving one 2^%d-row segment of the same circuit in %.2f s; scaled x%d by rows to 2^%d "
-                      "(favours the CPU: ignores the log factor); seal %d words" % (cpu_po2, dt, scale, po2, seal.size)}
+            "sample": "oracle/liborc.so (C, OpenMP, %d threads) proved one 2^%d-row segment of the same circuit in %.2f s; scaled x%d by rows "
+                      "to 2^%d (favours the CPU: drops the log factor); seal %d words.  The risc0 CPU prover cannot be built here (Rust)." % (
+                          cores, cpu_po2, dt, scale, po2, seal.size)}
 
 
 if __name__ == "__main__":

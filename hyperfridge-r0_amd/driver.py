@@ -1,0 +1,74 @@
+"""Multi-GPU driver logic for segment-parallel proving (one process per GPU, no data-path collective).
+
+Segments are independent units: rank r proves segments r, r + world, r + 2*world, ...  The only
+communication is the barrier around the timed region and the MAX / SUM reductions of the per-rank results, over
+torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
+import os
+import time
+
+
+def shard_segments(total, world, rank):
+    """Static round-robin partition of `total` segment indices (BASELINE.json config 3)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    return list(range(rank, total, world))
+
+
+class DistEnv:
+    """Rank bookkeeping + the three collectives the driver needs.  backend=None means single process."""
+
+    def __init__(self, backend=None, device=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.device = device
+        if self.world > 1:
+            if backend is None:
+                raise ValueError("WORLD_SIZE > 1 needs a backend")
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if not dist.is_initialized():
+                kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def _reduce(self, value, op_name):
+        if self.dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op_name))
+        return float(t.item())
+
+    def max(self, value):
+        return self._reduce(value, "MAX")
+
+    def sum(self, value):
+        return self._reduce(value, "SUM")
+
+    def close(self):
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def run_timed(env, step_fn, steps, warmup, device_sync=lambda: None):
+    """`warmup` untimed calls of step_fn(i), then exactly `steps` timed ones bracketed by barrier + device sync on both
+    sides; returns (max-over-ranks seconds, units processed by all ranks), where step_fn returns the units it processed."""
+    for i in range(warmup):
+        step_fn(-1 - i)
+    device_sync()
+    env.barrier()
+    t0 = time.perf_counter()
+    units = 0
+    for i in range(steps):
+        units += int(step_fn(i) or 0)
+    device_sync()
+    env.barrier()
+    elapsed = time.perf_counter() - t0
+    return env.max(elapsed), env.sum(units)

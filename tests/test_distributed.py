@@ -1,0 +1,73 @@
+"""CPU tests of the N > 1 path: the bench driver's sharding, barrier and reductions with gloo, world_size 2.
+The proving step itself needs a GPU, so a stand-in step (sleep + unit count) is injected; what is under test is the
+multi-process logic bench.py runs around r0h_prove_segment."""
+import os
+import socket
+import sys
+import time
+
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, total_segments, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import hyperfridge_r0_amd  # noqa: F401  (package import must work without a GPU)
+    from hyperfridge_r0_amd import driver
+    env = driver.DistEnv(backend="gloo")
+    mine = driver.shard_segments(total_segments, env.world, env.rank)
+    proved = []
+
+    def step(i):
+        if i < 0:
+            return 0
+        time.sleep(0.02 * (1 + env.rank))  # rank 1 is slower: the MAX must pick it up
+        batch = mine[i::3]
+        proved.extend(batch)
+        return len(batch)
+
+    elapsed, units = driver.run_timed(env, step, steps=3, warmup=1)
+    out.put((rank, elapsed, units, sorted(proved)))
+    env.close()
+
+
+def test_shard_segments_partitions_exactly():
+    sys.path.insert(0, ROOT)
+    from hyperfridge_r0_amd import driver
+    for total in (0, 1, 7, 64):
+        for world in (1, 2, 8):
+            parts = [driver.shard_segments(total, world, r) for r in range(world)]
+            assert sorted(x for p in parts for x in p) == list(range(total))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    with pytest.raises(ValueError):
+        driver.shard_segments(4, 2, 2)
+
+
+def test_two_rank_gloo_driver_aggregates_units_and_takes_the_slowest_rank():
+    world, total = 2, 11
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort()
+    (r0, e0, u0, p0), (r1, e1, u1, p1) = results
+    assert e0 == e1 and u0 == u1 == total              # every rank sees the same reduced numbers
+    assert sorted(p0 + p1) == list(range(total))        # all segments proved exactly once
+    assert e0 >= 3 * 0.04 - 1e-3                        # the slow rank's time (3 steps x 40 ms) bounds the result
