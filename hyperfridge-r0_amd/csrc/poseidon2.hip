@@ -43,12 +43,24 @@ __device__ __forceinline__ void p2_mix(uint32_t (&c)[P2_CELLS], const P2Consts* 
   }
 #pragma unroll 1
   for (int r = 0; r < P2_PARTIAL; r++) {
+    // lane 0 goes through the S-box; the diagonal products of the other lanes do not depend on it, and the state sum
+    // is a balanced tree, so the round has no 24-deep dependency chain
+    uint32_t p[P2_CELLS];
+#pragma unroll
+    for (int i = 1; i < P2_CELLS; i++) p[i] = mul(k->diag[i], c[i]);
+    uint32_t s1[12];
+#pragma unroll
+    for (int i = 0; i < 11; i++) s1[i] = add(c[2 * i + 2], c[2 * i + 3]);  // c[2..23]
+    s1[11] = c[1];
+    uint32_t s2[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) s2[i] = add(s1[2 * i], s1[2 * i + 1]);
+    uint32_t rest = add(add(add(s2[0], s2[1]), add(s2[2], s2[3])), add(s2[4], s2[5]));
     c[0] = sbox7(add(c[0], k->rc_partial[r]));
-    uint32_t sum = 0;
+    uint32_t sum = add(rest, c[0]);
+    c[0] = add(sum, mul(k->diag[0], c[0]));
 #pragma unroll
-    for (int i = 0; i < P2_CELLS; i++) sum = add(sum, c[i]);
-#pragma unroll
-    for (int i = 0; i < P2_CELLS; i++) c[i] = add(sum, mul(k->diag[i], c[i]));
+    for (int i = 1; i < P2_CELLS; i++) c[i] = add(sum, p[i]);
   }
 #pragma unroll 1
   for (int r = P2_HALF_FULL; r < 2 * P2_HALF_FULL; r++) {
@@ -67,6 +79,7 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(uint32_t* __restrict__ d
   for (int i = 0; i < P2_CELLS; i++) c[i] = 0;
   const uint32_t* src = matrix + row;
   uint32_t full = cols / P2_RATE, rem = cols % P2_RATE;
+  // (prefetching the next rate block into registers was measured: no gain, the kernel is VALU-issue bound)
   for (uint32_t blk = 0; blk < full; blk++) {
 #pragma unroll
     for (int i = 0; i < P2_RATE; i++) c[i] = src[(size_t)(blk * P2_RATE + i) * rows];
