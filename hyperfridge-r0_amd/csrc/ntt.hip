@@ -168,6 +168,20 @@ __device__ __forceinline__ uint32_t field_index(uint32_t rest0, int s, int j) {
   return ((r >> B) << (B + W)) | ((uint32_t)j << B) | (r & ((1u << B) - 1u));
 }
 
+// Inter-pass twiddles of one thread: element e = q*16 + j needs w_n^(brev_H(e) * lo) with
+// brev_H(e) = brev_4(j) << (H-4) | brev_{H-4}(q), i.e. base * g^brev_4(j) with base = w_n^(brev(q) * lo), g = w_n^(lo << (H-4)):
+// four table words and 29 products per 16 elements instead of 32 table words and 16 products.
+template <uint32_t H>
+__device__ __forceinline__ void interpass_twiddles(uint32_t (&t)[16], const TwTables& tw, uint32_t q, uint32_t lo, uint32_t n) {
+  const uint32_t base = omega_n(tw, bitrev(q, H - 4) * lo, n), g = omega_n(tw, lo << (H - 4), n);
+  uint32_t gp[16];  // base * g^k
+  gp[0] = base;
+#pragma unroll
+  for (int k = 1; k < 16; k++) gp[k] = mul(gp[k - 1], g);
+#pragma unroll
+  for (int j = 0; j < 16; j++) t[j] = gp[((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3)];
+}
+
 // [2^H][16] tile, H = 8 + WL: forward = DIT over the chunk index with the inter-pass twiddle on load,
 // inverse = DIF with the twiddle on store.  Block = 16 << (H - 4) threads.
 template <int WL, int DIR>
@@ -178,10 +192,11 @@ __global__ __launch_bounds__(1024) void ntt_strided16_kernel(uint32_t* __restric
   uint32_t* col = io + ((size_t)blockIdx.y << n);
   uint32_t x[16];
   if (DIR == 0) {
+    {
+      uint32_t tws[16];
+      interpass_twiddles<H>(tws, tw, q, lo, n);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      uint32_t e = q * 16 + j;
-      x[j] = mul(col[((size_t)e << L) + lo], omega_n(tw, bitrev(e, H) * lo, n));
+      for (int j = 0; j < 16; j++) x[j] = mul(col[((size_t)(q * 16 + j) << L) + lo], tws[j]);
     }
     field_layers<4, 0, 0, 0>(x, q, tw.tw12, c);
 #pragma unroll
@@ -234,11 +249,10 @@ __global__ __launch_bounds__(1024) void ntt_strided16_kernel(uint32_t* __restric
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = s[(q * 16 + j) * 16 + t];
     field_layers<4, 0, 1, 0>(x, q, tw.tw12, c);
+    uint32_t tws[16];
+    interpass_twiddles<H>(tws, tw, q, lo, n);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      uint32_t e = q * 16 + j;
-      col[((size_t)e << L) + lo] = mul(x[j], omega_n(tw, bitrev(e, H) * lo, n));
-    }
+    for (int j = 0; j < 16; j++) col[((size_t)(q * 16 + j) << L) + lo] = mul(x[j], tws[j]);
   }
 }
 
@@ -247,9 +261,15 @@ __device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + (e >> 4); }
 // One contiguous chunk of 2^L words (L = 8 + WL) per block of 2^(L-4) threads.
 // Forward (DIR 0): DIT, optionally fed by an input EXP_BITS (0 or 2) times shorter (each word replicated 2^EXP_BITS times,
 // the first EXP_BITS layers skipped).  Inverse (DIR 1): DIF, result scaled by `scale`.
-template <int WL, int DIR, int EXP_BITS>
+struct ZkShift {        // optional fused f(x) -> f(3x) on the inverse transform's output
+  const uint32_t* lo;   // 3^i, i < 2^11
+  const uint32_t* hi;   // 3^(i << 11)
+  uint32_t g[16];       // 3^(k << (n - 4)), k < 16
+};
+
+template <int WL, int DIR, int EXP_BITS, int ZK>
 __global__ __launch_bounds__(256) void ntt_local16_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint32_t n_out,
-                                                           const uint32_t* __restrict__ tw12, W16 c, uint32_t scale) {
+                                                           const uint32_t* __restrict__ tw12, W16 c, uint32_t scale, ZkShift zk) {
   extern __shared__ uint32_t s[];
   constexpr uint32_t L = 8 + WL;
   constexpr int WLs = WL == 0 ? 1 : WL, SETS = 16 >> WLs;
@@ -322,9 +342,19 @@ __global__ __launch_bounds__(256) void ntt_local16_kernel(uint32_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = s[lds_pad(q * 16 + j)];
     field_layers<4, 0, 1, 0>(x, q, tw12, c);
+    if (ZK) {
+      // position p = base + 16 q + j holds the coefficient of x^brev_n(p), brev_n(p) = brev_n(base + 16 q) + (brev_4(j) << (n - 4))
+      const uint32_t e0 = bitrev(base + q * 16, n_out);
+      const uint32_t s0 = mul(scale, mul(zk.lo[e0 & (TW_SIZE - 1)], zk.hi[e0 >> TW_BITS]));
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      *(uint4*)(dst + q * 16 + 4 * k) = make_uint4(mul(x[4 * k], scale), mul(x[4 * k + 1], scale), mul(x[4 * k + 2], scale), mul(x[4 * k + 3], scale));
+      for (int j = 0; j < 16; j++) x[j] = mul(x[j], mul(s0, zk.g[((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3)]));
+#pragma unroll
+      for (int k = 0; k < 4; k++) *(uint4*)(dst + q * 16 + 4 * k) = make_uint4(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        *(uint4*)(dst + q * 16 + 4 * k) = make_uint4(mul(x[4 * k], scale), mul(x[4 * k + 1], scale), mul(x[4 * k + 2], scale), mul(x[4 * k + 3], scale));
+    }
   }
 }
 
@@ -336,6 +366,32 @@ __global__ void bit_reverse_kernel(uint32_t* io, uint32_t po2) {
     uint32_t a = col[i], b = col[j];
     col[i] = b;
     col[j] = a;
+  }
+}
+
+// Tiled in-place bit reversal for po2 >= 10: i = (a:5 | m:po2-10 | b:5) maps to (brev b | brev m | brev a), so the 32x32
+// tile of middle index m lands, transposed and index-reversed, in the tile of brev(m).  A block swaps the pair
+// (m, brev m) through LDS: every global access is a 128-byte row.
+__global__ __launch_bounds__(256) void bit_reverse_tiled_kernel(uint32_t* io, uint32_t po2) {
+  __shared__ uint32_t ta[32][33], tb[32][33];
+  const uint32_t mbits = po2 - 10, m = blockIdx.x, mr = bitrev(m, mbits);
+  if (m > mr) return;
+  uint32_t* col = io + ((size_t)blockIdx.y << po2);
+  const uint32_t b = threadIdx.x & 31, a0 = threadIdx.x >> 5;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    uint32_t a = a0 + 8 * k;
+    ta[a][b] = col[((size_t)a << (po2 - 5)) + (m << 5) + b];
+    if (m != mr) tb[a][b] = col[((size_t)a << (po2 - 5)) + (mr << 5) + b];
+  }
+  __syncthreads();
+  const uint32_t rb = __brev(b) >> 27;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    uint32_t a = a0 + 8 * k, ra = __brev(a) >> 27;
+    // new tile(mr)[a][b] = old tile(m)[brev b][brev a]; and symmetrically
+    col[((size_t)a << (po2 - 5)) + (mr << 5) + b] = ta[rb][ra];
+    if (m != mr) col[((size_t)a << (po2 - 5)) + (m << 5) + b] = tb[rb][ra];
   }
 }
 
@@ -385,16 +441,17 @@ static W16 make_w16(bool inverse) {
 }
 static size_t local16_lds_bytes(uint32_t L) { return (((size_t)1 << L) + ((size_t)1 << (L - 4))) * 4; }
 
-template <int DIR, int EXP_BITS>
-static void launch_local16(r0h_ctx* ctx, uint32_t L, dim3 grid, uint32_t* out, const uint32_t* in, uint32_t n_out, const uint32_t* tw12, const W16& c, uint32_t scale) {
+template <int DIR, int EXP_BITS, int ZK = 0>
+static void launch_local16(r0h_ctx* ctx, uint32_t L, dim3 grid, uint32_t* out, const uint32_t* in, uint32_t n_out, const uint32_t* tw12, const W16& c, uint32_t scale,
+                           const ZkShift& zk = ZkShift{}) {
   const size_t lds = local16_lds_bytes(L);
   const dim3 block(1u << (L - 4));
   switch (L) {
-    case 8: hipLaunchKernelGGL((ntt_local16_kernel<0, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
-    case 9: hipLaunchKernelGGL((ntt_local16_kernel<1, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
-    case 10: hipLaunchKernelGGL((ntt_local16_kernel<2, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
-    case 11: hipLaunchKernelGGL((ntt_local16_kernel<3, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
-    default: hipLaunchKernelGGL((ntt_local16_kernel<4, DIR, EXP_BITS>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale); break;
+    case 8: hipLaunchKernelGGL((ntt_local16_kernel<0, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
+    case 9: hipLaunchKernelGGL((ntt_local16_kernel<1, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
+    case 10: hipLaunchKernelGGL((ntt_local16_kernel<2, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
+    case 11: hipLaunchKernelGGL((ntt_local16_kernel<3, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
+    default: hipLaunchKernelGGL((ntt_local16_kernel<4, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
   }
 }
 template <int DIR>
@@ -420,7 +477,12 @@ using namespace r0h;
 
 extern "C" {
 
-const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2) {
+const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2) { return r0h::interpolate_ntt(ctx, io, count, po2, false); }
+
+}  // extern "C"
+
+namespace r0h {
+const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2, bool zk_shift) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && io, "r0h_batch_interpolate_ntt: NULL argument");
   R0H_REQUIRE(po2 >= 1 && po2 <= MAX_DOMAIN_PO2, "r0h_batch_interpolate_ntt: po2 %u outside [1, %u]", po2, MAX_DOMAIN_PO2);
@@ -437,7 +499,15 @@ const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count,
       R0H_TRY(launch_check("ntt_strided16_kernel<inv>"));
     }
     KScope ks(ctx, "ntt_local_kernel", 8.0 * count * (double)(1u << po2));
-    launch_local16<1, 0>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), u32(io), po2, tw.tw12, c, norm);
+    if (zk_shift) {
+      ZkShift zk{ctx->pow3_lo, ctx->pow3_hi, {0}};
+      const uint32_t g = fpow(enc(3), (uint64_t)1 << (po2 - 4));
+      uint32_t cur = ONE;
+      for (int k = 0; k < 16; k++) { zk.g[k] = cur; cur = mul(cur, g); }
+      launch_local16<1, 0, 1>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), u32(io), po2, tw.tw12, c, norm, zk);
+    } else {
+      launch_local16<1, 0>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), u32(io), po2, tw.tw12, c, norm);
+    }
     return launch_check("ntt_local16_kernel<inv>");
   }
   const Split sp = split_for(po2);
@@ -450,9 +520,14 @@ const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count,
   KScope ks(ctx, "ntt_local_kernel", 8.0 * count * (double)(1u << po2));
   dim3 grid(1u << (po2 - sp.L), count);
   hipLaunchKernelGGL(ntt_local_kernel<1>, grid, dim3(256), (size_t)4 << sp.L, ctx->stream, u32(io), u32(io), sp.L, po2, 0u, tw.tw12, norm);
-  return launch_check("ntt_local_kernel<inv>");
+  R0H_TRY(launch_check("ntt_local_kernel<inv>"));
+  if (zk_shift) return r0h_zk_shift(ctx, io, count, po2);  // small sizes: separate pass
+  return nullptr;
   R0H_GUARD_END
 }
+}  // namespace r0h
+
+extern "C" {
 
 const char* r0h_batch_expand_into_evaluate_ntt(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t count,
                                                uint32_t in_po2, uint32_t expand_bits) {
@@ -506,6 +581,11 @@ const char* r0h_batch_bit_reverse(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uin
   R0H_REQUIRE(po2 <= MAX_DOMAIN_PO2 + 2, "r0h_batch_bit_reverse: po2 %u too large", po2);
   R0H_REQUIRE(((size_t)count << po2) * 4 <= io->bytes, "r0h_batch_bit_reverse: %u columns of 2^%u exceed the buffer", count, po2);
   if (!count || po2 == 0) return nullptr;
+  if (po2 >= 10) {
+    KScope ks(ctx, "bit_reverse_kernel", 8.0 * count * (double)(1u << po2));
+    hipLaunchKernelGGL(bit_reverse_tiled_kernel, dim3(1u << (po2 - 10), count), dim3(256), 0, ctx->stream, u32(io), po2);
+    return launch_check("bit_reverse_tiled_kernel");
+  }
   uint32_t threads = po2 >= 8 ? 256 : (1u << po2);
   KScope ks(ctx, "bit_reverse_kernel", 8.0 * count * (double)(1u << po2));
   dim3 grid((1u << po2) / threads, count);

@@ -175,8 +175,7 @@ static const char* group_from_witness(r0h_ctx* ctx, Scope& sc, Group& g, const r
   R0H_REQUIRE(bytes <= witness->bytes, "prove_segment: witness buffer holds fewer than %u columns of 2^%u", g.count, po2);
   R0H_TRY(sc.alloc(ctx, bytes, &g.coeffs));
   R0H_TRY_HIP(hipMemcpyAsync(g.coeffs->ptr, witness->ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  R0H_TRY(r0h_batch_interpolate_ntt(ctx, g.coeffs, g.count, po2));
-  R0H_TRY(r0h_zk_shift(ctx, g.coeffs, g.count, po2));
+  R0H_TRY(interpolate_ntt(ctx, g.coeffs, g.count, po2, true));  // iNTT with the zk shift fused into its last pass
   return group_finish(ctx, sc, g, po2);
 }
 
