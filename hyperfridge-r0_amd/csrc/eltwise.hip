@@ -54,9 +54,16 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(uint32_t* __restrict__ p
     const uint32_t* row = poly + ((size_t)hi << rl_log);
     Fp4 s = fp4_zero();
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      uint32_t lo = lane + 64 * k;
-      if (lo < rl) s = s + scale(a[k], row[lo]);
+    for (int g = 0; g < 4; g++) {  // four coefficient * power products per 64-bit sum, one reduction per component
+      uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+      for (int k = 4 * g; k < 4 * g + 4; k++) {
+        uint32_t lo = lane + 64 * k;
+        uint32_t cf = lo < rl ? row[lo] : 0u;
+        t0 += (uint64_t)a[k].e[0] * cf; t1 += (uint64_t)a[k].e[1] * cf;
+        t2 += (uint64_t)a[k].e[2] * cf; t3 += (uint64_t)a[k].e[3] * cf;
+      }
+      s = s + Fp4{{reduce64(t0), reduce64(t1), reduce64(t2), reduce64(t3)}};
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

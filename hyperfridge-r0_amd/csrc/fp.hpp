@@ -36,6 +36,15 @@ R0H_HD uint32_t mul(uint32_t a, uint32_t b) {
   uint64_t u = t + (uint64_t)m * P;
   return reduce1((uint32_t)(u >> 32));
 }
+// Montgomery reduction of a sum of up to four products (any T < 2^64): hi(T) - hi(m p) with m = lo(T) p^-1
+R0H_HD uint32_t reduce64(uint64_t t) {
+  uint32_t m = (uint32_t)t * 0x88000001u;  // p^-1 mod 2^32
+  uint32_t q = (uint32_t)(((uint64_t)m * P) >> 32);
+  uint32_t h = (uint32_t)(t >> 32);
+  uint32_t r = h - q;
+  r = h < q ? r + P : r;
+  return reduce1(reduce1(r));
+}
 R0H_HD uint32_t enc(uint32_t canonical) { return mul(canonical % P, R2); }
 R0H_HD uint32_t dec(uint32_t a) { return mul(a, 1u); }
 R0H_HD uint32_t fpow(uint32_t a, uint64_t n) {
@@ -68,15 +77,18 @@ R0H_HD Fp4 operator-(const Fp4& a, const Fp4& b) {
 }
 R0H_HD Fp4 scale(const Fp4& a, uint32_t s) { return Fp4{{mul(a.e[0], s), mul(a.e[1], s), mul(a.e[2], s), mul(a.e[3], s)}}; }
 R0H_HD Fp4 operator*(const Fp4& a, const Fp4& b) {
-  // (a0 + a1 x + a2 x^2 + a3 x^3)(b0 + ...), x^4 = 11
-  uint32_t c0 = mul(a.e[0], b.e[0]);
-  uint32_t c1 = add(mul(a.e[0], b.e[1]), mul(a.e[1], b.e[0]));
-  uint32_t c2 = add(add(mul(a.e[0], b.e[2]), mul(a.e[1], b.e[1])), mul(a.e[2], b.e[0]));
-  uint32_t c3 = add(add(mul(a.e[0], b.e[3]), mul(a.e[1], b.e[2])), add(mul(a.e[2], b.e[1]), mul(a.e[3], b.e[0])));
-  uint32_t c4 = add(add(mul(a.e[1], b.e[3]), mul(a.e[2], b.e[2])), mul(a.e[3], b.e[1]));
-  uint32_t c5 = add(mul(a.e[2], b.e[3]), mul(a.e[3], b.e[2]));
-  uint32_t c6 = mul(a.e[3], b.e[3]);
-  return Fp4{{add(c0, mul(BETA_M, c4)), add(c1, mul(BETA_M, c5)), add(c2, mul(BETA_M, c6)), c3}};
+  // (a0 + a1 x + a2 x^2 + a3 x^3)(b0 + ...), x^4 = 11; products are summed in 64 bits (at most four, 4 p^2 < 2^64)
+  // and reduced once per coefficient
+  typedef uint64_t u64;
+  uint32_t c4 = reduce64((u64)a.e[1] * b.e[3] + (u64)a.e[2] * b.e[2] + (u64)a.e[3] * b.e[1]);
+  uint32_t c5 = reduce64((u64)a.e[2] * b.e[3] + (u64)a.e[3] * b.e[2]);
+  uint32_t c6 = reduce64((u64)a.e[3] * b.e[3]);
+  Fp4 r;
+  r.e[0] = reduce64((u64)a.e[0] * b.e[0] + (u64)BETA_M * c4);
+  r.e[1] = reduce64((u64)a.e[0] * b.e[1] + (u64)a.e[1] * b.e[0] + (u64)BETA_M * c5);
+  r.e[2] = reduce64((u64)a.e[0] * b.e[2] + (u64)a.e[1] * b.e[1] + (u64)a.e[2] * b.e[0] + (u64)BETA_M * c6);
+  r.e[3] = reduce64((u64)a.e[0] * b.e[3] + (u64)a.e[1] * b.e[2] + (u64)a.e[2] * b.e[1] + (u64)a.e[3] * b.e[0]);
+  return r;
 }
 R0H_HD Fp4 fp4_pow(Fp4 a, uint64_t n) {
   Fp4 r = fp4_one();
