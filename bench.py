@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--circuit", default="bench")
     ap.add_argument("--contexts", type=int, default=2, help="segments in flight per GPU (one context + host thread each)")
     ap.add_argument("--cpu-po2", type=int, default=17, help="po2 of the bounded CPU-baseline sample (0 disables)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rehearsing ranks on one box)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses device 0")
     args = ap.parse_args()
 
     import numpy as np
@@ -63,9 +65,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    env = driver.DistEnv(backend="nccl", device=torch.device("cuda", local_rank))
+    env = driver.DistEnv(backend=args.backend, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     if env.world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, env.world))
 

@@ -228,3 +228,22 @@ def test_prove_segment_rejects_a_witness_that_breaks_the_taps(hal, orc):
     # but the constraint identity at z fails and the verifier must say so
     seal = hal.prove_segment(gc, 9, code, data, glob)
     assert oc.verify(seal)[0] == 4
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_randomly_generated_circuits_prove_bit_identically(hal, orc, seed):
+    """Fresh circuit structure per seed (taps, back-offsets, gates, accumulators differ): eval_check is compiled
+    in-process, the seal must verify and equal the oracle's word for word."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_circuit
+    words, info = gen_circuit.generate(n_code=5 + seed % 3, n_data=18 + seed, n_acc=1 + seed % 3, n_free=5, n_pad=20 + seed,
+                                       n_global=1 + seed % 3, seed=seed, cond_every=2 + seed % 3, comp=7)
+    blob = np.array(words, dtype=np.uint32)
+    oc = orc.circuit(blob)
+    gc = hal.load_circuit(blob)
+    po2 = 9 + seed % 3
+    code, data, glob = hal.witgen(gc, po2, seed)
+    seal = hal.prove_segment(gc, po2, code, data, glob)
+    assert oc.verify(seal) == (0, "ok")
+    assert np.array_equal(seal, oc.prove(po2, code.to_host(), data.to_host(), glob))
