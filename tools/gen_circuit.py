@@ -179,6 +179,8 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
         cols = range(q * comp, min(n_data, (q + 1) * comp))
         pool = sorted(t for t in b.taps if (t[0] == G_DATA and t[1] in cols)) + [(G_CODE, c, 0) for c in range(n_code)]
         share = n_pad // n_comp + (1 if q < n_pad % n_comp else 0)
+        if not defects[q]:  # a trailing component of free columns only has nothing to pad
+            share = 0
         for _ in range(share):
             d, deg = rng.pick(defects[q])
             t = [b.get(*rng.pick(pool)) for _ in range(7)]
