@@ -33,7 +33,11 @@ static void fill_p2(P2Consts& k, const uint32_t* rc, const uint32_t* diag) {
       k.rc_partial[pr++] = enc(rc[r * P2_CELLS]);
     }
   }
-  for (int i = 0; i < P2_CELLS; i++) k.diag[i] = enc(diag[i]);
+  for (int i = 0; i < P2_CELLS; i++) {
+    k.diag[i] = enc(diag[i]);
+    k.diag_canon[i] = diag[i];
+    k.diag_shoup[i] = shoup_companion(diag[i]);
+  }
 }
 
 static inline uint32_t sbox7(uint32_t x) {
@@ -123,6 +127,7 @@ const char* buf_alloc_pooled(r0h_ctx* ctx, size_t bytes, r0h_buf** out) {
   if (it != ctx->pool.end()) {
     b->ptr = it->second;
     ctx->pool.erase(it);
+    ctx->pool_bytes -= sz;
   } else {
     hipError_t e = hipMalloc(&b->ptr, sz);
     if (e != hipSuccess) {
@@ -270,7 +275,14 @@ const char* r0h_buf_free(r0h_buf* b) {
     r0h_buf* parent = b->parent;
     if (b->pooled && b->ptr) {
       // stream-ordered reuse: whoever takes this block next enqueues behind everything that used it
-      b->ctx->pool.emplace(b->bytes ? (b->bytes + 255) & ~(size_t)255 : 256, b->ptr);
+      const size_t sz = b->bytes ? (b->bytes + 255) & ~(size_t)255 : 256;
+      if (b->ctx->pool_bytes + sz > POOL_LIMIT) {
+        (void)hipStreamSynchronize(b->ctx->stream);
+        (void)hipFree(b->ptr);
+      } else {
+        b->ctx->pool.emplace(sz, b->ptr);
+        b->ctx->pool_bytes += sz;
+      }
     } else if (b->owned && b->ptr) {
       hipSetDevice(b->ctx->device);
       hipStreamSynchronize(b->ctx->stream);

@@ -45,6 +45,13 @@ R0H_HD uint32_t reduce64(uint64_t t) {
   r = h < q ? r + P : r;
   return reduce1(reduce1(r));
 }
+// Product with a known constant (Shoup): a in Montgomery form times the canonical constant w, given w' = floor(w 2^32 / p).
+// Result = a*w mod p, i.e. the same word mul(a, enc(w)) returns, in 9 issue slots instead of 12 (no 64-bit products).
+R0H_HD uint32_t mul_const(uint32_t a, uint32_t w, uint32_t w_shoup) {
+  uint32_t q = (uint32_t)(((uint64_t)a * w_shoup) >> 32);
+  return reduce1(a * w - q * P);  // exact in 32 bits: the true value lies in [0, 2p)
+}
+inline uint32_t shoup_companion(uint32_t w_canonical) { return (uint32_t)(((uint64_t)w_canonical << 32) / P); }
 R0H_HD uint32_t enc(uint32_t canonical) { return mul(canonical % P, R2); }
 R0H_HD uint32_t dec(uint32_t a) { return mul(a, 1u); }
 R0H_HD uint32_t fpow(uint32_t a, uint64_t n) {

@@ -40,13 +40,16 @@ const char* make_error(const char* fmt, ...);
 constexpr int P2_CELLS = 24, P2_RATE = 16, P2_OUT = 8, P2_HALF_FULL = 4, P2_PARTIAL = 21, P2_ROUNDS = 29;
 constexpr uint32_t TW_BITS = 11;            // two-level twiddle tables of 2^11 entries each
 constexpr uint32_t TW_SIZE = 1u << TW_BITS;
-constexpr uint32_t MAX_DOMAIN_PO2 = 22;     // 2^R0H_MAX_PO2 rows x INV_RATE
+constexpr uint32_t MAX_DOMAIN_PO2 = 22;
+constexpr size_t POOL_LIMIT = (size_t)48 << 30;  // one po2 = 20 segment parks about 8 GiB     // 2^R0H_MAX_PO2 rows x INV_RATE
 
 // Device-resident Poseidon2 tables (Montgomery form).
 struct P2Consts {
   uint32_t rc_full[2 * P2_HALF_FULL][P2_CELLS];
   uint32_t rc_partial[P2_PARTIAL];
-  uint32_t diag[P2_CELLS];
+  uint32_t diag[P2_CELLS];        // Montgomery form of (mu_i - 1)
+  uint32_t diag_canon[P2_CELLS];  // canonical (mu_i - 1) and its Shoup companion floor(w 2^32 / p): constant products
+  uint32_t diag_shoup[P2_CELLS];
 };
 
 // Optional per-kernel timing (HIP events on the context's stream around every launch of a named kernel family).
@@ -83,6 +86,7 @@ struct r0h_ctx {
   void* pinned = nullptr;       // pinned host staging ring for small parameter uploads
   size_t pinned_bytes = 0, pinned_off = 0;
   std::multimap<size_t, void*> pool;  // cached device allocations of the sequencer, by size (stream-ordered reuse)
+  size_t pool_bytes = 0;              // bytes parked in the pool; above POOL_LIMIT blocks are released instead
   r0h::Profile prof;
   bool ktime_on = false;
   std::map<std::string, r0h::KTimer> ktimers;

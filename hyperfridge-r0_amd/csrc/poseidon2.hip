@@ -47,7 +47,7 @@ __device__ __forceinline__ void p2_mix(uint32_t (&c)[P2_CELLS], const P2Consts* 
     // is a balanced tree, so the round has no 24-deep dependency chain
     uint32_t p[P2_CELLS];
 #pragma unroll
-    for (int i = 1; i < P2_CELLS; i++) p[i] = mul(k->diag[i], c[i]);
+    for (int i = 1; i < P2_CELLS; i++) p[i] = mul_const(c[i], k->diag_canon[i], k->diag_shoup[i]);
     uint32_t s1[12];
 #pragma unroll
     for (int i = 0; i < 11; i++) s1[i] = add(c[2 * i + 2], c[2 * i + 3]);  // c[2..23]
@@ -58,7 +58,7 @@ __device__ __forceinline__ void p2_mix(uint32_t (&c)[P2_CELLS], const P2Consts* 
     uint32_t rest = add(add(add(s2[0], s2[1]), add(s2[2], s2[3])), add(s2[4], s2[5]));
     c[0] = sbox7(add(c[0], k->rc_partial[r]));
     uint32_t sum = add(rest, c[0]);
-    c[0] = add(sum, mul(k->diag[0], c[0]));
+    c[0] = add(sum, mul_const(c[0], k->diag_canon[0], k->diag_shoup[0]));
 #pragma unroll
     for (int i = 1; i < P2_CELLS; i++) c[i] = add(sum, p[i]);
   }
