@@ -129,6 +129,20 @@ def main():
                         "share_of_device_time": round(st["total_ms"] / max(sum(v["total_ms"] for v in kstats.values()), 1e-9), 4),
                         "note": "this kernel is VALU-integer bound (Poseidon2: ~1.36k Montgomery products per permutation, "
                                 "~3.3 G permutations/s chip ceiling); its HBM fraction is reported because the metric asks for it: DESIGN.md 6"}
+        if roofline and roofline["kernel"] == "hash_rows_kernel":
+            # secondary view: the bound this kernel actually sits on.  Issue slots per permutation from the instruction mix
+            # (1,356 Montgomery products x ~12 slots + ~2,400 modular adds x 3 slots), peak = 256 CUs x 128 lanes/clk.
+            rows = 4 << po2
+            perms = rows * sum(-(-g // 16) for g in circuit.group_size) + rows  # three groups + CHECK (16 columns)
+            d = 1 << po2
+            while d > 256:  # FRI rounds: 4d/16 rows of 64 columns
+                perms += (4 * d // 16) * 4
+                d //= 16
+            st = kstats["hash_rows_kernel"]
+            gslots = perms * steps * 23.4e3 / (st["total_ms"] * 1e-3) / 1e9
+            roofline["valu_view"] = {"permutations_per_segment": perms, "slots_per_permutation": 23400,
+                                     "achieved_Gslots_per_s": round(gslots, 1), "peak_Gslots_per_s_at_2.4GHz": 78643.2,
+                                     "frac": round(gslots / 78643.2, 4)}
         cols = sum(circuit.group_size)
         seg_bytes = (68 * cols + 3132) * (1 << po2)  # Bytes(C) = 68 MiB*C + 3132 MiB at 2^20 rows
         line = {

@@ -247,3 +247,73 @@ def test_randomly_generated_circuits_prove_bit_identically(hal, orc, seed):
     seal = hal.prove_segment(gc, po2, code, data, glob)
     assert oc.verify(seal) == (0, "ok")
     assert np.array_equal(seal, oc.prove(po2, code.to_host(), data.to_host(), glob))
+
+
+def test_prove_segment_mid_size_two_pass_ntt_split(hal, orc):
+    """po2 = 17: the 2^17 / 2^19 transforms take the two-pass (contiguous + strided) radix-16 route inside the prover."""
+    blob = np.fromfile(circuit_path("small"), dtype=np.uint32)
+    oc = orc.circuit(blob)
+    gc = hal.load_circuit(blob)
+    code, data, glob = hal.witgen(gc, 17, 21)
+    seal = hal.prove_segment(gc, 17, code, data, glob)
+    assert oc.verify(seal) == (0, "ok")
+    assert np.array_equal(seal, oc.prove(17, code.to_host(), data.to_host(), glob))
+
+
+def test_wrapping_a_torch_tensor_is_zero_copy(orc, tmp_path):
+    """PyTorch is only plumbing here: device memory it owns can be handed to the C ABI without a copy.  Run in a child
+    process that initialises torch first (as bench.py does), so that one HIP runtime serves both."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(9)
+    po2, cols = 12, 3
+    x = rnd(rng, cols << po2)
+    np.save(tmp_path / "x.npy", x)
+    script = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+torch.cuda.init()
+import hyperfridge_r0_amd as r0
+x = np.load(%r)
+t32 = torch.from_numpy(x.view(np.int32).copy()).cuda()
+torch.cuda.synchronize()
+hal = r0.Hal(0)
+buf = hal.wrap(t32.data_ptr(), x.size)
+hal.batch_interpolate_ntt(buf, %d, %d)
+hal.sync()
+np.save(%r, t32.cpu().numpy().view(np.uint32))
+buf.free(); hal.close()
+""" % (root, str(tmp_path / "x.npy"), cols, po2, str(tmp_path / "y.npy"))
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert np.array_equal(np.load(tmp_path / "y.npy"), orc.batch_interpolate_ntt(x, cols, po2))
+
+
+def test_two_contexts_prove_concurrently_and_agree(orc):
+    """Two contexts on one device driven from two host threads (bench.py's in-flight mode) produce the same seals as one."""
+    import threading
+    import hyperfridge_r0_amd as r0
+    blob = np.fromfile(circuit_path("small"), dtype=np.uint32)
+    oc = orc.circuit(blob)
+    hals = [r0.Hal(0), r0.Hal(0)]
+    lanes = []
+    for k, h in enumerate(hals):
+        c = h.load_circuit(blob)
+        code, data, glob = h.witgen(c, 12, 100 + k)
+        lanes.append([h, c, code, data, glob, None])
+
+    def work(ln):
+        for _ in range(3):
+            ln[5] = ln[0].prove_segment(ln[1], 12, ln[2], ln[3], ln[4])
+
+    ts = [threading.Thread(target=work, args=(ln,)) for ln in lanes]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for ln in lanes:
+        assert oc.verify(ln[5]) == (0, "ok")
+        assert np.array_equal(ln[5], oc.prove(12, ln[2].to_host(), ln[3].to_host(), ln[4]))
+        for obj in (ln[2], ln[3], ln[1]):
+            obj.free()
+        ln[0].close()
