@@ -82,6 +82,15 @@ def test_poseidon2_constants_match_golden_and_recalled_words(orc):
         assert rc[24 * r] != 0 and not rc[24 * r + 1:24 * (r + 1)].any()
 
 
+def test_poseidon2_known_answer_vector(orc):
+    """The published KAT of the BabyBear t=24 permutation (risc0 `poseidon2_test_vectors` / HorizenLabs `kats`): input
+    (0..23) -> 24 fixed words.  Pins constants, both linear layers, the S-box and the round schedule in one shot."""
+    with open(os.path.join(ROOT, "tests/golden/poseidon2_kat_t24.json")) as f:
+        kat = json.load(f)
+    got = orc.poseidon2_mix([orc.enc(v) for v in kat["input"]])
+    assert list(dec_arr(orc, got)) == kat["output"]
+
+
 def test_poseidon2_permutation_structure(orc):
     """Independent numpy re-computation of the permutation from the golden constants (canonical arithmetic)."""
     with open(os.path.join(ROOT, "tests/golden/poseidon2_babybear_t24.json")) as f:
