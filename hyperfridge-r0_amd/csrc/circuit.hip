@@ -66,6 +66,10 @@ static const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words)
         c->acc_cols.resize(p[0]);
         memcpy(c->acc_cols.data(), p + 1, 12 * (size_t)p[0]);
         break;
+      case R0H_SEC_INFO:
+        R0H_REQUIRE(len == 4, "circuit blob: INFO must be 4 words");
+        memcpy(c->info, p, 16);
+        break;
       default: break;
     }
     pos += 2 + len;
@@ -490,11 +494,6 @@ const char* r0h_circuit_load(r0h_ctx* ctx, const uint32_t* blob, size_t n_words,
   size_t words = c->n_global + c->n_mix + 4 * (size_t)c->plan.n_pow + 4;
   e = hipMalloc((void**)&c->d_params, words * 4);
   if (e != hipSuccess) { hipModuleUnload(c->module); delete c; return make_error("r0h_circuit_load: hipMalloc: %s", hipGetErrorString(e)); }
-  {  // transcript digest of the blob, cached: every segment proof commits to it
-    std::vector<uint32_t> be(c->blob.size());
-    for (size_t i = 0; i < be.size(); i++) be[i] = enc(c->blob[i] % P);
-    p2_hash_elems_host(ctx->p2_host, be.data(), be.size(), c->blob_digest);
-  }
   ctx_retain(ctx);
   *out = c;
   return nullptr;

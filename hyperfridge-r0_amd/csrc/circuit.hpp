@@ -36,7 +36,7 @@ struct r0h_circuit {
   std::vector<r0h::DataCol> data_cols;
   std::vector<r0h::AccCol> acc_cols;
   std::vector<uint32_t> blob;
-  uint32_t blob_digest[8] = {0};  // Poseidon2 digest of the blob words (with the table current at load time)
+  uint8_t info[16] = {'R', '0', 'H', 'I', 'P', '_', 'S', 'Y', 'N', 'T', 'H', ':', 'v', '1', '_', '_'};  // circuit ProtocolInfo tag
   r0h::Plan plan;
   hipModule_t module = nullptr;
   std::vector<hipFunction_t> kernels;

@@ -219,13 +219,16 @@ static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, co
 
   phase(ctx, "transcript_seed");
   {
-    static const char info[] = "r0hip.stark.v1";
-    uint32_t e[32], d[8];
-    size_t len = strlen(info);
-    for (size_t i = 0; i < len; i++) e[i] = enc((uint8_t)info[i]);
-    p2_hash_elems_host(ctx->p2_host, e, len, d);
+    // risc0-circuit-rv32im prove/hal: the hashes of two 16-byte ProtocolInfo tags (one field element per byte) open the
+    // transcript: the proof system's and the circuit's
+    static const char proof_system_info[] = "RISC0_STARK:v1__";
+    uint32_t e[16], d[8];
+    for (int i = 0; i < 16; i++) e[i] = enc((uint8_t)proof_system_info[i]);
+    p2_hash_elems_host(ctx->p2_host, e, 16, d);
     io.commit(d);
-    io.commit(circ->blob_digest);
+    for (int i = 0; i < 16; i++) e[i] = enc(circ->info[i]);
+    p2_hash_elems_host(ctx->p2_host, e, 16, d);
+    io.commit(d);
     std::vector<uint32_t> gv(global, global + cv.n_global);
     for (uint32_t w : gv) R0H_REQUIRE(w < P, "prove_segment: global word not canonical");
     gv.push_back(enc(po2));

@@ -19,6 +19,7 @@
  *   WITGEN  (5): n_code, (kind, param) per CODE column: 0 first-row flag, 1 last-row flag, 2 row counter, 3 fixed random;
  *                n_data, (kind, a, b, c, e) per DATA column: 0 seeded random, 1 a*b+e, 2 a*b*c+e with refs
  *                ref = group<<28 | back<<20 | column (group 1 or 2; DATA refs point at lower-numbered columns)
+ *   INFO    (7): optional, 4 words = the circuit's 16-byte ProtocolInfo tag committed into the transcript (risc0 `CIRCUIT_INFO`)
  *   ACCUM   (6): n_acc, (first_code_col, a_data_col, b_data_col): extension column j (ACCUM columns 4j..4j+3) is the
  *                running product of (mix[8j..8j+4) + a + mix[8j+4..8j+8) * b) from row 0
  */
@@ -31,6 +32,7 @@
 #define R0H_SEC_POLY 4
 #define R0H_SEC_WITGEN 5
 #define R0H_SEC_ACCUM 6
+#define R0H_SEC_INFO 7
 #define R0H_OP_CONST 0
 #define R0H_OP_GET 2
 #define R0H_OP_GET_GLOBAL 3

@@ -18,7 +18,7 @@
 #include <string.h>
 
 #define BLOB_MAGIC 0x31433052u
-enum { SEC_GROUPS = 1, SEC_TAPS = 2, SEC_GLOBALS = 3, SEC_POLY = 4, SEC_WITGEN = 5, SEC_ACCUM = 6 };
+enum { SEC_GROUPS = 1, SEC_TAPS = 2, SEC_GLOBALS = 3, SEC_POLY = 4, SEC_WITGEN = 5, SEC_ACCUM = 6, SEC_INFO = 7 };
 
 uint32_t orc_circuit_group_size(const orc_circuit_t* c, uint32_t g) { return c->group_size[g]; }
 uint32_t orc_circuit_n_taps(const orc_circuit_t* c) { return c->n_taps; }
@@ -67,6 +67,7 @@ static void derive_regs_and_combos(orc_circuit_t* c) {
 orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
   if (n_words < 3 || w[0] != BLOB_MAGIC || w[1] != 1) return NULL;
   orc_circuit_t* c = (orc_circuit_t*)calloc(1, sizeof *c);
+  memcpy(c->info, "R0HIP_SYNTH:v1__", 16);
   size_t pos = 3;
   for (uint32_t s = 0; s < w[2]; s++) {
     if (pos + 2 > n_words) goto bad;
@@ -104,6 +105,9 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
         c->n_acc = p[0];
         c->acc_cols = (orc_acc_col_t*)malloc(sizeof(orc_acc_col_t) * (c->n_acc ? c->n_acc : 1));
         memcpy(c->acc_cols, p + 1, sizeof(orc_acc_col_t) * c->n_acc);
+        break;
+      case SEC_INFO:
+        if (len >= 4) memcpy(c->info, p, 16);
         break;
       default: break;
     }

@@ -23,6 +23,7 @@ struct orc_circuit {
   uint32_t n_code; orc_code_col_t* code_cols;
   uint32_t n_data; orc_data_col_t* data_cols;
   uint32_t n_acc; orc_acc_col_t* acc_cols;
+  uint8_t info[16]; /* circuit ProtocolInfo tag (risc0 `CIRCUIT_INFO`), 16 bytes */
 };
 
 /* poly_ext opcodes (risc0-zkp adapter.rs `PolyExtStep`) */

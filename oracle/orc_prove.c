@@ -35,18 +35,17 @@ static void wiop_write(wiop_t* io, const uint32_t* src, size_t n) {
 }
 static fp4_t rng_ext(orc_rng_t* r) { fp4_t v; for (int i = 0; i < 4; i++) v.e[i] = orc_rng_elem(r); return v; }
 
-static void transcript_seed(orc_rng_t* rng, const uint32_t* blob, size_t blob_words) {
-  static const char info[] = "r0hip.stark.v1";
-  uint32_t e[32], d[8];
-  size_t n = strlen(info);
-  for (size_t i = 0; i < n; i++) e[i] = fp_enc((uint8_t)info[i]);
-  orc_hash_elem_slice(e, n, d);
+/* risc0-circuit-rv32im prove/hal: the transcript starts with the hashes of two 16-byte ProtocolInfo tags, each byte one
+ * field element: the proof system's ("RISC0_STARK:v1__") and the circuit's (from the blob). */
+static void transcript_seed(orc_rng_t* rng, const orc_circuit_t* c) {
+  static const char proof_system_info[] = "RISC0_STARK:v1__";
+  uint32_t e[16], d[8];
+  for (int i = 0; i < 16; i++) e[i] = fp_enc((uint8_t)proof_system_info[i]);
+  orc_hash_elem_slice(e, 16, d);
   orc_rng_mix(rng, d);
-  uint32_t* be = (uint32_t*)malloc(4 * (blob_words ? blob_words : 1));
-  for (size_t i = 0; i < blob_words; i++) be[i] = fp_enc(blob[i] % ORC_P);
-  orc_hash_elem_slice(be, blob_words, d);
+  for (int i = 0; i < 16; i++) e[i] = fp_enc(c->info[i]);
+  orc_hash_elem_slice(e, 16, d);
   orc_rng_mix(rng, d);
-  free(be);
 }
 
 /* ------------------------------------------------------------------ Merkle prover */
@@ -139,7 +138,8 @@ size_t orc_prove_segment(const orc_circuit_t* c, const uint32_t* blob, size_t bl
   wiop_t io;
   memset(&io, 0, sizeof io);
   orc_rng_init(&io.rng);
-  transcript_seed(&io.rng, blob, blob_words);
+  (void)blob; (void)blob_words;
+  transcript_seed(&io.rng, c);
 
   /* globals ++ po2 */
   {
@@ -333,7 +333,8 @@ int orc_verify_segment(const orc_circuit_t* c, const uint32_t* blob, size_t blob
   memset(&io, 0, sizeof io);
   io.w = seal; io.n = seal_words;
   orc_rng_init(&io.rng);
-  transcript_seed(&io.rng, blob, blob_words);
+  (void)blob; (void)blob_words;
+  transcript_seed(&io.rng, c);
   int rc = V_OK;
 
   uint32_t ng = c->n_global;

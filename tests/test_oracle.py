@@ -45,6 +45,8 @@ def test_montgomery_constants(orc):
     for a in (1, 2, P - 1, 12345):
         assert orc.dec(orc.mul(orc.enc(a), orc.L.orc_fp_inv(orc.enc(a)))) == 1
     assert orc.dec(orc.L.orc_fp_pow(orc.enc(3), P - 1)) == 1
+    # the smoke vector of risc0-zkp field/baby_bear.rs (`pow` test): PowerMod[5, 1000, 15*2^27 + 1] == 589699054
+    assert orc.dec(orc.L.orc_fp_pow(orc.enc(5), 1000)) == 589699054 == pow(5, 1000, P)
 
 
 def test_roots_of_unity_match_recalled_risc0_table(orc):

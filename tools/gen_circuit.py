@@ -19,7 +19,7 @@ import sys
 
 P = 15 * 2**27 + 1
 MAGIC = 0x31433052
-SEC_GROUPS, SEC_TAPS, SEC_GLOBALS, SEC_POLY, SEC_WITGEN, SEC_ACCUM = 1, 2, 3, 4, 5, 6
+SEC_GROUPS, SEC_TAPS, SEC_GLOBALS, SEC_POLY, SEC_WITGEN, SEC_ACCUM, SEC_INFO = 1, 2, 3, 4, 5, 6, 7
 G_ACCUM, G_CODE, G_DATA = 0, 1, 2
 OP_CONST, OP_GET, OP_GET_GLOBAL, OP_ADD, OP_SUB, OP_MUL, OP_TRUE, OP_AND_EQZ, OP_AND_COND = 0, 2, 3, 4, 5, 6, 7, 8, 9
 BETA = 11
@@ -231,7 +231,8 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
     def section(tag, words):
         return [tag, len(words)] + list(words)
 
-    words = [MAGIC, 1, 6]
+    words = [MAGIC, 1, 7]
+    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_SYNTH:v1__")))
     words += section(SEC_GROUPS, [4 * n_acc, n_code, n_data])
     words += section(SEC_TAPS, [len(taps)] + [w for t in taps for w in t])
     words += section(SEC_GLOBALS, [n_global, 8 * n_acc] + global_cols)
