@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--circuit", default="bench")
-    ap.add_argument("--contexts", type=int, default=2, help="segments in flight per GPU (one context + host thread each)")
+    ap.add_argument("--contexts", type=int, default=3, help="segments in flight per GPU (one context + host thread each)")
     ap.add_argument("--cpu-po2", type=int, default=17, help="po2 of the bounded CPU-baseline sample (0 disables)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rehearsing ranks on one box)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses device 0")
@@ -60,6 +60,8 @@ def main():
     import torch
 
     import __graft_entry__ as entry
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        entry.ensure_built()  # no-op when the binaries travelled with the snapshot
     import hyperfridge_r0_amd as r0
     from hyperfridge_r0_amd import driver
 

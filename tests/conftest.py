@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import __graft_entry__ as entry
+    entry.ensure_built()  # the HIP library, code objects and the oracle are git-ignored build products
 
 
 @pytest.fixture(scope="session")
