@@ -57,6 +57,7 @@ _SIGNATURES = {
     "r0h_eltwise_add_elem": [_vp, _vp, _vp, _vp, _u32],
     "r0h_eltwise_copy_elem": [_vp, _vp, _vp, _u32],
     "r0h_eltwise_sum_extelem": [_vp, _vp, _vp, _u32, _u32],
+    "r0h_eltwise_zeroize_elem": [_vp, _vp, _u32],
     "r0h_gather_sample": [_vp, _vp, _vp, _u32, _u32, _u32],
     "r0h_scatter": [_vp, _vp, _vp, _vp, _vp, _u32],
     "r0h_fri_fold": [_vp, _vp, _vp, _vp, _u32],
@@ -272,6 +273,9 @@ class Hal:
 
     def eltwise_sum_extelem(self, out, inp, count, n):
         _check(lib().r0h_eltwise_sum_extelem(self.ctx, out.handle, inp.handle, count, n))
+
+    def eltwise_zeroize_elem(self, io, n):
+        _check(lib().r0h_eltwise_zeroize_elem(self.ctx, io.handle, n))
 
     def gather_sample(self, dst, src, idx, size, stride):
         _check(lib().r0h_gather_sample(self.ctx, dst.handle, src.handle, idx, size, stride))

@@ -127,6 +127,11 @@ __global__ void copy_elem_kernel(uint32_t* out, const uint32_t* in, uint32_t n) 
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
 }
+// risc0 marks untouched witness cells with Elem::INVALID (0xffffffff); the prover zeroes them before committing
+__global__ void zeroize_elem_kernel(uint32_t* io, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && io[i] == 0xffffffffu) io[i] = 0u;
+}
 __global__ void sum_extelem_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint32_t count, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -408,6 +413,13 @@ const char* r0h_eltwise_copy_elem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in,
   if (!n) return nullptr;
   hipLaunchKernelGGL(copy_elem_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, u32(out), u32(in), n);
   return launch_ok("copy_elem_kernel");
+}
+const char* r0h_eltwise_zeroize_elem(r0h_ctx* ctx, r0h_buf* io, uint32_t n) {
+  R0H_REQUIRE(ctx && io, "r0h_eltwise_zeroize_elem: NULL argument");
+  R0H_REQUIRE((size_t)n * 4 <= io->bytes, "r0h_eltwise_zeroize_elem: n %u exceeds the buffer", n);
+  if (!n) return nullptr;
+  hipLaunchKernelGGL(zeroize_elem_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, u32(io), n);
+  return launch_ok("zeroize_elem_kernel");
 }
 const char* r0h_eltwise_sum_extelem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t count, uint32_t n) {
   R0H_REQUIRE(ctx && out && in, "r0h_eltwise_sum_extelem: NULL argument");

@@ -92,6 +92,8 @@ const char* r0h_mix_poly_coeffs(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mi
 const char* r0h_eltwise_add_elem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* a, const r0h_buf* b, uint32_t n);
 const char* r0h_eltwise_copy_elem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t n);
 const char* r0h_eltwise_sum_extelem(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, uint32_t count, uint32_t n);
+/* cells still holding Elem::INVALID (0xffffffff) become zero (risc0 `eltwise_zeroize_elem`, run on the witness before commit) */
+const char* r0h_eltwise_zeroize_elem(r0h_ctx* ctx, r0h_buf* io, uint32_t n);
 const char* r0h_gather_sample(r0h_ctx* ctx, r0h_buf* dst, const r0h_buf* src, uint32_t idx, uint32_t size,
                               uint32_t stride);
 const char* r0h_scatter(r0h_ctx* ctx, r0h_buf* into, const r0h_buf* index, const r0h_buf* offsets,

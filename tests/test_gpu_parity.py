@@ -172,6 +172,13 @@ def test_small_eltwise_ops(hal, orc):
     assert np.array_equal(out.to_host().astype(np.int64), (a.astype(np.int64) + b) % P)
     hal.eltwise_copy_elem(out, hal.copy_from(b), 1000)
     assert np.array_equal(out.to_host(), b)
+    z = a.copy()
+    z[[0, 17, 999]] = 0xFFFFFFFF  # Elem::INVALID markers
+    zb = hal.copy_from(z)
+    hal.eltwise_zeroize_elem(zb, 1000)
+    want_z = a.copy()
+    want_z[[0, 17, 999]] = 0
+    assert np.array_equal(zb.to_host(), want_z)
     g = hal.alloc(100)
     hal.gather_sample(g, hal.copy_from(a), 3, 100, 9)
     assert np.array_equal(g.to_host(), a[3::9][:100])
