@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--circuit", default="bench")
     ap.add_argument("--contexts", type=int, default=3, help="segments in flight per GPU (one context + host thread each)")
     ap.add_argument("--cpu-po2", type=int, default=17, help="po2 of the bounded CPU-baseline sample (0 disables)")
+    ap.add_argument("--segments", type=int, default=0, help="BASELINE configs[2]/[3]: prove a fixed batch of this many segments, sharded "
+                                                              "round-robin over the ranks (strong scaling); 0 = the default weak-scaling steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rehearsing ranks on one box)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses device 0")
     args = ap.parse_args()
@@ -104,7 +106,30 @@ def main():
             ln["hal"].sync()
         torch.cuda.synchronize()
 
-    elapsed, units = driver.run_timed(env, step, args.steps, args.warmup, device_sync)
+    if args.segments:
+        # fixed batch: rank r owns segments r, r + world, ...; each in-flight context drains its share of them.  The proving
+        # cost does not depend on the witness values, so the resident witnesses are reused instead of regenerating 0.8 GiB
+        # per segment inside the timed region.
+        mine = driver.shard_segments(args.segments, env.world, env.rank)
+        shares = [mine[k::n_ctx] for k in range(n_ctx)]
+
+        def drain(_i):
+            def run(lane, todo):
+                for _ in todo:
+                    prove_on(lane)
+            ts = [threading.Thread(target=run, args=(ln, sh)) for ln, sh in zip(lanes, shares)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            return len(mine)
+
+        step(-1)
+        elapsed, units = driver.run_timed(env, drain, 1, 0, device_sync)
+        args.steps, scaling = 1, "strong"
+    else:
+        elapsed, units = driver.run_timed(env, step, args.steps, args.warmup, device_sync)
+        scaling = "weak"
     # per-kernel accounting: HIP events around every launch, on one context running alone, over as many segments as were
     # timed (outside the timed region, so the events neither perturb `value` nor see another context's kernels)
     lanes[0]["hal"].kernel_timing(True)
@@ -150,13 +175,14 @@ def main():
         line = {
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
             "value": round(value, 4), "unit": "segments/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u32 (BabyBear, Montgomery)", "data": "synthetic",
             "config": {"workload": "configs[1] shape: 2^%d-row segments, synthetic circuit %s.r0c W=(%d code,%d data,%d accum), %d segment(s) "
                                    "in flight per GPU, witness resident in HBM; no bundled camt53 trace exists (needs the risc0 executor)" % (
                                        po2, args.circuit, circuit.group_size[1], circuit.group_size[2], circuit.group_size[0], n_ctx),
                        "po2": po2, "columns": cols, "taps": circuit.n_taps, "seal_words": int(lanes[0]["seal_words"]),
-                       "segments_per_step_per_gpu": n_ctx, "parallelism": "segment-parallel x%d" % env.world},
+                       "segments_per_step_per_gpu": n_ctx, "fixed_batch_segments": args.segments or None,
+                       "parallelism": "segment-parallel x%d" % env.world},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline(blob, args.cpu_po2, po2) if (args.cpu_po2 and env.world == 1) else None,
             "segment_hbm_model": {"alg_bytes_per_segment": seg_bytes, "achieved_GBs_per_gpu": round(seg_bytes * value / env.world / 1e9, 2),
