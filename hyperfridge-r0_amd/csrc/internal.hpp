@@ -133,7 +133,7 @@ const char* stage_h2d(r0h_ctx* ctx, void* dst_device, const void* src_host, size
 // device buffer from the context's pool: no hipMalloc / hipFree (and no implicit device sync) in steady state
 const char* buf_alloc_pooled(r0h_ctx* ctx, size_t bytes, r0h_buf** out);
 // inverse NTT with the coset shift f(x) -> f(3x) optionally fused into its last pass (sequencer path)
-const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2, bool zk_shift);
+const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, const r0h_buf* src, uint32_t count, uint32_t po2, bool zk_shift);  // src may be io
 void ctx_retain(r0h_ctx* ctx);
 void ctx_release(r0h_ctx* ctx);
 // host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table

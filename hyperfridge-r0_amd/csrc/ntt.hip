@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t omega_n(const TwTables& t, uint32_t e, uint3
 
 // One contiguous chunk of 2^L words per block.  DIR 0: DIT layers (expand_bits, L]; DIR 1: DIF layers L..1.
 template <int DIR>
-__global__ __launch_bounds__(256) void ntt_local_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in,
+__global__ __launch_bounds__(256) void ntt_local_kernel(uint32_t* out, const uint32_t* in /* may alias out */,
                                                          uint32_t L, uint32_t n_out, uint32_t expand_bits,
                                                          const uint32_t* __restrict__ tw12, uint32_t scale) {
   extern __shared__ uint32_t s[];
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void ntt_local_kernel(uint32_t* __restrict__ o
 
 // A [2^H][T] tile per block: T = 2^tlog consecutive residues lo, every chunk index hi.
 template <int DIR>
-__global__ __launch_bounds__(512) void ntt_strided_kernel(uint32_t* __restrict__ io, uint32_t n, uint32_t L, uint32_t H,
+__global__ __launch_bounds__(512) void ntt_strided_kernel(uint32_t* io, uint32_t n, uint32_t L, uint32_t H,
                                                            uint32_t tlog, TwTables tw) {
   extern __shared__ uint32_t s[];
   const uint32_t T = 1u << tlog, tid = threadIdx.x, total = T << H;
@@ -185,18 +185,19 @@ __device__ __forceinline__ void interpass_twiddles(uint32_t (&t)[16], const TwTa
 // [2^H][16] tile, H = 8 + WL: forward = DIT over the chunk index with the inter-pass twiddle on load,
 // inverse = DIF with the twiddle on store.  Block = 16 << (H - 4) threads.
 template <int WL, int DIR>
-__global__ __launch_bounds__(1024) void ntt_strided16_kernel(uint32_t* __restrict__ io, uint32_t n, uint32_t L, TwTables tw, W16 c) {
+__global__ __launch_bounds__(1024) void ntt_strided16_kernel(uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, TwTables tw, W16 c) {
   extern __shared__ uint32_t s[];
   constexpr uint32_t H = 8 + WL;
   const uint32_t t = threadIdx.x & 15, q = threadIdx.x >> 4, lo = (blockIdx.x << 4) + t;
   uint32_t* col = io + ((size_t)blockIdx.y << n);
+  const uint32_t* src = in + ((size_t)blockIdx.y << n);  // may alias col (in-place): every word is read before its tile is written
   uint32_t x[16];
   if (DIR == 0) {
     {
       uint32_t tws[16];
       interpass_twiddles<H>(tws, tw, q, lo, n);
 #pragma unroll
-      for (int j = 0; j < 16; j++) x[j] = mul(col[((size_t)(q * 16 + j) << L) + lo], tws[j]);
+      for (int j = 0; j < 16; j++) x[j] = mul(src[((size_t)(q * 16 + j) << L) + lo], tws[j]);
     }
     field_layers<4, 0, 0, 0>(x, q, tw.tw12, c);
 #pragma unroll
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(1024) void ntt_strided16_kernel(uint32_t* __restric
 #pragma unroll
       for (int ss = 0; ss < SETS; ss++)
 #pragma unroll
-        for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = col[((size_t)field_index<WLs, 8>(q * SETS, ss, j) << L) + lo];
+        for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = src[((size_t)field_index<WLs, 8>(q * SETS, ss, j) << L) + lo];
       field_layers<WLs, 8, 1, 0>(x, q * SETS, tw.tw12, c);
 #pragma unroll
       for (int ss = 0; ss < SETS; ss++)
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(1024) void ntt_strided16_kernel(uint32_t* __restric
       for (int j = 0; j < 16; j++) x[j] = s[field_index<4, 4>(q, 0, j) * 16 + t];
     } else {
 #pragma unroll
-      for (int j = 0; j < 16; j++) x[j] = col[((size_t)field_index<4, 4>(q, 0, j) << L) + lo];
+      for (int j = 0; j < 16; j++) x[j] = src[((size_t)field_index<4, 4>(q, 0, j) << L) + lo];
     }
     field_layers<4, 4, 1, 0>(x, q, tw.tw12, c);
 #pragma unroll
@@ -268,7 +269,7 @@ struct ZkShift {        // optional fused f(x) -> f(3x) on the inverse transform
 };
 
 template <int WL, int DIR, int EXP_BITS, int ZK>
-__global__ __launch_bounds__(256) void ntt_local16_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint32_t n_out,
+__global__ __launch_bounds__(256) void ntt_local16_kernel(uint32_t* out, const uint32_t* in /* may alias out */, uint32_t n_out,
                                                            const uint32_t* __restrict__ tw12, W16 c, uint32_t scale, ZkShift zk) {
   extern __shared__ uint32_t s[];
   constexpr uint32_t L = 8 + WL;
@@ -455,13 +456,13 @@ static void launch_local16(r0h_ctx* ctx, uint32_t L, dim3 grid, uint32_t* out, c
   }
 }
 template <int DIR>
-static void launch_strided16(r0h_ctx* ctx, uint32_t H, dim3 grid, uint32_t* io, uint32_t n, uint32_t L, const TwTables& tw, const W16& c) {
+static void launch_strided16(r0h_ctx* ctx, uint32_t H, dim3 grid, uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, const TwTables& tw, const W16& c) {
   const size_t lds = ((size_t)16 << H) * 4;
   const dim3 block(16u << (H - 4));
   switch (H) {
-    case 8: hipLaunchKernelGGL((ntt_strided16_kernel<0, DIR>), grid, block, lds, ctx->stream, io, n, L, tw, c); break;
-    case 9: hipLaunchKernelGGL((ntt_strided16_kernel<1, DIR>), grid, block, lds, ctx->stream, io, n, L, tw, c); break;
-    default: hipLaunchKernelGGL((ntt_strided16_kernel<2, DIR>), grid, block, lds, ctx->stream, io, n, L, tw, c); break;
+    case 8: hipLaunchKernelGGL((ntt_strided16_kernel<0, DIR>), grid, block, lds, ctx->stream, io, in, n, L, tw, c); break;
+    case 9: hipLaunchKernelGGL((ntt_strided16_kernel<1, DIR>), grid, block, lds, ctx->stream, io, in, n, L, tw, c); break;
+    default: hipLaunchKernelGGL((ntt_strided16_kernel<2, DIR>), grid, block, lds, ctx->stream, io, in, n, L, tw, c); break;
   }
 }
 
@@ -477,14 +478,15 @@ using namespace r0h;
 
 extern "C" {
 
-const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2) { return r0h::interpolate_ntt(ctx, io, count, po2, false); }
+const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2) { return r0h::interpolate_ntt(ctx, io, io, count, po2, false); }
 
 }  // extern "C"
 
 namespace r0h {
-const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2, bool zk_shift) {
+const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, const r0h_buf* src, uint32_t count, uint32_t po2, bool zk_shift) {
   R0H_GUARD_BEGIN
-  R0H_REQUIRE(ctx && io, "r0h_batch_interpolate_ntt: NULL argument");
+  R0H_REQUIRE(ctx && io && src, "r0h_batch_interpolate_ntt: NULL argument");
+  R0H_REQUIRE(((size_t)count << po2) * 4 <= src->bytes, "r0h_batch_interpolate_ntt: %u columns of 2^%u exceed the source buffer", count, po2);
   R0H_REQUIRE(po2 >= 1 && po2 <= MAX_DOMAIN_PO2, "r0h_batch_interpolate_ntt: po2 %u outside [1, %u]", po2, MAX_DOMAIN_PO2);
   R0H_REQUIRE(((size_t)count << po2) * 4 <= io->bytes, "r0h_batch_interpolate_ntt: %u columns of 2^%u exceed the buffer", count, po2);
   if (!count) return nullptr;
@@ -495,7 +497,7 @@ const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t 
     const W16 c = make_w16(true);
     if (s16.H) {
       KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << po2));
-      launch_strided16<1>(ctx, s16.H, dim3(1u << (s16.L - 4), count), u32(io), po2, s16.L, tw, c);
+      launch_strided16<1>(ctx, s16.H, dim3(1u << (s16.L - 4), count), u32(io), u32(src), po2, s16.L, tw, c);
       R0H_TRY(launch_check("ntt_strided16_kernel<inv>"));
     }
     KScope ks(ctx, "ntt_local_kernel", 8.0 * count * (double)(1u << po2));
@@ -504,12 +506,13 @@ const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t 
       const uint32_t g = fpow(enc(3), (uint64_t)1 << (po2 - 4));
       uint32_t cur = ONE;
       for (int k = 0; k < 16; k++) { zk.g[k] = cur; cur = mul(cur, g); }
-      launch_local16<1, 0, 1>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), u32(io), po2, tw.tw12, c, norm, zk);
+      launch_local16<1, 0, 1>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), s16.H ? u32(io) : u32(src), po2, tw.tw12, c, norm, zk);
     } else {
-      launch_local16<1, 0>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), u32(io), po2, tw.tw12, c, norm);
+      launch_local16<1, 0>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), s16.H ? u32(io) : u32(src), po2, tw.tw12, c, norm);
     }
     return launch_check("ntt_local16_kernel<inv>");
   }
+  if (src->ptr != io->ptr) R0H_TRY_HIP(hipMemcpyAsync(io->ptr, src->ptr, ((size_t)count << po2) * 4, hipMemcpyDeviceToDevice, ctx->stream));
   const Split sp = split_for(po2);
   if (sp.H) {
     KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << po2));
@@ -552,7 +555,7 @@ const char* r0h_batch_expand_into_evaluate_ntt(r0h_ctx* ctx, r0h_buf* out, const
     R0H_TRY(launch_check("ntt_local16_kernel<fwd>"));
     if (s16.H) {
       KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << n));
-      launch_strided16<0>(ctx, s16.H, dim3(1u << (s16.L - 4), count), u32(out), n, s16.L, tw, c);
+      launch_strided16<0>(ctx, s16.H, dim3(1u << (s16.L - 4), count), u32(out), u32(out), n, s16.L, tw, c);
       R0H_TRY(launch_check("ntt_strided16_kernel<fwd>"));
     }
     return nullptr;

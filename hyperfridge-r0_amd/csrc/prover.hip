@@ -174,8 +174,8 @@ static const char* group_from_witness(r0h_ctx* ctx, Scope& sc, Group& g, const r
   const size_t bytes = ((size_t)g.count << po2) * 4;
   R0H_REQUIRE(bytes <= witness->bytes, "prove_segment: witness buffer holds fewer than %u columns of 2^%u", g.count, po2);
   R0H_TRY(sc.alloc(ctx, bytes, &g.coeffs));
-  R0H_TRY_HIP(hipMemcpyAsync(g.coeffs->ptr, witness->ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  R0H_TRY(interpolate_ntt(ctx, g.coeffs, g.count, po2, true));  // iNTT with the zk shift fused into its last pass
+  // out-of-place iNTT straight from the witness (no staging copy), zk shift fused into its last pass
+  R0H_TRY(interpolate_ntt(ctx, g.coeffs, witness, g.count, po2, true));
   return group_finish(ctx, sc, g, po2);
 }
 
