@@ -253,3 +253,41 @@ def test_prove_then_verify_and_reject_tampering(orc, name, po2):
     code3, data3, glob3 = c.witgen(po2, seed=12)
     seal3 = c.prove(po2, code3, data3, glob3)
     assert c.verify(seal3)[0] == 0 and not np.array_equal(seal3[:64], seal[:64])
+
+
+def test_verifier_checks_every_part_of_the_seal(orc):
+    """Tamper one word in each region of a seal (layout from DESIGN.md 2) and check that the verifier's *reason* is the
+    check that region feeds -- i.e. 'verifies' really means all of: transcript, constraint identity, Merkle, FRI."""
+    blob = np.fromfile(circuit_path("tiny"), dtype=np.uint32)
+    c = orc.circuit(blob)
+    po2 = 9
+    code, data, glob = c.witgen(po2, seed=3)
+    seal = c.prove(po2, code, data, glob)
+    assert c.verify(seal) == (0, "ok")
+    top = 32 * 8                                   # 2^11-row trees elide down to a 32-digest top layer
+    o_glob = 0
+    o_code = c.n_global + 1
+    o_data, o_accum, o_check = o_code + top, o_code + 2 * top, o_code + 3 * top
+    o_u = o_code + 4 * top
+    o_fri_top = o_u + 4 * (c.n_taps + 16)
+    o_final = o_fri_top + top                      # one FRI round at 2^9 rows: 128-row tree, 32-digest top
+    o_queries = o_final + 4 * 32
+
+    def reason(pos):
+        bad = seal.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        return c.verify(bad)[1]
+
+    assert reason(o_glob) == "constraint check mismatch at z"            # globals enter the constraint program
+    for o in (o_code, o_data + 9, o_accum + 100, o_check + 255):           # a changed top digest changes the root -> new z
+        assert reason(o) in ("constraint check mismatch at z", "group merkle path rejected")
+    assert reason(o_u) == "constraint check mismatch at z"                # tap coefficients at z
+    assert reason(o_u + 4 * c.n_taps) == "constraint check mismatch at z"  # CHECK coefficients at z^4
+    assert reason(o_fri_top + 3) in ("fri merkle path rejected", "group merkle path rejected", "fri fold goal mismatch")
+    assert reason(o_final + 5) in ("fri final polynomial mismatch", "group merkle path rejected", "fri merkle path rejected", "fri fold goal mismatch")
+    assert reason(o_queries) == "group merkle path rejected"              # first opened ACCUM column value
+    assert reason(seal.size - 1) == "fri merkle path rejected"            # last sibling digest of the last FRI opening
+    # a non-canonical field element anywhere in an opened column is refused outright
+    bad = seal.copy()
+    bad[o_queries] = P
+    assert c.verify(bad)[0] != 0
