@@ -228,7 +228,7 @@ typedef unsigned long long u64;
 #define FP_P 2013265921u
 __device__ __forceinline__ u32 fred(u32 x) { u32 y = x - FP_P; return y < x ? y : x; }
 __device__ __forceinline__ u32 fadd(u32 a, u32 b) { return fred(a + b); }
-__device__ __forceinline__ u32 fsub(u32 a, u32 b) { u32 d = a - b; return a < b ? d + FP_P : d; }
+__device__ __forceinline__ u32 fsub(u32 a, u32 b) { u32 d = a - b, e = d + FP_P; return d < e ? d : e; }
 __device__ __forceinline__ u32 fmul(u32 a, u32 b) {
   u64 t = (u64)a * b;
   u32 m = (u32)t * 0x77ffffffu;

@@ -26,8 +26,8 @@ R0H_HD uint32_t reduce1(uint32_t x) {  // x < 2p  ->  x mod p
 }
 R0H_HD uint32_t add(uint32_t a, uint32_t b) { return reduce1(a + b); }
 R0H_HD uint32_t sub(uint32_t a, uint32_t b) {
-  uint32_t d = a - b;
-  return a < b ? d + P : d;
+  uint32_t d = a - b, e = d + P;  // a >= b: d < p <= e;  a < b: d wrapped above 2^32 - p, e = p - (b - a) < p
+  return d < e ? d : e;           // three full-rate instructions (sub, add, min) instead of sub/cmp/add/select
 }
 R0H_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
 R0H_HD uint32_t mul(uint32_t a, uint32_t b) {
