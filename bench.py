@@ -176,7 +176,7 @@ def main():
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
             "value": round(value, 4), "unit": "segments/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "u32 (BabyBear, Montgomery)", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic",
             "config": {"workload": "configs[1] shape: 2^%d-row segments, synthetic circuit %s.r0c W=(%d code,%d data,%d accum), %d segment(s) "
                                    "in flight per GPU, witness resident in HBM; no bundled camt53 trace exists (needs the risc0 executor)" % (
                                        po2, args.circuit, circuit.group_size[1], circuit.group_size[2], circuit.group_size[0], n_ctx),
