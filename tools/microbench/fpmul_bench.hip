@@ -87,6 +87,42 @@ static void run(const char* name, uint32_t* d) {
   printf("%-10s %8.3f ms  %8.2f Gop/s  (%.2f lane-ops/clk/CU at 2.4 GHz)\n", name, best, ops / best * 1e-6, ops / (best * 1e-3) / 256 / 2.4e9);
 }
 
+// Shader clock the chip sustains under this integer load: d(s_memtime) / d(s_memrealtime) x 100 MHz, one stamp pair
+// around a long Montgomery-product loop per workgroup (MI355X_MICROARCH.md, DVFS give-back item 6).
+__global__ __launch_bounds__(256) void clock_probe(uint32_t* sink, unsigned long long* stamps, int iters) {
+  uint32_t x[8], y = 12345u + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; k++) x[k] = (k * 40503u + threadIdx.x + blockIdx.x * 977u) % P;
+  unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = MulMad::f(x[k], y);
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc ^= x[k];
+  unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (acc == 0xdeadbeef) sink[0] = acc;
+  if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+static void probe_clock() {
+  const int blocks = 256 * 8;
+  uint32_t* sink; unsigned long long* d;
+  hipMalloc(&sink, 64); hipMalloc(&d, blocks * 16);
+  for (int rep = 0; rep < 20; rep++) clock_probe<<<blocks, 256>>>(sink, d, 200000);  // ~2 s of back-to-back launches
+  hipDeviceSynchronize();
+  unsigned long long h[blocks * 2];
+  hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+  double lo = 1e9, hi = 0, sum = 0;
+  for (int b = 0; b < blocks; b++) {
+    double ghz = (double)h[2 * b] / (double)h[2 * b + 1] * 0.1;
+    lo = ghz < lo ? ghz : lo; hi = ghz > hi ? ghz : hi; sum += ghz;
+  }
+  printf("in-kernel shader clock under the Montgomery-product load: mean %.3f GHz (min %.3f, max %.3f over %d workgroups)\n", sum / blocks, lo, hi, blocks);
+  hipFree(sink); hipFree(d);
+}
+
 int main() {
   uint32_t* d;
   hipMalloc(&d, 4096);
@@ -99,6 +135,7 @@ int main() {
   run<MulMad>("mont_mad", d);
   run<MulHiLo>("mont_hilo", d);
   run<MulF64>("mod_f64", d);
+  probe_clock();
   hipFree(d);
   return 0;
 }
