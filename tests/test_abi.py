@@ -69,3 +69,27 @@ def test_eval_check_codegen_is_deterministic_and_complete():
     bad = blob[:-7]
     with pytest.raises(r0.R0HipError):
         r0.emit_eval_check_source(bad)
+
+
+def test_blob_parser_survives_random_corruption():
+    """Host-only fuzz of the circuit loader's validation (r0h_circuit_emit_hip parses and plans without a GPU): a mutated
+    blob must either be rejected with a message or produce source -- never crash, never hang."""
+    import hyperfridge_r0_amd as r0
+    blob = np.fromfile(circuit_path("tiny"), dtype=np.uint32)
+    rng = np.random.default_rng(2024)
+    rejected = accepted = 0
+    for trial in range(300):
+        bad = blob.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, bad.size))
+            mode = int(rng.integers(0, 3))
+            bad[pos] = [int(rng.integers(0, 2**32)), int(bad[pos]) ^ (1 << int(rng.integers(0, 32))), int(rng.integers(0, 64))][mode]
+        if trial % 10 == 0:
+            bad = bad[:int(rng.integers(3, bad.size))]
+        try:
+            r0.emit_eval_check_source(bad)
+            accepted += 1
+        except r0.R0HipError as e:
+            assert str(e)
+            rejected += 1
+    assert rejected > 50 and accepted + rejected == 300
