@@ -2,12 +2,13 @@
 // witness on the device, prove K segments, print throughput and a digest of the seal.
 // It stands where hyperfridge's `host prove-camt53` stands relative to risc0 (host/src/main.rs:420-423 obtains a prover and
 // calls prove once); everything risc0-specific above the segment prover (executor, receipts) is out of scope.
-//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--seal-out file]
+//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/r0hip.h"
@@ -25,11 +26,11 @@ static void die(const char* what, const char* err) {
 
 int main(int argc, char** argv) {
   if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) {
-    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--seal-out file]\n%s\n", r0h_version());
+    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file]\n%s\n", r0h_version());
     return argc < 2 ? 1 : 0;
   }
   std::string blob_path = argv[1], co_path, seal_out;
-  unsigned po2 = 16, segments = 1, device = 0;
+  unsigned po2 = 16, segments = 1, device = 0, contexts = 1;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--code-object")) co_path = argv[i + 1];
@@ -37,6 +38,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--segments")) segments = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], nullptr, 10);
     else if (!strcmp(argv[i], "--device")) device = (unsigned)atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--contexts")) contexts = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--seal-out")) seal_out = argv[i + 1];
     else { fprintf(stderr, "r0h_prove: unknown option %s\n", argv[i]); return 1; }
   }
@@ -48,36 +50,56 @@ int main(int argc, char** argv) {
   std::vector<uint32_t> blob((size_t)sz / 4);
   if (fread(blob.data(), 4, blob.size(), f) != blob.size()) { fprintf(stderr, "r0h_prove: short read\n"); return 1; }
   fclose(f);
+  if (contexts < 1 || contexts > 8) { fprintf(stderr, "r0h_prove: --contexts must be 1..8\n"); return 1; }
 
-  r0h_ctx* ctx = nullptr;
-  CHECK(r0h_ctx_create((int)device, &ctx));
-  r0h_circuit* circ = nullptr;
-  CHECK(r0h_circuit_load(ctx, blob.data(), blob.size(), co_path.empty() ? nullptr : co_path.c_str(), &circ));
+  // one context (+ circuit + resident witness) per in-flight lane, each driven by its own host thread: segments are
+  // independent, so the lanes never talk to each other
+  struct Lane {
+    r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; r0h_buf* code = nullptr; r0h_buf* data = nullptr;
+    std::vector<uint32_t> global, seal; size_t words = 0; unsigned proved = 0;
+  };
+  std::vector<Lane> lanes(contexts);
   const size_t n = (size_t)1 << po2;
-  r0h_buf *code = nullptr, *data = nullptr;
-  CHECK(r0h_buf_alloc(ctx, (size_t)r0h_circuit_group_size(circ, R0H_GROUP_CODE) * n * 4, &code));
-  CHECK(r0h_buf_alloc(ctx, (size_t)r0h_circuit_group_size(circ, R0H_GROUP_DATA) * n * 4, &data));
-  std::vector<uint32_t> global(r0h_circuit_n_global(circ) + 1), seal((size_t)1 << 20);
-  size_t words = 0;
-  double total = 0;
-  for (unsigned s = 0; s < segments; s++) {
-    CHECK(r0h_witgen(ctx, circ, po2, seed + s, code, data, global.data()));
-    auto t0 = std::chrono::steady_clock::now();
-    CHECK(r0h_prove_segment(ctx, circ, po2, code, data, global.data(), seal.data(), seal.size(), &words));
-    total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (unsigned k = 0; k < contexts; k++) {
+    Lane& ln = lanes[k];
+    CHECK(r0h_ctx_create((int)device, &ln.ctx));
+    CHECK(r0h_circuit_load(ln.ctx, blob.data(), blob.size(), co_path.empty() ? nullptr : co_path.c_str(), &ln.circ));
+    CHECK(r0h_buf_alloc(ln.ctx, (size_t)r0h_circuit_group_size(ln.circ, R0H_GROUP_CODE) * n * 4, &ln.code));
+    CHECK(r0h_buf_alloc(ln.ctx, (size_t)r0h_circuit_group_size(ln.circ, R0H_GROUP_DATA) * n * 4, &ln.data));
+    ln.global.resize(r0h_circuit_n_global(ln.circ) + 1);
+    ln.seal.resize((size_t)1 << 20);
+    CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + k, ln.code, ln.data, ln.global.data()));
   }
-  uint64_t h = 1469598103934665603ull;  // FNV-1a over the last seal, to compare runs
-  for (size_t i = 0; i < words; i++) { h ^= seal[i]; h *= 1099511628211ull; }
-  printf("{\"segments\": %u, \"po2\": %u, \"seal_words\": %zu, \"seal_fnv1a\": \"%016llx\", \"seconds\": %.6f, \"segments_per_s\": %.4f}\n", segments, po2, words,
-         (unsigned long long)h, total, segments / total);
+  auto work = [&](unsigned k) {
+    Lane& ln = lanes[k];
+    for (unsigned s = k; s < segments; s += contexts) {
+      if (s >= contexts) CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + s, ln.code, ln.data, ln.global.data()));  // next segment of this lane
+      CHECK(r0h_prove_segment(ln.ctx, ln.circ, po2, ln.code, ln.data, ln.global.data(), ln.seal.data(), ln.seal.size(), &ln.words));
+      ln.proved++;
+    }
+  };
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> threads;
+  for (unsigned k = 1; k < contexts; k++) threads.emplace_back(work, k);
+  work(0);
+  for (auto& t : threads) t.join();
+  const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  // report the seal of the last segment proved by lane 0 (segment index = largest s < segments with s % contexts == 0)
+  const Lane& l0 = lanes[0];
+  uint64_t h = 1469598103934665603ull;  // FNV-1a, to compare runs
+  for (size_t i = 0; i < l0.words; i++) { h ^= l0.seal[i]; h *= 1099511628211ull; }
+  printf("{\"segments\": %u, \"contexts\": %u, \"po2\": %u, \"seal_words\": %zu, \"seal_fnv1a\": \"%016llx\", \"seconds\": %.6f, \"segments_per_s\": %.4f}\n",
+         segments, contexts, po2, l0.words, (unsigned long long)h, total, segments / total);
   if (!seal_out.empty()) {
     FILE* o = fopen(seal_out.c_str(), "wb");
-    if (!o || fwrite(seal.data(), 4, words, o) != words) { fprintf(stderr, "r0h_prove: cannot write %s\n", seal_out.c_str()); return 1; }
+    if (!o || fwrite(l0.seal.data(), 4, l0.words, o) != l0.words) { fprintf(stderr, "r0h_prove: cannot write %s\n", seal_out.c_str()); return 1; }
     fclose(o);
   }
-  CHECK(r0h_buf_free(code));
-  CHECK(r0h_buf_free(data));
-  CHECK(r0h_circuit_free(circ));
-  CHECK(r0h_ctx_destroy(ctx));
+  for (Lane& ln : lanes) {
+    CHECK(r0h_buf_free(ln.code));
+    CHECK(r0h_buf_free(ln.data));
+    CHECK(r0h_circuit_free(ln.circ));
+    CHECK(r0h_ctx_destroy(ln.ctx));
+  }
   return 0;
 }
