@@ -52,6 +52,13 @@ R0H_HD uint32_t mul_const(uint32_t a, uint32_t w, uint32_t w_shoup) {
   return reduce1(a * w - q * P);  // exact in 32 bits: the true value lies in [0, 2p)
 }
 inline uint32_t shoup_companion(uint32_t w_canonical) { return (uint32_t)(((uint64_t)w_canonical << 32) / P); }
+// Montgomery product without the final conditional subtraction.  For a*b + 2^32 p < 2^64 (e.g. a < 2p, b < p; or both
+// below 1.47p) the result is congruent to a*b/2^32 and below a*b/2^32 + p; callers track the bound.
+R0H_HD uint32_t mul_lazy(uint32_t a, uint32_t b) {
+  uint64_t t = (uint64_t)a * b;
+  uint32_t m = (uint32_t)t * NPINV;
+  return (uint32_t)((t + (uint64_t)m * P) >> 32);
+}
 R0H_HD uint32_t enc(uint32_t canonical) { return mul(canonical % P, R2); }
 R0H_HD uint32_t dec(uint32_t a) { return mul(a, 1u); }
 R0H_HD uint32_t fpow(uint32_t a, uint64_t n) {

@@ -10,9 +10,15 @@
 
 namespace r0h {
 
+// x^7 with lazily reduced intermediates (bounds in units of p, x < 1):
+//   x2 = x*x        < 0.47 + 1 = 1.47        x3 = x2*x < 0.69 + 1 = 1.69      x4 = x2*x2 < 1.02 + 1 = 2.02 (t + 2^32 p < 2^64 holds)
+//   x4' = x4 - p if that does not wrap (< 1.02)                               x7 = x3*x4' < 0.81 + 1, then one reduction
+// Two conditional subtractions fewer than four full products; the result is the same canonical word.
 __device__ __forceinline__ uint32_t sbox7(uint32_t x) {
-  uint32_t x2 = mul(x, x), x4 = mul(x2, x2);
-  return mul(mul(x4, x2), x);
+  uint32_t x2 = mul_lazy(x, x);
+  uint32_t x3 = mul_lazy(x2, x);
+  uint32_t x4 = reduce1(mul_lazy(x2, x2));
+  return reduce1(mul_lazy(x3, x4));
 }
 
 __device__ __forceinline__ void m_ext(uint32_t (&c)[P2_CELLS]) {
