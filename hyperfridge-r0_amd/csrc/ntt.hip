@@ -146,7 +146,7 @@ __device__ __forceinline__ void field_layers(uint32_t (&x)[16], uint32_t rest0, 
         uint32_t& u = x[s * (1 << W) + j0];
         uint32_t& v = x[s * (1 << W) + j1];
         const bool trivial = B == 0 && cidx == 0;
-        uint32_t twd = cidx == 0 ? a_tw : (B == 0 ? c.w[cidx] : mul(a_tw, c.w[cidx]));
+        uint32_t twd = cidx == 0 ? a_tw : (B == 0 ? c.w[cidx] : mul_lazy(a_tw, c.w[cidx]));  // < 2p is fine as a multiplier
         if (DIR == 0) {
           uint32_t a = u, t = trivial ? v : mul(v, twd);
           u = add(a, t);
@@ -177,7 +177,7 @@ __device__ __forceinline__ void interpass_twiddles(uint32_t (&t)[16], const TwTa
   uint32_t gp[16];  // base * g^k
   gp[0] = base;
 #pragma unroll
-  for (int k = 1; k < 16; k++) gp[k] = mul(gp[k - 1], g);
+  for (int k = 1; k < 16; k++) gp[k] = mul_lazy(gp[k - 1], g);  // multipliers may stay below 2p (g < p keeps the bound)
 #pragma unroll
   for (int j = 0; j < 16; j++) t[j] = gp[((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3)];
 }
