@@ -235,14 +235,15 @@ __device__ __forceinline__ u32 fmul(u32 a, u32 b) {
   u64 u = t + (u64)m * FP_P;
   return fred((u32)(u >> 32));
 }
-// Montgomery reduction of a sum of up to four 62-bit products (any T < 2^64): hi(T) - hi(m*p) with m = lo(T) * p^-1
+// Montgomery reduction of a sum of up to four products of reduced words (T < 4 p^2): hi(T) - hi(m*p), m = lo(T) * p^-1;
+// hi(T) < 1.875 p, so one conditional subtraction after the sign fix
 __device__ __forceinline__ u32 fred64(u64 T) {
   u32 m = (u32)T * 0x88000001u;
   u32 q = __umulhi(m, FP_P);
   u32 h = (u32)(T >> 32);
   u32 r = h - q;
   r = h < q ? r + FP_P : r;
-  return fred(fred(r));
+  return fred(r);
 }
 #define TAP(g, col, back) g[(size_t)(col) * domain + ((i - 4u * (back)) & mask)]
 )SRC";
@@ -583,6 +584,7 @@ const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, con
   R0H_REQUIRE(ctx && c && eval_accum && eval_code && eval_data && check && poly_mix, "r0h_eval_check: NULL argument");
   R0H_REQUIRE((global || !c->n_global) && (mix || !c->n_mix), "r0h_eval_check: NULL globals");
   R0H_REQUIRE(po2 >= 6 && po2 <= R0H_MAX_PO2, "r0h_eval_check: po2 %u outside [6, %u]", po2, R0H_MAX_PO2);
+  for (int q = 0; q < 4; q++) R0H_REQUIRE(poly_mix[q] < P, "r0h_eval_check: poly_mix words must be canonical (< p)");
   const size_t domain = (size_t)4 << po2;
   const r0h_buf* g[3] = {eval_accum, eval_code, eval_data};
   for (int k = 0; k < 3; k++) R0H_REQUIRE(domain * c->group_size[k] * 4 <= g[k]->bytes, "r0h_eval_check: group %d buffer too small", k);

@@ -318,6 +318,7 @@ __global__ void divide_apply_kernel(uint32_t* __restrict__ poly, const uint32_t*
 }
 
 static Fp4 host_fp4(const uint32_t v[4]) { return Fp4{{v[0], v[1], v[2], v[3]}}; }
+static bool canonical4(const uint32_t v[4]) { return v[0] < P && v[1] < P && v[2] < P && v[3] < P; }
 
 }  // namespace r0h
 
@@ -369,6 +370,7 @@ const char* r0h_mix_poly_coeffs(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mi
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && combos && input && mix_start && mix && (combo_of || !input_count), "r0h_mix_poly_coeffs: NULL argument");
   R0H_REQUIRE(po2 <= MAX_DOMAIN_PO2, "r0h_mix_poly_coeffs: po2 %u too large", po2);
+  R0H_REQUIRE(canonical4(mix_start) && canonical4(mix), "r0h_mix_poly_coeffs: mix words must be canonical (< p)");
   R0H_REQUIRE(((size_t)input_count << po2) * 4 <= input->bytes, "r0h_mix_poly_coeffs: %u columns exceed the input buffer", input_count);
   if (!input_count) return nullptr;
   std::vector<uint32_t> order(input_count);
@@ -457,6 +459,7 @@ const char* r0h_scatter(r0h_ctx* ctx, r0h_buf* into, const r0h_buf* index, const
 
 const char* r0h_fri_fold(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, const uint32_t mix[4], uint32_t n_out) {
   R0H_REQUIRE(ctx && out && in && mix, "r0h_fri_fold: NULL argument");
+  R0H_REQUIRE(canonical4(mix), "r0h_fri_fold: mix words must be canonical (< p)");
   R0H_REQUIRE((size_t)n_out * 16 <= out->bytes && (size_t)n_out * 16 * R0H_FRI_FOLD <= in->bytes, "r0h_fri_fold: n_out %u exceeds a buffer", n_out);
   if (!n_out) return nullptr;
   hipLaunchKernelGGL(fri_fold_kernel, dim3((n_out + 255) / 256), dim3(256), 0, ctx->stream, u32(out), u32(in), host_fp4(mix), n_out);
@@ -478,6 +481,7 @@ const char* r0h_prefix_products(r0h_ctx* ctx, r0h_buf* io, uint32_t n) {
 
 const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint32_t z[4], uint32_t remainder[4]) {
   R0H_REQUIRE(ctx && poly && z, "r0h_poly_divide: NULL argument");
+  R0H_REQUIRE(canonical4(z), "r0h_poly_divide: z words must be canonical (< p)");
   R0H_REQUIRE(n && (n & (n - 1)) == 0, "r0h_poly_divide: n %u is not a power of two", n);
   R0H_REQUIRE((size_t)n * 16 <= poly->bytes, "r0h_poly_divide: n %u exceeds the buffer", n);
   const ScanGeom g = scan_geom(n);

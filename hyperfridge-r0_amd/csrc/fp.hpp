@@ -36,14 +36,15 @@ R0H_HD uint32_t mul(uint32_t a, uint32_t b) {
   uint64_t u = t + (uint64_t)m * P;
   return reduce1((uint32_t)(u >> 32));
 }
-// Montgomery reduction of a sum of up to four products (any T < 2^64): hi(T) - hi(m p) with m = lo(T) p^-1
+// Montgomery reduction of a sum of up to four products of reduced words (T < 4 p^2 < 2^64): hi(T) - hi(m p) with
+// m = lo(T) p^-1.  hi(T) < 4 p^2 / 2^32 = 1.875 p and hi(m p) < p, so after the sign fix one conditional subtraction is enough.
 R0H_HD uint32_t reduce64(uint64_t t) {
   uint32_t m = (uint32_t)t * 0x88000001u;  // p^-1 mod 2^32
   uint32_t q = (uint32_t)(((uint64_t)m * P) >> 32);
   uint32_t h = (uint32_t)(t >> 32);
   uint32_t r = h - q;
   r = h < q ? r + P : r;
-  return reduce1(reduce1(r));
+  return reduce1(r);
 }
 // Product with a known constant (Shoup): a in Montgomery form times the canonical constant w, given w' = floor(w 2^32 / p).
 // Result = a*w mod p, i.e. the same word mul(a, enc(w)) returns, in 9 issue slots instead of 12 (no 64-bit products).
