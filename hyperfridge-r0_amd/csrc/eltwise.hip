@@ -31,10 +31,12 @@ static const char* launch_ok(const char* what) {
 constexpr uint32_t EVAL_RL_LOG = 10;
 constexpr uint32_t EVAL_BLOCKS = 64;  // partial sums per evaluation
 
-__global__ void eval_tables_kernel(uint32_t* __restrict__ tab, Fp4 x, uint32_t rl, uint32_t rows) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < rl) st4(tab + 4 * (size_t)i, fp4_pow(x, i));
-  else if (i < rl + rows) st4(tab + 4 * (size_t)i, fp4_pow(x, (uint64_t)(i - rl) * rl));
+// A[lo] and B[hi] with A[lo] * B[hi] = x^e(hi*rl + lo): e = identity for natural-order coefficients, e = brev_n for
+// bit-reversed ones (brev_n(hi*rl + lo) = brev(lo) * rows + brev(hi))
+__global__ void eval_tables_kernel(uint32_t* __restrict__ tab, Fp4 x, uint32_t rl_log, uint32_t rows_log, uint32_t bitrev_coeffs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, rl = 1u << rl_log, rows = 1u << rows_log;
+  if (i < rl) st4(tab + 4 * (size_t)i, fp4_pow(x, bitrev_coeffs ? (uint64_t)bitrev(i, rl_log) << rows_log : (uint64_t)i));
+  else if (i < rl + rows) st4(tab + 4 * (size_t)i, fp4_pow(x, bitrev_coeffs ? (uint64_t)bitrev(i - rl, rows_log) : (uint64_t)(i - rl) << rl_log));
 }
 
 __global__ __launch_bounds__(256) void eval_rows_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
@@ -328,6 +330,14 @@ extern "C" {
 
 const char* r0h_batch_evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, const uint32_t* which,
                                    const uint32_t* xs, uint32_t n_eval, r0h_buf* out) {
+  return r0h::evaluate_any(ctx, coeffs, po2, which, xs, n_eval, out, false);
+}
+
+}  // extern "C"
+
+namespace r0h {
+const char* evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, const uint32_t* which, const uint32_t* xs,
+                         uint32_t n_eval, r0h_buf* out, bool bitrev_coeffs) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && coeffs && out && (n_eval == 0 || (which && xs)), "r0h_batch_evaluate_any: NULL argument");
   R0H_REQUIRE(po2 <= MAX_DOMAIN_PO2, "r0h_batch_evaluate_any: po2 %u too large", po2);
@@ -356,7 +366,7 @@ const char* r0h_batch_evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t
     R0H_TRY(stage_h2d(ctx, idx, host.data(), host.size() * 4));
     Fp4 x = Fp4{{g.first[0], g.first[1], g.first[2], g.first[3]}};
     KScope ks(ctx, "batch_evaluate_any", 4.0 * ng * (double)(1u << po2));
-    hipLaunchKernelGGL(eval_tables_kernel, dim3((rl + rows + 255) / 256), dim3(256), 0, ctx->stream, tab, x, rl, rows);
+    hipLaunchKernelGGL(eval_tables_kernel, dim3((rl + rows + 255) / 256), dim3(256), 0, ctx->stream, tab, x, rl_log, po2 - rl_log, bitrev_coeffs ? 1u : 0u);
     hipLaunchKernelGGL(eval_rows_kernel, dim3(blocks, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((ng + 63) / 64), dim3(64), 0, ctx->stream, u32(out), part, idx + ng, blocks, ng);
     R0H_TRY(launch_ok("batch_evaluate_any kernels"));  // scratch reuse by the next group is ordered by the stream
@@ -364,6 +374,9 @@ const char* r0h_batch_evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t
   return nullptr;
   R0H_GUARD_END
 }
+}  // namespace r0h
+
+extern "C" {
 
 const char* r0h_mix_poly_coeffs(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mix_start[4], const uint32_t mix[4],
                                 const r0h_buf* input, const uint32_t* combo_of, uint32_t input_count, uint32_t po2) {

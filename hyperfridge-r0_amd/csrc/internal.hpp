@@ -134,6 +134,11 @@ const char* stage_h2d(r0h_ctx* ctx, void* dst_device, const void* src_host, size
 const char* buf_alloc_pooled(r0h_ctx* ctx, size_t bytes, r0h_buf** out);
 // inverse NTT with the coset shift f(x) -> f(3x) optionally fused into its last pass (sequencer path)
 const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, const r0h_buf* src, uint32_t count, uint32_t po2, bool zk_shift);  // src may be io
+// batch_evaluate_any over coefficients stored in natural or bit-reversed order (the sequencer keeps them bit-reversed)
+const char* evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, const uint32_t* which, const uint32_t* xs, uint32_t n_eval,
+                         r0h_buf* out, bool bitrev_coeffs);
+// in-place bit reversal of `count` columns of 2^po2 extension elements (16-byte units)
+const char* bit_reverse_ext(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
 void ctx_retain(r0h_ctx* ctx);
 void ctx_release(r0h_ctx* ctx);
 // host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table

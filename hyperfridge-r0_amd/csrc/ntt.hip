@@ -396,6 +396,31 @@ __global__ __launch_bounds__(256) void bit_reverse_tiled_kernel(uint32_t* io, ui
   }
 }
 
+// the same pair-of-tiles swap for 16-byte (extension) elements: 16x16 tiles, 256-byte rows
+__global__ __launch_bounds__(256) void bit_reverse_ext_tiled_kernel(uint4* io, uint32_t po2) {
+  __shared__ uint4 ta[16][17], tb[16][17];
+  const uint32_t mbits = po2 - 8, m = blockIdx.x, mr = bitrev(m, mbits);
+  if (m > mr) return;
+  uint4* col = io + ((size_t)blockIdx.y << po2);
+  const uint32_t b = threadIdx.x & 15, a = threadIdx.x >> 4;
+  ta[a][b] = col[((size_t)a << (po2 - 4)) + (m << 4) + b];
+  if (m != mr) tb[a][b] = col[((size_t)a << (po2 - 4)) + (mr << 4) + b];
+  __syncthreads();
+  const uint32_t rb = __brev(b) >> 28, ra = __brev(a) >> 28;
+  col[((size_t)a << (po2 - 4)) + (mr << 4) + b] = ta[rb][ra];
+  if (m != mr) col[((size_t)a << (po2 - 4)) + (m << 4) + b] = tb[rb][ra];
+}
+__global__ void bit_reverse_ext_kernel(uint4* io, uint32_t po2) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint4* col = io + ((size_t)blockIdx.y << po2);
+  uint32_t j = bitrev(i, po2);
+  if (i < j) {
+    uint4 a = col[i], b = col[j];
+    col[i] = b;
+    col[j] = a;
+  }
+}
+
 __global__ void zk_shift_kernel(uint32_t* io, uint32_t po2, const uint32_t* pow3_lo, const uint32_t* pow3_hi) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t* col = io + ((size_t)blockIdx.y << po2);
@@ -596,6 +621,25 @@ const char* r0h_batch_bit_reverse(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uin
   return launch_check("bit_reverse_kernel");
   R0H_GUARD_END
 }
+
+}  // extern "C"
+namespace r0h {
+const char* bit_reverse_ext(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && io && po2 <= MAX_DOMAIN_PO2, "bit_reverse_ext: bad argument");
+  R0H_REQUIRE(((size_t)count << po2) * 16 <= io->bytes, "bit_reverse_ext: %u columns of 2^%u exceed the buffer", count, po2);
+  if (!count || po2 == 0) return nullptr;
+  KScope ks(ctx, "bit_reverse_kernel", 32.0 * count * (double)(1u << po2));
+  if (po2 >= 8) {
+    hipLaunchKernelGGL(bit_reverse_ext_tiled_kernel, dim3(1u << (po2 - 8), count), dim3(256), 0, ctx->stream, (uint4*)io->ptr, po2);
+  } else {
+    hipLaunchKernelGGL(bit_reverse_ext_kernel, dim3(1, count), dim3(1u << po2), 0, ctx->stream, (uint4*)io->ptr, po2);
+  }
+  return launch_check("bit_reverse_ext kernel");
+  R0H_GUARD_END
+}
+}  // namespace r0h
+extern "C" {
 
 const char* r0h_zk_shift(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2) {
   R0H_GUARD_BEGIN

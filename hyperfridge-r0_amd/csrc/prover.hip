@@ -157,7 +157,7 @@ static const char* tree_open(r0h_ctx* ctx, Scope& sc, const Tree& t, const r0h_b
 
 // ------------------------------------------------------------------ poly groups
 struct Group {
-  r0h_buf* coeffs = nullptr;     // natural order once finished
+  r0h_buf* coeffs = nullptr;     // bit-reversed, zk-shifted coefficients
   r0h_buf* evaluated = nullptr;  // [count][4N]
   uint32_t count = 0;
   Tree tree;
@@ -167,7 +167,8 @@ struct Group {
 static const char* group_finish(r0h_ctx* ctx, Scope& sc, Group& g, uint32_t po2) {
   R0H_TRY(sc.alloc(ctx, ((size_t)g.count << (po2 + 2)) * 4, &g.evaluated));
   R0H_TRY(r0h_batch_expand_into_evaluate_ntt(ctx, g.evaluated, g.coeffs, g.count, po2, 2));
-  R0H_TRY(r0h_batch_bit_reverse(ctx, g.coeffs, g.count, po2));
+  // upstream flips the coefficients to natural order here; the sequencer keeps them bit-reversed instead (evaluate-at-z
+  // uses permuted power tables, the FRI mix is order-agnostic) and flips only the handful of mixed combos
   return tree_build(ctx, sc, g.tree, g.evaluated);
 }
 static const char* group_from_witness(r0h_ctx* ctx, Scope& sc, Group& g, const r0h_buf* witness, uint32_t po2) {
@@ -289,13 +290,13 @@ static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, co
     r0h_buf view = *d_eval;
     view.ptr = (char*)d_eval->ptr + (size_t)b * 16;
     view.bytes = (size_t)(e - b) * 16;
-    R0H_TRY(r0h_batch_evaluate_any(ctx, grp[g]->coeffs, po2, which.data() + b, (const uint32_t*)(all_xs.data() + b), e - b, &view));
+    R0H_TRY(evaluate_any(ctx, grp[g]->coeffs, po2, which.data() + b, (const uint32_t*)(all_xs.data() + b), e - b, &view, true));
   }
   {
     r0h_buf view = *d_eval;
     view.ptr = (char*)d_eval->ptr + (size_t)cv.n_taps * 16;
     view.bytes = (size_t)R0H_CHECK_SIZE * 16;
-    R0H_TRY(r0h_batch_evaluate_any(ctx, g_check.coeffs, po2, which.data() + cv.n_taps, (const uint32_t*)(all_xs.data() + cv.n_taps), R0H_CHECK_SIZE, &view));
+    R0H_TRY(evaluate_any(ctx, g_check.coeffs, po2, which.data() + cv.n_taps, (const uint32_t*)(all_xs.data() + cv.n_taps), R0H_CHECK_SIZE, &view, true));
   }
   std::vector<Fp4> eval_u(n_u);
   R0H_TRY(r0h_buf_d2h(ctx, d_eval, 0, eval_u.data(), (size_t)n_u * 16));
@@ -331,6 +332,7 @@ static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, co
     for (int i = 0; i < R0H_CHECK_SIZE; i++) combo_of[i] = n_combos;
     R0H_TRY(r0h_mix_poly_coeffs(ctx, combos, cur.e, mixv.e, g_check.coeffs, combo_of, R0H_CHECK_SIZE, po2));
   }
+  R0H_TRY(bit_reverse_ext(ctx, combos, n_combos + 1, po2));  // combos were mixed in bit-reversed order: natural from here on
   // subtract the interpolants: only the first few coefficients of each combo change
   {
     std::vector<Fp4> head((size_t)(n_combos + 1) * 64, fp4_zero());
