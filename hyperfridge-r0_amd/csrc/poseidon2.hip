@@ -122,6 +122,48 @@ __global__ __launch_bounds__(256) void hash_fold_kernel(uint32_t* __restrict__ n
   dst[1] = make_uint4(c[4], c[5], c[6], c[7]);
 }
 
+// Upper Merkle levels have fewer parents than the chip has lanes: one permutation per lane then takes a full
+// single-wave latency (~26 us) per level, 17 levels per tree.  This variant spreads ONE permutation over 24 lanes of a
+// 32-lane half-wave (one state cell per lane): S-boxes run in parallel, the external layer exchanges within quads and
+// across the six quads by shuffles, the internal layer is a 5-step shuffle all-reduce.  Latency per level drops ~7x.
+__device__ __forceinline__ uint32_t half_shfl(uint32_t v, uint32_t src_in_half) {
+  return __shfl(v, (int)((threadIdx.x & 32u) | src_in_half), 64);
+}
+__device__ __forceinline__ uint32_t m_ext_lanes(uint32_t x, uint32_t l) {
+  const uint32_t q = l & ~3u;
+  uint32_t a = half_shfl(x, q), b = half_shfl(x, q | 1), d = half_shfl(x, q | 2), e = half_shfl(x, q | 3);
+  uint32_t t0 = add(a, b), t1 = add(d, e);
+  uint32_t t2 = add(add(b, b), t1), t3 = add(add(e, e), t0);
+  uint32_t t1x2 = add(t1, t1), t0x2 = add(t0, t0);
+  uint32_t t4 = add(add(t1x2, t1x2), t3), t5 = add(add(t0x2, t0x2), t2);
+  uint32_t t6 = add(t3, t5), t7 = add(t2, t4);
+  const uint32_t j = l & 3u;
+  uint32_t y = j == 0 ? t6 : (j == 1 ? t5 : (j == 2 ? t7 : t4));
+  // column sums over the six quads: pair neighbours, then add the two other pairs (lanes 24..31 carry don't-cares)
+  uint32_t t = add(y, half_shfl(y, l ^ 4u));
+  uint32_t s = add(t, add(half_shfl(t, (l + 8u) % 24u), half_shfl(t, (l + 16u) % 24u)));
+  return add(y, s);
+}
+__global__ __launch_bounds__(256) void hash_fold_lanes_kernel(uint32_t* __restrict__ nodes, uint32_t output_size,
+                                                               const P2Consts* __restrict__ k) {
+  const uint32_t l = threadIdx.x & 31u, slot = (blockIdx.x * 256 + threadIdx.x) >> 5;  // one permutation per 32 lanes
+  const bool live = slot < output_size, cell = l < 24u;
+  const uint32_t node = output_size + (live ? slot : 0u), li = cell ? l : 0u;
+  uint32_t c = (live && l < 16u) ? nodes[(size_t)2 * node * 8 + l] : 0u;
+  const uint32_t dg = k->diag_canon[li], ds = k->diag_shoup[li];
+  c = m_ext_lanes(c, l);
+  for (int r = 0; r < P2_HALF_FULL; r++) c = m_ext_lanes(sbox7(add(c, k->rc_full[r][li])), l);
+  for (int r = 0; r < P2_PARTIAL; r++) {
+    if (l == 0) c = sbox7(add(c, k->rc_partial[r]));
+    uint32_t sum = cell ? c : 0u;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) sum = add(sum, half_shfl(sum, l ^ (uint32_t)off));
+    c = add(sum, mul_const(c, dg, ds));
+  }
+  for (int r = P2_HALF_FULL; r < 2 * P2_HALF_FULL; r++) c = m_ext_lanes(sbox7(add(c, k->rc_full[r][li])), l);
+  if (live && l < 8u) nodes[(size_t)node * 8 + l] = c;
+}
+
 }  // namespace r0h
 
 using namespace r0h;
@@ -150,6 +192,12 @@ const char* r0h_hash_fold(r0h_ctx* ctx, r0h_buf* nodes, uint32_t output_size) {
   R0H_REQUIRE(((uintptr_t)nodes->ptr & 15) == 0, "r0h_hash_fold: node buffer must be 16-byte aligned");
   if (!output_size) return nullptr;
   KScope ks(ctx, "hash_fold_kernel", (double)output_size * 96);
+  if (output_size <= 1024) {  // far fewer parents than lanes (32x the instructions per permutation, ~7x less latency): spread each permutation over 24 lanes (latency, not throughput)
+    hipLaunchKernelGGL(hash_fold_lanes_kernel, dim3((output_size * 32 + 255) / 256), dim3(256), 0, ctx->stream, u32(nodes), output_size, ctx->p2);
+    hipError_t e = hipGetLastError();
+    R0H_REQUIRE(e == hipSuccess, "hash_fold_lanes_kernel: %s", hipGetErrorString(e));
+    return nullptr;
+  }
   hipLaunchKernelGGL(hash_fold_kernel, dim3((output_size + 255) / 256), dim3(256), 0, ctx->stream, u32(nodes), output_size, ctx->p2);
   hipError_t e = hipGetLastError();
   R0H_REQUIRE(e == hipSuccess, "hash_fold_kernel: %s", hipGetErrorString(e));
