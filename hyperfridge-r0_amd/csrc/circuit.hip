@@ -41,7 +41,8 @@ static const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words)
         break;
       }
       case R0H_SEC_GLOBALS:
-        R0H_REQUIRE(len >= 2 && len == 2 + (size_t)p[0], "circuit blob: GLOBALS length mismatch");
+        R0H_REQUIRE(len >= 2 && (len == 2 + (size_t)p[0] || len == 2), "circuit blob: GLOBALS length mismatch");
+        if (len == 2) { c->n_global = p[0]; c->n_mix = p[1]; c->global_cols.assign(p[0], 0); break; }
         c->n_global = p[0]; c->n_mix = p[1];
         c->global_cols.assign(p + 2, p + 2 + p[0]);
         break;
@@ -74,10 +75,14 @@ static const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words)
     }
     pos += 2 + len;
   }
-  for (int t = 1; t <= 6; t++) R0H_REQUIRE(seen[t], "circuit blob: section %d missing", t);
-  R0H_REQUIRE(c->code_cols.size() == c->group_size[R0H_GROUP_CODE] && c->data_cols.size() == c->group_size[R0H_GROUP_DATA] &&
-                  4 * c->acc_cols.size() == c->group_size[R0H_GROUP_ACCUM] && c->n_mix == 8 * c->acc_cols.size(),
-              "circuit blob: group sizes disagree with the column programs");
+  for (int t = 1; t <= 4; t++) R0H_REQUIRE(seen[t], "circuit blob: section %d missing", t);
+  // WITGEN + ACCUM (the synthetic column program) are optional: a circuit imported from risc0 brings its own witness
+  c->has_column_program = seen[R0H_SEC_WITGEN] && seen[R0H_SEC_ACCUM];
+  R0H_REQUIRE(seen[R0H_SEC_WITGEN] == seen[R0H_SEC_ACCUM], "circuit blob: WITGEN and ACCUM sections must come together");
+  if (c->has_column_program)
+    R0H_REQUIRE(c->code_cols.size() == c->group_size[R0H_GROUP_CODE] && c->data_cols.size() == c->group_size[R0H_GROUP_DATA] &&
+                    4 * c->acc_cols.size() == c->group_size[R0H_GROUP_ACCUM] && c->n_mix == 8 * c->acc_cols.size(),
+                "circuit blob: group sizes disagree with the column programs");
   // taps: sorted, in range, every column owns back 0
   std::vector<std::vector<bool>> has0(3);
   for (int g = 0; g < 3; g++) has0[g].assign(c->group_size[g], false);
@@ -139,7 +144,8 @@ static const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words)
     }
   }
   R0H_REQUIRE(c->ret < c->mix_step.size(), "circuit blob: ret is not a mix variable");
-  for (uint32_t k = 0; k < c->n_global; k++) R0H_REQUIRE(c->global_cols[k] < c->data_cols.size(), "circuit blob: global column out of range");
+  for (uint32_t k = 0; k < c->n_global && c->has_column_program; k++)
+    R0H_REQUIRE(c->global_cols[k] < c->data_cols.size(), "circuit blob: global column out of range");
   for (size_t k = 0; k < c->data_cols.size(); k++) {
     const DataCol& d = c->data_cols[k];
     R0H_REQUIRE(d.kind <= 2, "witgen: data column %zu has unknown kind", k);
@@ -521,6 +527,7 @@ uint32_t r0h_circuit_n_taps(const r0h_circuit* c) { return c ? (uint32_t)c->taps
 const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, r0h_buf* code, r0h_buf* data, uint32_t* global_out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && c && code && data, "r0h_witgen: NULL argument");
+  R0H_REQUIRE(c->has_column_program, "r0h_witgen: this circuit carries no synthetic column program (WITGEN/ACCUM sections); supply the witness");
   R0H_REQUIRE(po2 >= 4 && po2 <= R0H_MAX_PO2, "r0h_witgen: po2 %u outside [4, %u]", po2, R0H_MAX_PO2);
   const uint32_t n = 1u << po2, threads = n < 256 ? n : 256, nc = (uint32_t)c->code_cols.size(), nd = (uint32_t)c->data_cols.size();
   R0H_REQUIRE(((size_t)nc << po2) * 4 <= code->bytes && ((size_t)nd << po2) * 4 <= data->bytes, "r0h_witgen: buffers too small for 2^%u rows", po2);
@@ -556,6 +563,7 @@ const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0
   R0H_GUARD_BEGIN
   (void)code;
   R0H_REQUIRE(ctx && c && data && accum && (mix || c->n_mix == 0), "r0h_accum: NULL argument");
+  R0H_REQUIRE(c->has_column_program, "r0h_accum: this circuit carries no synthetic column program (WITGEN/ACCUM sections)");
   R0H_REQUIRE(po2 >= 4 && po2 <= R0H_MAX_PO2, "r0h_accum: po2 %u outside [4, %u]", po2, R0H_MAX_PO2);
   const uint32_t n = 1u << po2, threads = n < 256 ? n : 256;
   R0H_REQUIRE(((size_t)c->data_cols.size() << po2) * 4 <= data->bytes && ((size_t)c->group_size[R0H_GROUP_ACCUM] << po2) * 4 <= accum->bytes,

@@ -35,6 +35,7 @@ struct r0h_circuit {
   std::vector<r0h::CodeCol> code_cols;
   std::vector<r0h::DataCol> data_cols;
   std::vector<r0h::AccCol> acc_cols;
+  bool has_column_program = false;  // WITGEN + ACCUM present (synthetic circuits); imported circuits bring their own witness
   std::vector<uint32_t> blob;
   uint8_t info[16] = {'R', '0', 'H', 'I', 'P', '_', 'S', 'Y', 'N', 'T', 'H', ':', 'v', '1', '_', '_'};  // circuit ProtocolInfo tag
   r0h::Plan plan;

@@ -473,6 +473,7 @@ const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, 
   R0H_REQUIRE(ctx && c && code && data && seal_words_out, "r0h_prove_segment: NULL argument");
   R0H_REQUIRE(global || r0h_circuit_n_global(c) == 0, "r0h_prove_segment: global is NULL");
   R0H_REQUIRE(po2 >= 9 && po2 <= R0H_MAX_PO2, "r0h_prove_segment: po2 %u outside [9, %u]", po2, R0H_MAX_PO2);
+  R0H_REQUIRE(c->has_column_program, "r0h_prove_segment: the circuit has no accumulation program; drive the per-op entry points with your own accum step");
   R0H_TRY_HIP(hipSetDevice(ctx->device));
   std::vector<uint32_t> seal;
   R0H_TRY(prove(ctx, c, po2, code, data, global, seal));

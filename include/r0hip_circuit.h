@@ -10,13 +10,13 @@
  *   GROUPS  (1): size of tap groups ACCUM(0), CODE(1), DATA(2) in columns
  *   TAPS    (2): n_taps, then (group, offset, back) sorted ascending; a register = all taps of one (group, offset);
  *                every column must own a tap with back 0; combos (distinct back lists) are derived on load
- *   GLOBALS (3): n_global, n_mix, then n_global DATA column indices (global k = that column at row 0)
+ *   GLOBALS (3): n_global, n_mix, then (synthetic circuits only) n_global DATA column indices (global k = that column at row 0)
  *   POLY    (4): n_steps, ret (mix var), then (op, a, b, c):
  *                  0 CONST a=canonical value      2 GET a=tap index       3 GET_GLOBAL a=0 global | 1 mix, b=offset
  *                  4 ADD / 5 SUB / 6 MUL a,b=fp vars                      7 TRUE
  *                  8 AND_EQZ a=mix var, b=fp var                          9 AND_COND a=mix var, b=fp var, c=inner mix var
  *                fp vars and mix vars are numbered separately in creation order (risc0-zkp adapter.rs PolyExtStep)
- *   WITGEN  (5): n_code, (kind, param) per CODE column: 0 first-row flag, 1 last-row flag, 2 row counter, 3 fixed random;
+ *   WITGEN  (5): [optional, with ACCUM: the synthetic column program; circuits imported from risc0 omit both] n_code, (kind, param) per CODE column: 0 first-row flag, 1 last-row flag, 2 row counter, 3 fixed random;
  *                n_data, (kind, a, b, c, e) per DATA column: 0 seeded random, 1 a*b+e, 2 a*b*c+e with refs
  *                ref = group<<28 | back<<20 | column (group 1 or 2; DATA refs point at lower-numbered columns)
  *   INFO    (7): optional, 4 words = the circuit's 16-byte ProtocolInfo tag committed into the transcript (risc0 `CIRCUIT_INFO`)

@@ -83,8 +83,8 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
         break;
       case SEC_GLOBALS:
         c->n_global = p[0]; c->n_mix = p[1];
-        c->global_cols = (uint32_t*)malloc(4 * (c->n_global ? c->n_global : 1));
-        memcpy(c->global_cols, p + 2, 4 * c->n_global);
+        c->global_cols = (uint32_t*)calloc(c->n_global ? c->n_global : 1, 4);
+        if (len >= 2 + c->n_global) memcpy(c->global_cols, p + 2, 4 * c->n_global);
         break;
       case SEC_POLY:
         c->n_steps = p[0]; c->ret = p[1];
@@ -118,8 +118,10 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
     if (op == OP_TRUE || op == OP_AND_EQZ || op == OP_AND_COND) c->n_mix_vars++;
     else c->n_fp_vars++;
   }
-  if (c->n_code != c->group_size[ORC_GROUP_CODE] || c->n_data != c->group_size[ORC_GROUP_DATA] ||
-      4 * c->n_acc != c->group_size[ORC_GROUP_ACCUM] || c->n_mix != 8 * c->n_acc)
+  /* WITGEN/ACCUM (the synthetic column program) are optional: circuits imported from risc0 tables omit both */
+  if ((c->code_cols || c->acc_cols) &&
+      (c->n_code != c->group_size[ORC_GROUP_CODE] || c->n_data != c->group_size[ORC_GROUP_DATA] ||
+       4 * c->n_acc != c->group_size[ORC_GROUP_ACCUM] || c->n_mix != 8 * c->n_acc))
     goto bad;
   derive_regs_and_combos(c);
   return c;
