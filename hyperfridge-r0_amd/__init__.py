@@ -70,6 +70,9 @@ _SIGNATURES = {
     "r0h_accum": [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
     "r0h_eval_check": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "r0h_prove_segment": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)],
+    "r0h_proof_begin": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _pp],
+    "r0h_proof_finish": [_vp, _vp, _vp, _sz, _c.POINTER(_sz)],
+    "r0h_proof_abort": [_vp],
     "r0h_kernel_timing": [_vp, _c.c_int],
     "r0h_kernel_stats": [_vp, _vp, _sz],
     "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],
@@ -335,6 +338,23 @@ class Hal:
         _check(lib().r0h_prove_segment(self.ctx, circuit.handle, po2, code.handle, data.handle, pg,
                                        seal.ctypes.data_as(_vp), seal.size, ctypes.byref(n)))
         return seal[:n.value].copy()
+
+    def proof_begin(self, circuit, po2, code, data, glob):
+        """Commit CODE and DATA; returns (proof handle, accumulation mix words)."""
+        g, pg = _u32arr(glob)
+        mix = np.zeros(max(circuit.n_mix, 1), dtype=np.uint32)
+        h = _vp()
+        _check(lib().r0h_proof_begin(self.ctx, circuit.handle, po2, code.handle, data.handle, pg, mix.ctypes.data_as(_vp), ctypes.byref(h)))
+        return h, mix[:circuit.n_mix]
+
+    def proof_finish(self, proof, accum, seal_capacity_words=1 << 20):
+        seal = np.empty(seal_capacity_words, dtype=np.uint32)
+        n = _sz(0)
+        _check(lib().r0h_proof_finish(proof, accum.handle, seal.ctypes.data_as(_vp), seal.size, ctypes.byref(n)))
+        return seal[:n.value].copy()
+
+    def proof_abort(self, proof):
+        _check(lib().r0h_proof_abort(proof))
 
     def kernel_timing(self, enable=True):
         _check(lib().r0h_kernel_timing(self.ctx, 1 if enable else 0))

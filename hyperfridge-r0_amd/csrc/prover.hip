@@ -209,14 +209,37 @@ __global__ void sub_head_kernel(uint32_t* __restrict__ combos, const uint32_t* _
   if (k < n) combos[fix[2 * k]] = sub(combos[fix[2 * k]], fix[2 * k + 1]);
 }
 
-static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
-                         const uint32_t* global, std::vector<uint32_t>& seal) {
-  CircuitView cv;
-  circuit_view(circ, &cv);
-  const size_t n = (size_t)1 << po2, domain = n * R0H_INV_RATE;
-  Scope sc;
+}  // namespace r0h
+
+// A proof in flight between r0h_proof_begin (CODE and DATA committed, accumulation mix drawn) and r0h_proof_finish.
+// Mirrors risc0-zkp's `Prover` object between `commit_group(DATA)` and `finalize`.
+struct r0h_proof {
+  r0h_ctx* ctx;
+  const r0h_circuit* circ;
+  uint32_t po2;
+  r0h::CircuitView cv;
+  r0h::Scope sc;
+  r0h::WriteIop io;
+  r0h::Group g_accum, g_code, g_data, g_check;
+  std::vector<uint32_t> mix, global;
+  r0h_proof(r0h_ctx* c, const r0h_circuit* ci, uint32_t p, const r0h::CircuitView& v)
+      : ctx(c), circ(ci), po2(p), cv(v), io(&c->p2_host), g_accum(v.group_size[R0H_GROUP_ACCUM], (size_t)4 << p),
+        g_code(v.group_size[R0H_GROUP_CODE], (size_t)4 << p), g_data(v.group_size[R0H_GROUP_DATA], (size_t)4 << p),
+        g_check(R0H_CHECK_SIZE, (size_t)4 << p) {}
+};
+
+namespace r0h {
+
+static const char* proof_begin(r0h_proof& st, const r0h_buf* code, const r0h_buf* data, const uint32_t* global) {
+  r0h_ctx* ctx = st.ctx;
+  const r0h_circuit* circ = st.circ;
+  const uint32_t po2 = st.po2;
+  CircuitView& cv = st.cv;
+  Scope& sc = st.sc;
+  WriteIop& io = st.io;
+  Group &g_code = st.g_code, &g_data = st.g_data;
   ctx->prof.names.clear();
-  WriteIop io(&ctx->p2_host);
+  st.global.assign(global, global + cv.n_global);
 
   phase(ctx, "transcript_seed");
   {
@@ -238,9 +261,7 @@ static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, co
     io.write(gv.data(), gv.size());
   }
 
-  Group g_accum(cv.group_size[R0H_GROUP_ACCUM], domain), g_code(cv.group_size[R0H_GROUP_CODE], domain),
-      g_data(cv.group_size[R0H_GROUP_DATA], domain), g_check(R0H_CHECK_SIZE, domain);
-  Group* grp[3] = {&g_accum, &g_code, &g_data};
+
 
   phase(ctx, "commit_code");
   R0H_TRY(group_from_witness(ctx, sc, g_code, code, po2));
@@ -249,17 +270,26 @@ static const char* prove(r0h_ctx* ctx, const r0h_circuit* circ, uint32_t po2, co
   R0H_TRY(group_from_witness(ctx, sc, g_data, data, po2));
   R0H_TRY(tree_commit(ctx, g_data.tree, io));
 
+  st.mix.resize(cv.n_mix);
+  for (uint32_t i = 0; i < cv.n_mix; i++) st.mix[i] = io.rng.elem();
   phase(ctx, "accum");
-  std::vector<uint32_t> mix(cv.n_mix);
-  for (uint32_t i = 0; i < cv.n_mix; i++) mix[i] = io.rng.elem();
-  {
-    r0h_buf* accum = nullptr;
-    R0H_TRY(sc.alloc(ctx, ((size_t)g_accum.count << po2) * 4, &accum));
-    R0H_TRY(r0h_accum(ctx, circ, po2, code, data, mix.data(), accum));
-    phase(ctx, "commit_accum");
-    R0H_TRY(group_from_witness(ctx, sc, g_accum, accum, po2));
-    sc.release(accum);
-  }
+  return nullptr;
+}
+
+static const char* proof_finish(r0h_proof& st, const r0h_buf* accum, std::vector<uint32_t>& seal) {
+  r0h_ctx* ctx = st.ctx;
+  const r0h_circuit* circ = st.circ;
+  const uint32_t po2 = st.po2;
+  const size_t n = (size_t)1 << po2, domain = n * R0H_INV_RATE;
+  CircuitView& cv = st.cv;
+  Scope& sc = st.sc;
+  WriteIop& io = st.io;
+  Group &g_accum = st.g_accum, &g_code = st.g_code, &g_data = st.g_data, &g_check = st.g_check;
+  Group* grp[3] = {&g_accum, &g_code, &g_data};
+  const std::vector<uint32_t>& mix = st.mix;
+  const uint32_t* global = st.global.data();
+  phase(ctx, "commit_accum");
+  R0H_TRY(group_from_witness(ctx, sc, g_accum, accum, po2));
   R0H_TRY(tree_commit(ctx, g_accum.tree, io));
 
   phase(ctx, "eval_check");
@@ -476,12 +506,59 @@ const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, 
   R0H_REQUIRE(c->has_column_program, "r0h_prove_segment: the circuit has no accumulation program; drive the per-op entry points with your own accum step");
   R0H_TRY_HIP(hipSetDevice(ctx->device));
   std::vector<uint32_t> seal;
-  R0H_TRY(prove(ctx, c, po2, code, data, global, seal));
+  {
+    CircuitView cv;
+    circuit_view(c, &cv);
+    r0h_proof st(ctx, c, po2, cv);
+    R0H_TRY(proof_begin(st, code, data, global));
+    r0h_buf* accum = nullptr;
+    R0H_TRY(st.sc.alloc(ctx, ((size_t)cv.group_size[R0H_GROUP_ACCUM] << po2) * 4, &accum));
+    R0H_TRY(r0h_accum(ctx, c, po2, code, data, st.mix.data(), accum));
+    R0H_TRY(proof_finish(st, accum, seal));
+  }
   *seal_words_out = seal.size();
   R0H_REQUIRE(seal.size() <= seal_cap || !seal_out, "r0h_prove_segment: seal needs %zu words, capacity is %zu", seal.size(), seal_cap);
   if (seal_out) memcpy(seal_out, seal.data(), seal.size() * 4);
   return nullptr;
   R0H_GUARD_END
+}
+
+const char* r0h_proof_begin(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
+                            const uint32_t* global, uint32_t* mix_out, r0h_proof** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && c && code && data && out, "r0h_proof_begin: NULL argument");
+  R0H_REQUIRE((global || r0h_circuit_n_global(c) == 0) && (mix_out || r0h_circuit_n_mix(c) == 0), "r0h_proof_begin: NULL globals / mix_out");
+  R0H_REQUIRE(po2 >= 9 && po2 <= R0H_MAX_PO2, "r0h_proof_begin: po2 %u outside [9, %u]", po2, R0H_MAX_PO2);
+  R0H_TRY_HIP(hipSetDevice(ctx->device));
+  CircuitView cv;
+  circuit_view(c, &cv);
+  r0h_proof* st = new r0h_proof(ctx, c, po2, cv);
+  const char* err = proof_begin(*st, code, data, global);
+  if (err) { delete st; return err; }
+  if (cv.n_mix) memcpy(mix_out, st->mix.data(), (size_t)cv.n_mix * 4);
+  *out = st;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_proof_finish(r0h_proof* proof, const r0h_buf* accum, uint32_t* seal_out, size_t seal_cap, size_t* seal_words_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(proof && accum && seal_words_out, "r0h_proof_finish: NULL argument");
+  R0H_TRY_HIP(hipSetDevice(proof->ctx->device));
+  std::vector<uint32_t> seal;
+  const char* err = proof_finish(*proof, accum, seal);
+  delete proof;  // consumed either way
+  if (err) return err;
+  *seal_words_out = seal.size();
+  R0H_REQUIRE(seal.size() <= seal_cap || !seal_out, "r0h_proof_finish: seal needs %zu words, capacity is %zu", seal.size(), seal_cap);
+  if (seal_out) memcpy(seal_out, seal.data(), seal.size() * 4);
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_proof_abort(r0h_proof* proof) {
+  delete proof;
+  return nullptr;
 }
 
 const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out) {

@@ -128,6 +128,17 @@ const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, con
 const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code,
                               const r0h_buf* data, const uint32_t* global_host, uint32_t* seal_out,
                               size_t seal_capacity_words, size_t* seal_words_out);
+/* The same sequencer split around the accumulation step, as risc0-zkp's `Prover` is used by the segment driver
+ * (commit_group(CODE), commit_group(DATA), draw the mix -> caller accumulates -> commit_group(ACCUM), finalize):
+ * r0h_proof_begin commits CODE and DATA and returns the n_mix accumulation-mix words; the caller fills the ACCUM witness
+ * ([group_size(ACCUM)][2^po2], e.g. with its own step_accum or r0h_accum) and hands it to r0h_proof_finish, which consumes
+ * the proof object.  r0h_prove_segment == begin + r0h_accum + finish. */
+typedef struct r0h_proof r0h_proof;
+const char* r0h_proof_begin(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
+                            const uint32_t* global_host, uint32_t* mix_out, r0h_proof** out);
+const char* r0h_proof_finish(r0h_proof* proof, const r0h_buf* accum, uint32_t* seal_out, size_t seal_capacity_words,
+                             size_t* seal_words_out);
+const char* r0h_proof_abort(r0h_proof* proof);
 /* Per-phase device time of the last r0h_prove_segment on this context (ms), for bench.py; names are static strings. */
 const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out);
 

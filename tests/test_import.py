@@ -86,3 +86,31 @@ def test_imported_circuit_runs_eval_check_on_the_device_and_refuses_synthetic_st
     code, data = hal.alloc(oc.group_size[1] << po2), hal.alloc(oc.group_size[2] << po2)
     with pytest.raises(r0.R0HipError):
         hal.prove_segment(gc, po2, code, data, glob)
+
+
+@pytest.mark.gpu
+def test_split_sequencer_with_caller_supplied_accumulation(tmp_path, hal, orc):
+    """r0h_proof_begin / r0h_proof_finish: the caller owns the accumulation step (as risc0's segment driver does).  With the
+    caller computing the same accumulators the seal equals r0h_prove_segment's; and an imported circuit (no column
+    program in the blob) proves through this path with witness + accumulators supplied from outside."""
+    blob = np.fromfile(circuit_path("small"), dtype=np.uint32)
+    gc, oc = hal.load_circuit(blob), orc.circuit(blob)
+    po2 = 11
+    code, data, glob = hal.witgen(gc, po2, 31)
+    whole = hal.prove_segment(gc, po2, code, data, glob)
+    proof, mix = hal.proof_begin(gc, po2, code, data, glob)
+    accum_host = oc.accum(po2, code.to_host(), data.to_host(), mix)   # "caller's own step_accum": here the oracle's
+    seal = hal.proof_finish(proof, hal.copy_from(accum_host))
+    assert np.array_equal(seal, whole) and oc.verify(seal) == (0, "ok")
+    # abandoned proofs release their buffers
+    proof2, _ = hal.proof_begin(gc, po2, code, data, glob)
+    hal.proof_abort(proof2)
+    # imported circuit: same taps / program / info tag, but the blob carries no WITGEN/ACCUM
+    subprocess.check_call([sys.executable, TOOL, "--emit-rust", circuit_path("small"), str(tmp_path)])
+    out = tmp_path / "imported.r0c"
+    subprocess.check_call([sys.executable, TOOL, str(tmp_path / "taps.rs"), str(tmp_path / "poly_ext.rs"), str(out), "--info", "R0HIP_SYNTH:v1__"])
+    ic = hal.load_circuit(np.fromfile(out, dtype=np.uint32))
+    proof3, mix3 = hal.proof_begin(ic, po2, code, data, glob)
+    assert np.array_equal(mix3, mix)  # same transcript so far
+    seal3 = hal.proof_finish(proof3, hal.copy_from(accum_host))
+    assert np.array_equal(seal3, whole)
