@@ -342,3 +342,66 @@ def test_two_contexts_prove_concurrently_and_agree(orc):
         for obj in (ln[2], ln[3], ln[1]):
             obj.free()
         ln[0].close()
+
+
+def _extreme(rng, n):
+    """Words drawn from the corners of [0, p): the lazy-reduction bounds of the kernels are worst at p-1."""
+    pool = np.array([0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 2**31 - 2**27, 0x0FFFFFFF, 0x70000000], dtype=np.uint32)
+    return pool[rng.integers(0, pool.size, size=n)]
+
+
+def test_extreme_field_values_through_every_arithmetic_kernel(hal, orc):
+    rng = np.random.default_rng(4242)
+    # Poseidon2: lane-per-row, lane-per-parent and the 24-lane cross-lane variant
+    for rows, cols in ((512, 40), (4096, 16)):
+        m = _extreme(rng, rows * cols)
+        m[:rows] = P - 1  # a whole column at p-1
+        dig = hal.alloc(rows * 8)
+        hal.hash_rows(dig, hal.copy_from(m), rows, cols)
+        assert np.array_equal(dig.to_host(), orc.hash_rows(m, rows, cols))
+    for out_size in (1, 8, 1024, 2048, 8192):
+        lvl = _extreme(rng, out_size * 4 * 8)
+        nb = hal.copy_from(lvl)
+        hal.hash_fold(nb, out_size)
+        assert np.array_equal(nb.to_host(), orc.hash_fold(lvl, out_size))
+    # NTTs (radix-16 and radix-2 routes), zk shift, bit reversal
+    for po2, cols in ((10, 3), (13, 2), (17, 2)):
+        x = _extreme(rng, cols << po2)
+        buf = hal.copy_from(x)
+        hal.batch_interpolate_ntt(buf, cols, po2)
+        want = orc.batch_interpolate_ntt(x, cols, po2)
+        assert np.array_equal(buf.to_host(), want)
+        hal.zk_shift(buf, cols, po2)
+        assert np.array_equal(buf.to_host(), orc.zk_shift(want, cols, po2))
+        out = hal.alloc(cols << (po2 + 2))
+        hal.batch_expand_into_evaluate_ntt(out, hal.copy_from(x), cols, po2, 2)
+        assert np.array_equal(out.to_host(), orc.batch_expand_into_evaluate_ntt(x, cols, po2, 2))
+    # extension-field streams with extreme operands (lazy 64-bit sums)
+    n_out = 256
+    inp, mix = _extreme(rng, 4 * 16 * n_out), np.array([P - 1] * 4, np.uint32)
+    o = hal.alloc(4 * n_out)
+    hal.fri_fold(o, hal.copy_from(inp), mix, n_out)
+    assert np.array_equal(o.to_host(), orc.fri_fold(inp, mix, n_out))
+    coeffs = _extreme(rng, 4 << 12)
+    which, xs = np.array([0, 1, 2, 3], np.uint32), np.tile(np.array([P - 1, P - 1, P - 1, P - 1], np.uint32), 4)
+    ev = hal.alloc(16)
+    hal.batch_evaluate_any(hal.copy_from(coeffs), 12, which, xs, ev)
+    assert np.array_equal(ev.to_host(), orc.batch_evaluate_any(coeffs, 12, which, xs))
+    v = _extreme(rng, 4 * 8192)
+    b = hal.copy_from(v)
+    hal.prefix_products(b, 8192)
+    assert np.array_equal(b.to_host(), orc.prefix_products(v, 8192))
+    b = hal.copy_from(v)
+    z = np.array([P - 1, P - 2, 1, 0], np.uint32)
+    rem = hal.poly_divide(b, 8192, z)
+    q, wr = orc.poly_divide(v, 8192, z)
+    assert np.array_equal(rem, wr) and np.array_equal(b.to_host(), q)
+    # constraint evaluation (generated code: lazy term sums) on extreme taps, globals and mixes
+    blob = np.fromfile(circuit_path("small"), dtype=np.uint32)
+    oc, gc = orc.circuit(blob), hal.load_circuit(blob)
+    po2 = 9
+    dom = 4 << po2
+    ea, ec, ed = (_extreme(rng, oc.group_size[g] * dom) for g in range(3))
+    glob, mixw, pm = _extreme(rng, oc.n_global), _extreme(rng, oc.n_mix), np.array([P - 1, P - 1, P - 1, P - 1], np.uint32)
+    check = hal.eval_check(gc, po2, hal.copy_from(ea), hal.copy_from(ec), hal.copy_from(ed), glob, mixw, pm)
+    assert np.array_equal(check.to_host(), oc.eval_check(po2, ea, ec, ed, glob, mixw, pm))
