@@ -73,6 +73,7 @@ _SIGNATURES = {
     "r0h_proof_begin": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _pp],
     "r0h_proof_finish": [_vp, _vp, _vp, _sz, _c.POINTER(_sz)],
     "r0h_proof_abort": [_vp],
+    "r0h_verify_seal": [_vp, _sz, _vp, _vp, _vp, _sz, _c.POINTER(_c.c_int), _c.POINTER(_u32)],
     "r0h_kernel_timing": [_vp, _c.c_int],
     "r0h_kernel_stats": [_vp, _vp, _sz],
     "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],
@@ -80,6 +81,7 @@ _SIGNATURES = {
 _PLAIN = {
     "r0h_free_error": ([_vp], None),
     "r0h_version": ([], _cp),
+    "r0h_verify_reason": ([_c.c_int], _cp),
     "r0h_buf_device_ptr": ([_vp], _vp),
     "r0h_buf_bytes": ([_vp], _sz),
     "r0h_circuit_group_size": ([_vp, _u32], _u32),
@@ -189,6 +191,23 @@ def emit_eval_check_source(blob):
     src = out.value.decode()
     lib().r0h_free_error(ctypes.cast(out, _vp))
     return src
+
+
+def verify_seal(blob, seal, poseidon2_consts=None):
+    """Host-side check of a seal against a circuit blob (r0h_verify_seal; needs no GPU): returns (verdict, reason, po2),
+    verdict 0 = accepted.  poseidon2_consts = (round_constants[29*24], diag_m1[24]) canonical words, or None for the
+    compiled-in table.  Mirrors `receipt.verify(image_id)` (verifier/src/main.rs:124-126)."""
+    b, pb = _u32arr(blob)
+    s_, ps = _u32arr(seal)
+    prc = pdg = None
+    if poseidon2_consts is not None:
+        rc, prc = _u32arr(poseidon2_consts[0])
+        dg, pdg = _u32arr(poseidon2_consts[1])
+        if rc.size != 29 * 24 or dg.size != 24:
+            raise R0HipError("verify_seal: Poseidon2 tables must hold 29*24 and 24 words")
+    verdict, po2 = _c.c_int(-1), _u32(0)
+    _check(lib().r0h_verify_seal(pb, b.size, prc, pdg, ps, s_.size, ctypes.byref(verdict), ctypes.byref(po2)))
+    return verdict.value, lib().r0h_verify_reason(verdict.value).decode(), po2.value
 
 
 class Hal:

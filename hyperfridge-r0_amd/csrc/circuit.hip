@@ -19,7 +19,7 @@
 
 namespace r0h {
 
-static const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
+const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
   R0H_REQUIRE(n_words >= 3 && w[0] == R0H_BLOB_MAGIC && w[1] == 1, "circuit blob: bad magic or version");
   size_t pos = 3;
   bool seen[8] = {false};

@@ -44,3 +44,7 @@ struct r0h_circuit {
   uint32_t* d_params = nullptr;  // device: [n_global globals][n_mix mix][4*n_pow mixpow][4 inv_van]
 };
 
+namespace r0h {
+// fills the host tables of `c` from a blob (no device work); validates every index the sequencer and the verifier follow
+const char* parse_blob(r0h_circuit* c, const uint32_t* blob, size_t n_words);
+}  // namespace r0h

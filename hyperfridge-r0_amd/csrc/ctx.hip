@@ -22,7 +22,7 @@ const char* make_error(const char* fmt, ...) {
   return out;
 }
 
-static void fill_p2(P2Consts& k, const uint32_t* rc, const uint32_t* diag) {
+void fill_p2(P2Consts& k, const uint32_t* rc, const uint32_t* diag) {
   int fr = 0, pr = 0;
   for (int r = 0; r < P2_ROUNDS; r++) {
     bool full = r < P2_HALF_FULL || r >= P2_HALF_FULL + P2_PARTIAL;
@@ -39,6 +39,7 @@ static void fill_p2(P2Consts& k, const uint32_t* rc, const uint32_t* diag) {
     k.diag_shoup[i] = shoup_companion(diag[i]);
   }
 }
+void p2_default_host(P2Consts& k) { fill_p2(k, R0H_P2_ROUND_CONSTANTS, R0H_P2_INT_DIAG_M1); }
 
 static inline uint32_t sbox7(uint32_t x) {
   uint32_t x2 = mul(x, x), x4 = mul(x2, x2);

@@ -143,5 +143,8 @@ void ctx_retain(r0h_ctx* ctx);
 void ctx_release(r0h_ctx* ctx);
 // host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table
 void p2_mix_host(const P2Consts& k, uint32_t* cells);
+// table from canonical round constants [29][24] and canonical (mu_i - 1) [24]; the compiled-in risc0 table
+void fill_p2(P2Consts& k, const uint32_t* rc, const uint32_t* diag_m1);
+void p2_default_host(P2Consts& k);
 void p2_hash_elems_host(const P2Consts& k, const uint32_t* elems, size_t n, uint32_t digest[8]);
 }  // namespace r0h

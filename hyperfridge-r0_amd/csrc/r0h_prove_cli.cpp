@@ -2,7 +2,7 @@
 // witness on the device, prove K segments, print throughput and a digest of the seal.
 // It stands where hyperfridge's `host prove-camt53` stands relative to risc0 (host/src/main.rs:420-423 obtains a prover and
 // calls prove once); everything risc0-specific above the segment prover (executor, receipts) is out of scope.
-//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file]
+//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,11 +26,11 @@ static void die(const char* what, const char* err) {
 
 int main(int argc, char** argv) {
   if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) {
-    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file]\n%s\n", r0h_version());
+    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1]\n%s\n", r0h_version());
     return argc < 2 ? 1 : 0;
   }
   std::string blob_path = argv[1], co_path, seal_out;
-  unsigned po2 = 16, segments = 1, device = 0, contexts = 1;
+  unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--code-object")) co_path = argv[i + 1];
@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--device")) device = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--contexts")) contexts = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--seal-out")) seal_out = argv[i + 1];
+    else if (!strcmp(argv[i], "--verify")) verify = (unsigned)atoi(argv[i + 1]);
     else { fprintf(stderr, "r0h_prove: unknown option %s\n", argv[i]); return 1; }
   }
   FILE* f = fopen(blob_path.c_str(), "rb");
@@ -90,6 +91,15 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < l0.words; i++) { h ^= l0.seal[i]; h *= 1099511628211ull; }
   printf("{\"segments\": %u, \"contexts\": %u, \"po2\": %u, \"seal_words\": %zu, \"seal_fnv1a\": \"%016llx\", \"seconds\": %.6f, \"segments_per_s\": %.4f}\n",
          segments, contexts, po2, l0.words, (unsigned long long)h, total, segments / total);
+  if (verify) {  // outside the timed region: the host-side verifier on every lane's last seal
+    for (const Lane& ln : lanes) {
+      if (!ln.proved) continue;
+      int verdict = -1;
+      CHECK(r0h_verify_seal(blob.data(), blob.size(), nullptr, nullptr, ln.seal.data(), ln.words, &verdict, nullptr));
+      if (verdict != R0H_VERIFY_OK) { fprintf(stderr, "r0h_prove: the verifier rejects the seal: %s\n", r0h_verify_reason(verdict)); return 3; }
+    }
+    fprintf(stderr, "r0h_prove: seals verified\n");
+  }
   if (!seal_out.empty()) {
     FILE* o = fopen(seal_out.c_str(), "wb");
     if (!o || fwrite(l0.seal.data(), 4, l0.words, o) != l0.words) { fprintf(stderr, "r0h_prove: cannot write %s\n", seal_out.c_str()); return 1; }

@@ -1,0 +1,350 @@
+// Host-side seal verifier (no device work): replays the Fiat-Shamir transcript of prover.hip, re-evaluates the
+// constraint program at the out-of-domain point from the opened interpolants, and checks every Merkle opening and FRI
+// fold of the 50 queries.  Replaces risc0-zkp 3.0.4 verify/{mod.rs, merkle.rs, fri.rs, read_iop.rs} as reached from
+// `receipt.verify(image_id)` (host/src/main.rs:622-624, verifier/src/main.rs:124-126) -- SURVEY.md 8(f) rank 1.
+// Written against the seal layout the sequencer emits; the tests cross-check its verdicts with the CPU restatement's verifier.
+#include "../../include/r0hip_circuit.h"
+#include "circuit.hpp"
+
+#include <algorithm>
+#include <memory>
+
+namespace r0h {
+namespace {
+
+struct Reject { int code; };  // unwinds the verifier; never crosses the C ABI
+
+class SealReader {
+ public:
+  SealReader(const P2Consts& k, const uint32_t* w, size_t n) : k_(k), w_(w), n_(n) { memset(cells_, 0, sizeof cells_); }
+  const uint32_t* take(size_t n) {
+    if (n > n_ - pos_) throw Reject{R0H_VERIFY_TRUNCATED};
+    const uint32_t* p = w_ + pos_;
+    pos_ += n;
+    return p;
+  }
+  const uint32_t* take_elems(size_t n) {
+    const uint32_t* p = take(n);
+    for (size_t i = 0; i < n; i++)
+      if (p[i] >= P) throw Reject{R0H_VERIFY_BAD_ELEM};
+    return p;
+  }
+  bool exhausted() const { return pos_ == n_; }
+  void commit(const uint32_t digest[8]) {
+    if (used_ != 0) { p2_mix_host(k_, cells_); used_ = 0; }
+    for (int i = 0; i < 8; i++) cells_[i] = add(cells_[i], digest[i] % P);
+    p2_mix_host(k_, cells_);
+  }
+  void commit_elems(const uint32_t* e, size_t n) {
+    uint32_t d[8];
+    p2_hash_elems_host(k_, e, n, d);
+    commit(d);
+  }
+  uint32_t elem() {
+    if (used_ == P2_RATE) { p2_mix_host(k_, cells_); used_ = 0; }
+    return cells_[used_++];
+  }
+  Fp4 ext() { Fp4 r; for (int i = 0; i < 4; i++) r.e[i] = elem(); return r; }
+  uint32_t bits(uint32_t n) {
+    uint32_t v = dec(elem());
+    for (int i = 0; i < 3; i++) { uint32_t nv = dec(elem()); if (v == 0) v = nv; }
+    return v & (uint32_t)(((uint64_t)1 << n) - 1);
+  }
+  const P2Consts& consts() const { return k_; }
+
+ private:
+  const P2Consts& k_;
+  const uint32_t* w_;
+  size_t n_, pos_ = 0;
+  uint32_t cells_[P2_CELLS];
+  uint32_t used_ = 0;
+};
+
+unsigned log2_exact(size_t x) { unsigned n = 0; while (((size_t)1 << n) < x) n++; return n; }
+
+void hash_pair(const P2Consts& k, const uint32_t* left, const uint32_t* right, uint32_t* out) {
+  uint32_t st[P2_CELLS] = {0};
+  memcpy(st, left, 32);
+  memcpy(st + 8, right, 32);
+  p2_mix_host(k, st);
+  memcpy(out, st, 32);
+}
+
+// The verifier's view of one committed matrix: the elided top layer (read from the seal) folded down to the root.
+class TreeVerifier {
+ public:
+  TreeVerifier(SealReader& io, size_t rows, size_t cols, int reject_code) : rows_(rows), cols_(cols), reject_(reject_code) {
+    const size_t layers = log2_exact(rows);
+    size_t top_layer = 0;
+    for (size_t i = 1; i < layers; i++) {
+      if (((size_t)1 << i) > R0H_QUERIES) break;
+      top_layer = i;
+    }
+    top_size_ = (size_t)1 << top_layer;
+    top_.assign(2 * top_size_ * 8, 0);
+    memcpy(&top_[top_size_ * 8], io.take(top_size_ * 8), top_size_ * 32);
+    for (size_t i = top_size_; i-- > 1;) hash_pair(io.consts(), &top_[2 * i * 8], &top_[(2 * i + 1) * 8], &top_[i * 8]);
+    io.commit(&top_[8]);
+  }
+  // the opened row (cols_ canonical words) if its path leads to the committed top layer
+  const uint32_t* open(SealReader& io, size_t row) const {
+    if (row >= rows_) throw Reject{reject_};
+    const uint32_t* values = io.take(cols_);
+    for (size_t i = 0; i < cols_; i++)
+      if (values[i] >= P) throw Reject{reject_};
+    uint32_t cur[8];
+    p2_hash_elems_host(io.consts(), values, cols_, cur);
+    size_t node = row + rows_;
+    for (; node >= 2 * top_size_; node >>= 1) {
+      const uint32_t* sibling = io.take(8);
+      uint32_t parent[8];
+      if (node & 1) hash_pair(io.consts(), sibling, cur, parent); else hash_pair(io.consts(), cur, sibling, parent);
+      memcpy(cur, parent, 32);
+    }
+    if (memcmp(&top_[node * 8], cur, 32) != 0) throw Reject{reject_};
+    return values;
+  }
+
+ private:
+  size_t rows_, cols_, top_size_ = 1;
+  int reject_;
+  std::vector<uint32_t> top_;
+};
+
+Fp4 horner(const Fp4* coeffs, size_t n, const Fp4& x) {
+  Fp4 acc = fp4_zero();
+  for (size_t i = n; i-- > 0;) acc = acc * x + coeffs[i];
+  return acc;
+}
+Fp4 lift(uint32_t a) { Fp4 r = fp4_zero(); r.e[0] = a; return r; }
+
+// risc0-zkp adapter.rs `PolyExtStepDef::step` over extension values: the constraint polynomial at z
+Fp4 constraint_at_z(const r0h_circuit& c, const Fp4& poly_mix, const std::vector<Fp4>& taps_at_z, const uint32_t* global, const uint32_t* mix) {
+  struct MixState { Fp4 tot, mul; };
+  std::vector<Fp4> fp;
+  std::vector<MixState> mx;
+  fp.reserve(c.fp_step.size());
+  mx.reserve(c.mix_step.size());
+  for (const Step& s : c.steps) {
+    switch (s.op) {
+      case R0H_OP_CONST: fp.push_back(lift(enc(s.a))); break;
+      case R0H_OP_GET: fp.push_back(taps_at_z[s.a]); break;
+      case R0H_OP_GET_GLOBAL: fp.push_back(lift(s.a == 0 ? global[s.b] : mix[s.b])); break;
+      case R0H_OP_ADD: fp.push_back(fp[s.a] + fp[s.b]); break;
+      case R0H_OP_SUB: fp.push_back(fp[s.a] - fp[s.b]); break;
+      case R0H_OP_MUL: fp.push_back(fp[s.a] * fp[s.b]); break;
+      case R0H_OP_TRUE: mx.push_back({fp4_zero(), fp4_one()}); break;
+      case R0H_OP_AND_EQZ: mx.push_back({mx[s.a].tot + mx[s.a].mul * fp[s.b], mx[s.a].mul * poly_mix}); break;
+      case R0H_OP_AND_COND: mx.push_back({mx[s.a].tot + fp[s.b] * mx[s.c].tot * mx[s.a].mul, mx[s.a].mul * mx[s.c].mul}); break;
+      default: break;
+    }
+  }
+  return mx[c.ret].tot;
+}
+
+void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_t seal_words, uint32_t* po2_out) {
+  SealReader io(k, seal, seal_words);
+  {
+    static const char proof_system_info[] = "RISC0_STARK:v1__";
+    uint32_t e[16];
+    for (int i = 0; i < 16; i++) e[i] = enc((uint8_t)proof_system_info[i]);
+    io.commit_elems(e, 16);
+    for (int i = 0; i < 16; i++) e[i] = enc(c.info[i]);
+    io.commit_elems(e, 16);
+  }
+  const uint32_t* global = io.take_elems((size_t)c.n_global + 1);
+  const uint32_t po2 = dec(global[c.n_global]);
+  if (po2 < 9 || po2 > 24) throw Reject{R0H_VERIFY_BAD_PO2};
+  if (po2_out) *po2_out = po2;
+  io.commit_elems(global, (size_t)c.n_global + 1);
+  const size_t n = (size_t)1 << po2, domain = n * R0H_INV_RATE;
+  const uint32_t n_taps = (uint32_t)c.taps.size(), n_regs = (uint32_t)c.regs.size(), n_combos = (uint32_t)c.combo_begin.size() - 1;
+  const uint32_t n_u = n_taps + R0H_CHECK_SIZE;
+
+  // commitments, in the order the prover made them
+  std::unique_ptr<TreeVerifier> group[4];  // ACCUM, CODE, DATA, CHECK
+  group[R0H_GROUP_CODE].reset(new TreeVerifier(io, domain, c.group_size[R0H_GROUP_CODE], R0H_VERIFY_MERKLE_GROUP));
+  group[R0H_GROUP_DATA].reset(new TreeVerifier(io, domain, c.group_size[R0H_GROUP_DATA], R0H_VERIFY_MERKLE_GROUP));
+  std::vector<uint32_t> mix(c.n_mix);
+  for (uint32_t& m : mix) m = io.elem();
+  group[R0H_GROUP_ACCUM].reset(new TreeVerifier(io, domain, c.group_size[R0H_GROUP_ACCUM], R0H_VERIFY_MERKLE_GROUP));
+  const Fp4 poly_mix = io.ext();
+  group[3].reset(new TreeVerifier(io, domain, R0H_CHECK_SIZE, R0H_VERIFY_MERKLE_GROUP));
+  const Fp4 z = io.ext(), z4 = fp4_pow(z, 4);
+  const uint32_t back_one = rou_rev(po2);
+
+  // interpolant coefficients of every register (and the 16 check values at z^4)
+  std::vector<Fp4> coeff_u(n_u);
+  {
+    const uint32_t* cu = io.take_elems(4 * (size_t)n_u);
+    memcpy(coeff_u.data(), cu, 16 * (size_t)n_u);
+    io.commit_elems(cu, 4 * (size_t)n_u);
+  }
+  std::vector<Fp4> tap_point(n_taps), taps_at_z(n_taps);
+  for (uint32_t t = 0; t < n_taps; t++) tap_point[t] = scale(z, fpow(back_one, c.taps[t].back));
+  for (const Reg& r : c.regs)
+    for (uint32_t i = 0; i < r.size; i++) taps_at_z[r.first_tap + i] = horner(&coeff_u[r.first_tap], r.size, tap_point[r.first_tap + i]);
+
+  // the constraint identity  C(z) == check(z) * (Z_H(3z)),  check(z) reassembled from its 4 x 4 split
+  {
+    const Fp4 lhs = constraint_at_z(c, poly_mix, taps_at_z, global, mix.data());
+    Fp4 check = fp4_zero(), zr = fp4_one();
+    for (uint32_t r = 0; r < 4; r++) {
+      const uint32_t block = ((r & 1) << 1) | (r >> 1);  // the split polynomials sit in bit-reversed order
+      Fp4 part = fp4_zero();
+      for (uint32_t j = 4; j-- > 0;) {
+        // part = sum_j coeff[4j + block] * X^j  in  Fp[X]/(X^4 - 11):  multiply the accumulated value by X, add the next
+        Fp4 shifted{{mul(part.e[3], enc(11)), part.e[0], part.e[1], part.e[2]}};
+        part = shifted + coeff_u[n_taps + 4 * j + block];
+      }
+      check = check + part * zr;
+      zr = zr * z;
+    }
+    const Fp4 vanishing = fp4_pow(scale(z, enc(3)), n) - fp4_one();
+    if (!(check * vanishing == lhs)) throw Reject{R0H_VERIFY_CHECK_MISMATCH};
+  }
+
+  // DEEP batching: the per-combo mixes of the interpolants
+  const Fp4 deep_mix = io.ext();
+  size_t widest = 1;
+  for (uint32_t kq = 0; kq < n_combos; kq++) widest = std::max<size_t>(widest, c.combo_begin[kq + 1] - c.combo_begin[kq]);
+  std::vector<Fp4> combo_u((size_t)(n_combos + 1) * widest, fp4_zero());
+  std::vector<Fp4> reg_weight(n_regs), check_weight(R0H_CHECK_SIZE);
+  {
+    Fp4 cur = fp4_one();
+    for (uint32_t r = 0; r < n_regs; r++) {
+      reg_weight[r] = cur;
+      for (uint32_t i = 0; i < c.regs[r].size; i++) {
+        Fp4& dst = combo_u[(size_t)c.regs[r].combo * widest + i];
+        dst = dst + cur * coeff_u[c.regs[r].first_tap + i];
+      }
+      cur = cur * deep_mix;
+    }
+    for (uint32_t i = 0; i < R0H_CHECK_SIZE; i++) {
+      check_weight[i] = cur;
+      combo_u[(size_t)n_combos * widest] = combo_u[(size_t)n_combos * widest] + cur * coeff_u[n_taps + i];
+      cur = cur * deep_mix;
+    }
+  }
+  std::vector<Fp4> combo_points;  // z * w^-back for every (combo, back)
+  for (size_t b = 0; b < c.combo_backs.size(); b++) combo_points.push_back(scale(z, fpow(back_one, c.combo_backs[b])));
+
+  // FRI commitments and the final polynomial
+  struct Round { std::unique_ptr<TreeVerifier> tree; Fp4 mix; size_t rows; };
+  std::vector<Round> rounds;
+  size_t degree = n, dom = domain;
+  while (degree > R0H_FRI_MIN_DEGREE) {
+    Round rd;
+    rd.rows = dom / R0H_FRI_FOLD;
+    rd.tree.reset(new TreeVerifier(io, rd.rows, R0H_FRI_FOLD * 4, R0H_VERIFY_FRI_MERKLE));
+    rd.mix = io.ext();
+    rounds.push_back(std::move(rd));
+    dom /= R0H_FRI_FOLD;
+    degree /= R0H_FRI_FOLD;
+  }
+  std::vector<Fp4> final_poly(degree);
+  {
+    const uint32_t* fc = io.take_elems(4 * degree);
+    io.commit_elems(fc, 4 * degree);
+    for (size_t i = 0; i < degree; i++)
+      for (int q = 0; q < 4; q++) final_poly[i].e[q] = fc[(size_t)q * degree + i];
+  }
+
+  // the size-16 inverse DFT matrix of a fold, shared by all queries
+  uint32_t idft[R0H_FRI_FOLD][R0H_FRI_FOLD];
+  {
+    const uint32_t zeta_inv = rou_rev(4), inv16 = fpow(enc(R0H_FRI_FOLD), P - 2);
+    for (uint32_t j = 0; j < R0H_FRI_FOLD; j++)
+      for (uint32_t kq = 0; kq < R0H_FRI_FOLD; kq++) idft[j][kq] = mul(inv16, fpow(zeta_inv, (uint64_t)j * kq));
+  }
+  const uint32_t w_domain = rou_fwd(log2_exact(domain)), w_final = rou_fwd(log2_exact(dom));
+  std::vector<Fp4> combo_tot(n_combos + 1);
+  for (uint32_t q = 0; q < R0H_QUERIES; q++) {
+    size_t pos = io.bits(log2_exact(domain)) % domain;
+    const uint32_t* row[4];
+    for (int g = 0; g < 4; g++) row[g] = group[g]->open(io, pos);
+    const Fp4 x = lift(fpow(w_domain, pos));
+    std::fill(combo_tot.begin(), combo_tot.end(), fp4_zero());
+    for (uint32_t r = 0; r < n_regs; r++) {
+      Fp4& t = combo_tot[c.regs[r].combo];
+      t = t + scale(reg_weight[r], row[c.regs[r].group][c.regs[r].offset]);
+    }
+    for (uint32_t i = 0; i < R0H_CHECK_SIZE; i++) combo_tot[n_combos] = combo_tot[n_combos] + scale(check_weight[i], row[3][i]);
+    Fp4 goal = fp4_zero();
+    for (uint32_t kq = 0; kq < n_combos; kq++) {
+      const uint32_t b0 = c.combo_begin[kq], b1 = c.combo_begin[kq + 1];
+      Fp4 den = fp4_one();
+      for (uint32_t b = b0; b < b1; b++) den = den * (x - combo_points[b]);
+      goal = goal + (combo_tot[kq] - horner(&combo_u[(size_t)kq * widest], b1 - b0, x)) * fp4_inv(den);
+    }
+    goal = goal + (combo_tot[n_combos] - combo_u[(size_t)n_combos * widest]) * fp4_inv(x - z4);
+
+    size_t rows_above = domain;
+    for (const Round& rd : rounds) {
+      const size_t quot = pos / rd.rows, grp = pos % rd.rows;
+      const uint32_t* col = rd.tree->open(io, grp);
+      Fp4 v[R0H_FRI_FOLD];
+      for (uint32_t i = 0; i < R0H_FRI_FOLD; i++)
+        for (int e = 0; e < 4; e++) v[i].e[e] = col[e * R0H_FRI_FOLD + i];
+      if (!(v[quot] == goal)) throw Reject{R0H_VERIFY_FRI_GOAL};
+      // interpolate the 16 values over the coset w^grp * <zeta>, then evaluate the interpolant's fold at the round mix
+      const uint32_t untwist = fpow(rou_rev(log2_exact(rows_above)), grp);
+      Fp4 tot = fp4_zero(), mixpow = fp4_one();
+      uint32_t tw = ONE;
+      for (uint32_t j = 0; j < R0H_FRI_FOLD; j++) {
+        Fp4 cj = fp4_zero();
+        for (uint32_t i = 0; i < R0H_FRI_FOLD; i++) cj = cj + scale(v[i], idft[j][i]);
+        tot = tot + scale(cj, tw) * mixpow;
+        mixpow = mixpow * rd.mix;
+        tw = mul(tw, untwist);
+      }
+      goal = tot;
+      pos = grp;
+      rows_above = rd.rows;
+    }
+    if (!(horner(final_poly.data(), degree, lift(fpow(w_final, pos))) == goal)) throw Reject{R0H_VERIFY_FRI_FINAL};
+  }
+  if (!io.exhausted()) throw Reject{R0H_VERIFY_TRAILING};
+}
+
+}  // namespace
+}  // namespace r0h
+
+using namespace r0h;
+
+extern "C" {
+
+const char* r0h_verify_reason(int verdict) {
+  static const char* const names[] = {"ok", "seal truncated", "bad po2", "group merkle path rejected", "constraint check mismatch at z",
+                                      "fri merkle path rejected", "fri fold goal mismatch", "fri final polynomial mismatch",
+                                      "trailing words in seal", "non-canonical field element"};
+  return verdict >= 0 && verdict <= R0H_VERIFY_BAD_ELEM ? names[verdict] : "unknown";
+}
+
+const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
+                            const uint32_t* seal, size_t seal_words, int* verdict_out, uint32_t* po2_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(blob && (seal || seal_words == 0) && verdict_out, "r0h_verify_seal: NULL argument");
+  R0H_REQUIRE((p2_round_constants == nullptr) == (p2_diag_m1 == nullptr), "r0h_verify_seal: pass both Poseidon2 tables or neither");
+  r0h_circuit c;
+  R0H_TRY(parse_blob(&c, blob, blob_words));
+  std::unique_ptr<P2Consts> k(new P2Consts);
+  if (p2_round_constants) {
+    for (size_t i = 0; i < (size_t)P2_ROUNDS * P2_CELLS; i++) R0H_REQUIRE(p2_round_constants[i] < P, "r0h_verify_seal: round constant %zu not canonical", i);
+    for (size_t i = 0; i < P2_CELLS; i++) R0H_REQUIRE(p2_diag_m1[i] < P, "r0h_verify_seal: diagonal entry %zu not canonical", i);
+    fill_p2(*k, p2_round_constants, p2_diag_m1);
+  } else {
+    p2_default_host(*k);
+  }
+  if (po2_out) *po2_out = 0;
+  try {
+    verify(c, *k, seal, seal_words, po2_out);
+    *verdict_out = R0H_VERIFY_OK;
+  } catch (const Reject& r) {
+    *verdict_out = r.code;
+  }
+  return nullptr;
+  R0H_GUARD_END
+}
+
+}  // extern "C"

@@ -142,6 +142,26 @@ const char* r0h_proof_abort(r0h_proof* proof);
 /* Per-phase device time of the last r0h_prove_segment on this context (ms), for bench.py; names are static strings. */
 const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out);
 
+/* ---- verifier: risc0-zkp verify/mod.rs as reached from `receipt.verify(image_id)` (host/src/main.rs:622-624,
+ * verifier/src/main.rs:124-126).  Pure host code: no context, no GPU.  Returns NULL when the check itself ran (the outcome is
+ * in *verdict_out: R0H_VERIFY_OK or the first reason for rejection) and an error string only for unusable arguments
+ * (malformed circuit blob, non-canonical Poseidon2 tables).  p2_round_constants [29][24] / p2_diag_m1 [24] are canonical words,
+ * or both NULL for the compiled-in risc0 table.  *po2_out (optional) receives the trace size the seal claims. ---- */
+#define R0H_VERIFY_OK 0
+#define R0H_VERIFY_TRUNCATED 1
+#define R0H_VERIFY_BAD_PO2 2
+#define R0H_VERIFY_MERKLE_GROUP 3
+#define R0H_VERIFY_CHECK_MISMATCH 4
+#define R0H_VERIFY_FRI_MERKLE 5
+#define R0H_VERIFY_FRI_GOAL 6
+#define R0H_VERIFY_FRI_FINAL 7
+#define R0H_VERIFY_TRAILING 8
+#define R0H_VERIFY_BAD_ELEM 9
+const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants,
+                            const uint32_t* p2_diag_m1, const uint32_t* seal, size_t seal_words, int* verdict_out,
+                            uint32_t* po2_out);
+const char* r0h_verify_reason(int verdict); /* static string, do not free */
+
 /* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
  * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */
 const char* r0h_kernel_timing(r0h_ctx* ctx, int enable);

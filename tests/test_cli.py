@@ -9,6 +9,23 @@ import pytest
 from conftest import ROOT, circuit_path
 
 CLI = os.path.join(ROOT, "hyperfridge-r0_amd", "r0h_prove")
+VERIFY = os.path.join(ROOT, "hyperfridge-r0_amd", "r0h_verify")
+
+
+def test_verify_cli_accepts_the_golden_seal_and_rejects_a_flipped_word(tmp_path):
+    """`verifier verify` counterpart (verifier/src/main.rs:118-126): host only, exit status carries the outcome."""
+    seal = np.load(os.path.join(ROOT, "tests", "golden", "seal_tiny_po2_9_seed_1.npy"))
+    good, bad = str(tmp_path / "good.bin"), str(tmp_path / "bad.bin")
+    seal.tofile(good)
+    flipped = seal.copy()
+    flipped[-1] ^= 1
+    flipped.tofile(bad)
+    out = subprocess.run([VERIFY, circuit_path("tiny"), good], capture_output=True, text=True)
+    assert out.returncode == 0 and json.loads(out.stdout)["accepted"] is True and json.loads(out.stdout)["po2"] == 9
+    out = subprocess.run([VERIFY, circuit_path("tiny"), bad], capture_output=True, text=True)
+    assert out.returncode == 1 and json.loads(out.stdout)["accepted"] is False
+    out = subprocess.run([VERIFY, good, good], capture_output=True, text=True)  # a seal is not a circuit blob
+    assert out.returncode == 2 and "circuit blob" in out.stderr
 
 
 def test_cli_builds_and_reports_usage():
@@ -30,8 +47,9 @@ def test_cli_without_a_gpu_fails_loudly():
 @pytest.mark.gpu
 def test_cli_seal_matches_the_harness_and_verifies(hal, orc, tmp_path):
     seal_file = str(tmp_path / "seal.bin")
-    out = subprocess.run([CLI, circuit_path("small"), "--po2", "11", "--seed", "9", "--seal-out", seal_file], capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr
+    out = subprocess.run([CLI, circuit_path("small"), "--po2", "11", "--seed", "9", "--seal-out", seal_file, "--verify", "1"], capture_output=True, text=True)
+    assert out.returncode == 0 and "seals verified" in out.stderr, out.stderr
+    assert subprocess.run([VERIFY, circuit_path("small"), seal_file], capture_output=True).returncode == 0
     info = json.loads(out.stdout.strip().splitlines()[-1])
     seal = np.fromfile(seal_file, dtype=np.uint32)
     assert info["seal_words"] == seal.size

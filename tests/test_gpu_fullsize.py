@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import __graft_entry__ as entry
+import hyperfridge_r0_amd as r0
 from conftest import circuit_path
 
 pytestmark = pytest.mark.gpu
@@ -22,10 +23,11 @@ def test_full_size_seal_is_accepted_by_the_oracle_verifier_and_is_deterministic(
     code, data, glob = hal.witgen(gc, po2, seed=77)
     seal = hal.prove_segment(gc, po2, code, data, glob)
     assert oc.verify(seal) == (0, "ok")
+    assert r0.verify_seal(blob, seal) == (0, "ok", po2)  # the product's own host-side verifier
     assert np.array_equal(seal, hal.prove_segment(gc, po2, code, data, glob))
     bad = seal.copy()
     bad[seal.size // 2] ^= 1
-    assert oc.verify(bad)[0] != 0
+    assert oc.verify(bad)[0] != 0 and r0.verify_seal(blob, bad)[:2] == oc.verify(bad)
     # a different segment of the same circuit
     code2, data2, glob2 = hal.witgen(gc, po2, seed=78)
     seal2 = hal.prove_segment(gc, po2, code2, data2, glob2)

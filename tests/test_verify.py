@@ -1,0 +1,87 @@
+"""The product's host-side verifier (r0h_verify_seal, hyperfridge-r0_amd/csrc/verify.hip) -- the `receipt.verify(image_id)`
+half of the boundary (verifier/src/main.rs:124-126).  It needs no GPU, so these run in the CPU suite: it must accept the
+frozen golden seal and seals made by the oracle prover, and agree with the oracle's independent verifier -- verdict AND
+reason -- on every mutation (word flips in each region of the seal, truncation, extension, a different circuit)."""
+import os
+
+import numpy as np
+import pytest
+
+import hyperfridge_r0_amd as r0
+from conftest import ROOT, circuit_path
+
+P = 2013265921
+GOLDEN = os.path.join(ROOT, "tests", "golden", "seal_tiny_po2_9_seed_1.npy")
+
+
+def _blob(name):
+    return np.fromfile(circuit_path(name), dtype=np.uint32)
+
+
+def test_accepts_the_frozen_seal_without_a_gpu():
+    assert r0.verify_seal(_blob("tiny"), np.load(GOLDEN)) == (0, "ok", 9)
+
+
+def test_explicit_poseidon2_tables_equal_the_compiled_in_ones():
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "poseidon2_babybear_t24.json")))
+    rc = np.array(g["round_constants"], dtype=np.uint32).reshape(-1)
+    dg = np.array(g["int_diag_m1"], dtype=np.uint32)
+    seal = np.load(GOLDEN)
+    assert r0.verify_seal(_blob("tiny"), seal, (rc, dg))[0] == 0
+    rc2 = rc.copy()
+    rc2[5] ^= 1  # another hash function: the first commitment already disagrees
+    assert r0.verify_seal(_blob("tiny"), seal, (rc2, dg))[0] != 0
+    rc2[5] = P
+    with pytest.raises(r0.R0HipError, match="not canonical"):
+        r0.verify_seal(_blob("tiny"), seal, (rc2, dg))
+
+
+def test_rejects_a_malformed_blob_with_an_error_not_a_verdict():
+    with pytest.raises(r0.R0HipError, match="circuit blob"):
+        r0.verify_seal(np.zeros(8, np.uint32), np.load(GOLDEN))
+
+
+@pytest.mark.parametrize("name,po2,seed", [("tiny", 9, 1), ("tiny", 11, 5), ("small", 10, 2)])
+def test_agrees_with_the_oracle_verifier_on_mutated_seals(orc, name, po2, seed):
+    blob = _blob(name)
+    c = orc.circuit(blob)
+    code, data, glob = c.witgen(po2, seed)
+    seal = c.prove(po2, code, data, glob)
+    assert c.verify(seal) == (0, "ok")
+    assert r0.verify_seal(blob, seal) == (0, "ok", po2)
+
+    rng = np.random.default_rng(1000 + seed)
+    seen = set()
+    # dense at the front (globals, tree tops, mixes, coefficients), sparse over the query openings
+    positions = list(range(0, min(seal.size, 40))) + list(rng.integers(0, seal.size, 160))
+    for pos in positions:
+        bad = seal.copy()
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            bad[pos] = (int(bad[pos]) + 1) % P
+        elif kind == 1:
+            bad[pos] = int(rng.integers(0, P))
+        else:
+            bad[pos] = int(rng.integers(P, 1 << 32))  # non-canonical word
+        if np.array_equal(bad, seal):
+            continue
+        want = c.verify(bad)
+        got = r0.verify_seal(blob, bad)
+        assert got[:2] == want, "word %d: product says %r, oracle says %r" % (pos, got, want)
+        assert got[0] != 0
+        seen.add(got[0])
+    for cut in (0, 1, 7, seal.size // 3, seal.size - 1):
+        assert r0.verify_seal(blob, seal[:cut])[:2] == c.verify(seal[:cut])
+        seen.add(r0.verify_seal(blob, seal[:cut])[0])
+    longer = np.concatenate([seal, np.zeros(3, np.uint32)])
+    assert r0.verify_seal(blob, longer)[:2] == c.verify(longer) == (8, "trailing words in seal")
+    # every class of rejection the protocol has was exercised, not just one
+    assert {1, 3, 4}.issubset(seen) and len(seen) >= 5, seen
+
+
+def test_a_seal_for_one_circuit_is_not_a_seal_for_another(orc):
+    seal = np.load(GOLDEN)
+    other = _blob("small")
+    got = r0.verify_seal(other, seal)
+    assert got[0] != 0 and got[:2] == orc.circuit(other).verify(seal)
