@@ -232,9 +232,18 @@ static const char* PRELUDE = R"SRC(// GENERATED by r0h_circuit_emit_hip -- eval_
 typedef unsigned int u32;
 typedef unsigned long long u64;
 #define FP_P 2013265921u
-__device__ __forceinline__ u32 fred(u32 x) { u32 y = x - FP_P; return y < x ? y : x; }
+// corrections by p go through the carry flag (v_sub_co_u32 + v_cndmask_b32, full rate) rather than v_min_u32 (half rate on gfx950)
+__device__ __forceinline__ u32 fred(u32 x) {
+  u32 r;
+  asm("v_subrev_co_u32 %0, vcc, 0x78000001, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "=&v"(r) : "v"(x) : "vcc");
+  return r;
+}
 __device__ __forceinline__ u32 fadd(u32 a, u32 b) { return fred(a + b); }
-__device__ __forceinline__ u32 fsub(u32 a, u32 b) { u32 d = a - b, e = d + FP_P; return d < e ? d : e; }
+__device__ __forceinline__ u32 fsub(u32 a, u32 b) {
+  u32 d, e;
+  asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_add_u32 %1, 0x78000001, %0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "=&v"(d), "=&v"(e) : "v"(a), "v"(b) : "vcc");
+  return d;
+}
 __device__ __forceinline__ u32 fmul(u32 a, u32 b) {
   u64 t = (u64)a * b;
   u32 m = (u32)t * 0x77ffffffu;
@@ -247,9 +256,7 @@ __device__ __forceinline__ u32 fred64(u64 T) {
   u32 m = (u32)T * 0x88000001u;
   u32 q = __umulhi(m, FP_P);
   u32 h = (u32)(T >> 32);
-  u32 r = h - q;
-  r = h < q ? r + FP_P : r;
-  return fred(r);
+  return fred(fsub(h, q));
 }
 #define TAP(g, col, back) g[(size_t)(col) * domain + ((i - 4u * (back)) & mask)]
 )SRC";

@@ -20,14 +20,30 @@ constexpr uint32_t ONE = 268435454u;     // 2^32 mod p
 constexpr uint32_t ROU_GEN = 137u;       // primitive 2^27-th root (canonical)
 constexpr uint32_t BETA_CANON = 11u;
 
+// Conditional correction by p through the carry flag: on gfx950 v_min_u32 / v_max_u32 issue at half rate (4.4 SIMD cycles
+// per wave instruction, like every three-operand VOP3 integer op) while v_sub_co_u32 + v_cndmask_b32 are full rate (2.4 each)
+// -- tools/microbench/valu_rate_bench.hip, profiles/r01/valu_rate_microbench.txt.  The host build keeps plain C++.
 R0H_HD uint32_t reduce1(uint32_t x) {  // x < 2p  ->  x mod p
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_subrev_co_u32 %0, vcc, 0x78000001, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "=&v"(r) : "v"(x) : "vcc");  // r = x - p; borrow ? x : r
+  return r;
+#else
   uint32_t y = x - P;
   return y < x ? y : x;  // min as unsigned: x-P wraps above x when x < P
+#endif
 }
 R0H_HD uint32_t add(uint32_t a, uint32_t b) { return reduce1(a + b); }
 R0H_HD uint32_t sub(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t d, e;
+  asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_add_u32 %1, 0x78000001, %0\n\tv_cndmask_b32 %0, %0, %1, vcc"
+      : "=&v"(d), "=&v"(e) : "v"(a), "v"(b) : "vcc");  // d = a - b; borrow ? d + p : d
+  return d;
+#else
   uint32_t d = a - b, e = d + P;  // a >= b: d < p <= e;  a < b: d wrapped above 2^32 - p, e = p - (b - a) < p
-  return d < e ? d : e;           // three full-rate instructions (sub, add, min) instead of sub/cmp/add/select
+  return d < e ? d : e;
+#endif
 }
 R0H_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
 R0H_HD uint32_t mul(uint32_t a, uint32_t b) {
@@ -36,15 +52,25 @@ R0H_HD uint32_t mul(uint32_t a, uint32_t b) {
   uint64_t u = t + (uint64_t)m * P;
   return reduce1((uint32_t)(u >> 32));
 }
+// a - b, plus p when it went negative (operands need not be reduced: a < b + p must hold for the result to be below 2p)
+R0H_HD uint32_t sub_lazy(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t d, e;
+  asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_add_u32 %1, 0x78000001, %0\n\tv_cndmask_b32 %0, %0, %1, vcc"
+      : "=&v"(d), "=&v"(e) : "v"(a), "v"(b) : "vcc");
+  return d;
+#else
+  uint32_t d = a - b;
+  return a < b ? d + P : d;
+#endif
+}
 // Montgomery reduction of a sum of up to four products of reduced words (T < 4 p^2 < 2^64): hi(T) - hi(m p) with
 // m = lo(T) p^-1.  hi(T) < 4 p^2 / 2^32 = 1.875 p and hi(m p) < p, so after the sign fix one conditional subtraction is enough.
 R0H_HD uint32_t reduce64(uint64_t t) {
   uint32_t m = (uint32_t)t * 0x88000001u;  // p^-1 mod 2^32
   uint32_t q = (uint32_t)(((uint64_t)m * P) >> 32);
   uint32_t h = (uint32_t)(t >> 32);
-  uint32_t r = h - q;
-  r = h < q ? r + P : r;
-  return reduce1(r);
+  return reduce1(sub_lazy(h, q));
 }
 // Product with a known constant (Shoup): a in Montgomery form times the canonical constant w, given w' = floor(w 2^32 / p).
 // Result = a*w mod p, i.e. the same word mul(a, enc(w)) returns, in 9 issue slots instead of 12 (no 64-bit products).
