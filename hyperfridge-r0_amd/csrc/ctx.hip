@@ -38,6 +38,24 @@ void fill_p2(P2Consts& k, const uint32_t* rc, const uint32_t* diag) {
     k.diag_canon[i] = diag[i];
     k.diag_shoup[i] = shoup_companion(diag[i]);
   }
+  // tables of the deferred partial rounds: powers of the diagonal and their lane sums (canonical arithmetic, then encoded)
+  uint32_t pw[P2_PARTIAL + 1][P2_CELLS], kappa[P2_PARTIAL + 1];
+  for (int e = 0; e <= P2_PARTIAL; e++) {
+    uint64_t ks = 0;
+    for (int i = 1; i < P2_CELLS; i++) {
+      pw[e][i] = e == 0 ? 1u : (uint32_t)((uint64_t)pw[e - 1][i] * diag[i] % P);
+      ks += pw[e][i];
+    }
+    kappa[e] = (uint32_t)(ks % P);
+  }
+  uint32_t* w = k.part_sigma;
+  for (int r = 1; r < P2_PARTIAL; r++) {
+    for (int i = 1; i < P2_CELLS; i++) *w++ = enc(pw[r][i]);
+    for (int j = 0; j < r; j++) *w++ = enc(kappa[r - 1 - j]);
+  }
+  w = k.part_final;
+  for (int i = 1; i < P2_CELLS; i++)
+    for (int e = P2_PARTIAL; e >= 0; e--) *w++ = enc(pw[e][i]);
 }
 void p2_default_host(P2Consts& k) { fill_p2(k, R0H_P2_ROUND_CONSTANTS, R0H_P2_INT_DIAG_M1); }
 

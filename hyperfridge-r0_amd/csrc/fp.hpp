@@ -26,7 +26,11 @@ constexpr uint32_t BETA_CANON = 11u;
 R0H_HD uint32_t reduce1(uint32_t x) {  // x < 2p  ->  x mod p
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t r;
+#if defined(R0H_P_IN_VGPR)
+  asm("v_sub_co_u32 %0, vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "=&v"(r) : "v"(x), "v"(P) : "vcc");
+#else
   asm("v_subrev_co_u32 %0, vcc, 0x78000001, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "=&v"(r) : "v"(x) : "vcc");  // r = x - p; borrow ? x : r
+#endif
   return r;
 #else
   uint32_t y = x - P;

@@ -38,6 +38,7 @@ const char* make_error(const char* fmt, ...);
   catch (...) { return r0h::make_error("unknown exception"); }
 
 constexpr int P2_CELLS = 24, P2_RATE = 16, P2_OUT = 8, P2_HALF_FULL = 4, P2_PARTIAL = 21, P2_ROUNDS = 29;
+constexpr int P2_PART_SIGMA_WORDS = (P2_PARTIAL - 1) * (P2_CELLS - 1) + (P2_PARTIAL - 1) * P2_PARTIAL / 2;  // sum_{r=1}^{20} (23 + r) = 670
 constexpr uint32_t TW_BITS = 11;            // two-level twiddle tables of 2^11 entries each
 constexpr uint32_t TW_SIZE = 1u << TW_BITS;
 constexpr uint32_t MAX_DOMAIN_PO2 = 22;
@@ -50,6 +51,12 @@ struct P2Consts {
   uint32_t diag[P2_CELLS];        // Montgomery form of (mu_i - 1)
   uint32_t diag_canon[P2_CELLS];  // canonical (mu_i - 1) and its Shoup companion floor(w 2^32 / p): constant products
   uint32_t diag_shoup[P2_CELLS];
+  // Partial rounds with the linear layer of lanes 1..23 deferred (poseidon2_device.hpp): with D_i = mu_i - 1 and
+  // kappa_k = sum_{i>=1} D_i^k, all in Montgomery form,
+  //   part_sigma: for r = 1..20 the row [D_1^r .. D_23^r, kappa_{r-1}, kappa_{r-2}, .., kappa_0]   (23 + r words each)
+  //   part_final: for i = 1..23 the row [D_i^21, D_i^20, .., D_i^0]
+  uint32_t part_sigma[P2_PART_SIGMA_WORDS];
+  uint32_t part_final[(P2_CELLS - 1) * (P2_PARTIAL + 1)];
 };
 
 // Optional per-kernel timing (HIP events on the context's stream around every launch of a named kernel family).

@@ -6,75 +6,9 @@
 // constants are wave-uniform and come in through scalar loads, and consecutive lanes read consecutive rows of each
 // column so every column access of a wave is one contiguous 256-byte run.  This kernel is VALU-integer bound
 // (about 1.36k Montgomery products per permutation), not HBM bound: see DESIGN.md for the arithmetic.
-#include "internal.hpp"
+#include "poseidon2_device.hpp"
 
 namespace r0h {
-
-// x^7 with lazily reduced intermediates (bounds in units of p, x < 1):
-//   x2 = x*x        < 0.47 + 1 = 1.47        x3 = x2*x < 0.69 + 1 = 1.69      x4 = x2*x2 < 1.02 + 1 = 2.02 (t + 2^32 p < 2^64 holds)
-//   x4' = x4 - p if that does not wrap (< 1.02)                               x7 = x3*x4' < 0.81 + 1, then one reduction
-// Two conditional subtractions fewer than four full products; the result is the same canonical word.
-__device__ __forceinline__ uint32_t sbox7(uint32_t x) {
-  uint32_t x2 = mul_lazy(x, x);
-  uint32_t x3 = mul_lazy(x2, x);
-  uint32_t x4 = reduce1(mul_lazy(x2, x2));
-  return reduce1(mul_lazy(x3, x4));
-}
-
-__device__ __forceinline__ void m_ext(uint32_t (&c)[P2_CELLS]) {
-  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
-  for (int k = 0; k < P2_CELLS; k += 4) {
-    uint32_t a = c[k], b = c[k + 1], d = c[k + 2], e = c[k + 3];
-    uint32_t t0 = add(a, b), t1 = add(d, e);
-    uint32_t t2 = add(add(b, b), t1), t3 = add(add(e, e), t0);
-    uint32_t t1x2 = add(t1, t1), t0x2 = add(t0, t0);
-    uint32_t t4 = add(add(t1x2, t1x2), t3), t5 = add(add(t0x2, t0x2), t2);
-    c[k] = add(t3, t5); c[k + 1] = t5; c[k + 2] = add(t2, t4); c[k + 3] = t4;
-    s0 = add(s0, c[k]); s1 = add(s1, c[k + 1]); s2 = add(s2, c[k + 2]); s3 = add(s3, c[k + 3]);
-  }
-#pragma unroll
-  for (int k = 0; k < P2_CELLS; k += 4) {
-    c[k] = add(c[k], s0); c[k + 1] = add(c[k + 1], s1); c[k + 2] = add(c[k + 2], s2); c[k + 3] = add(c[k + 3], s3);
-  }
-}
-
-__device__ __forceinline__ void p2_mix(uint32_t (&c)[P2_CELLS], const P2Consts* __restrict__ k) {
-  m_ext(c);
-#pragma unroll 1
-  for (int r = 0; r < P2_HALF_FULL; r++) {
-#pragma unroll
-    for (int i = 0; i < P2_CELLS; i++) c[i] = sbox7(add(c[i], k->rc_full[r][i]));
-    m_ext(c);
-  }
-#pragma unroll 1
-  for (int r = 0; r < P2_PARTIAL; r++) {
-    // lane 0 goes through the S-box; the diagonal products of the other lanes do not depend on it, and the state sum
-    // is a balanced tree, so the round has no 24-deep dependency chain
-    uint32_t p[P2_CELLS];
-#pragma unroll
-    for (int i = 1; i < P2_CELLS; i++) p[i] = mul_const(c[i], k->diag_canon[i], k->diag_shoup[i]);
-    uint32_t s1[12];
-#pragma unroll
-    for (int i = 0; i < 11; i++) s1[i] = add(c[2 * i + 2], c[2 * i + 3]);  // c[2..23]
-    s1[11] = c[1];
-    uint32_t s2[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) s2[i] = add(s1[2 * i], s1[2 * i + 1]);
-    uint32_t rest = add(add(add(s2[0], s2[1]), add(s2[2], s2[3])), add(s2[4], s2[5]));
-    c[0] = sbox7(add(c[0], k->rc_partial[r]));
-    uint32_t sum = add(rest, c[0]);
-    c[0] = add(sum, mul_const(c[0], k->diag_canon[0], k->diag_shoup[0]));
-#pragma unroll
-    for (int i = 1; i < P2_CELLS; i++) c[i] = add(sum, p[i]);
-  }
-#pragma unroll 1
-  for (int r = P2_HALF_FULL; r < 2 * P2_HALF_FULL; r++) {
-#pragma unroll
-    for (int i = 0; i < P2_CELLS; i++) c[i] = sbox7(add(c[i], k->rc_full[r][i]));
-    m_ext(c);
-  }
-}
 
 __global__ __launch_bounds__(256) void hash_rows_kernel(uint32_t* __restrict__ digests, const uint32_t* __restrict__ matrix,
                                                          uint32_t rows, uint32_t cols, const P2Consts* __restrict__ k) {

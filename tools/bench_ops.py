@@ -9,6 +9,9 @@ import numpy as np
 
 import hyperfridge_r0_amd as r0
 
+if os.environ.get("R0HIP_AB_LIB"):  # A/B runs: a variant build of the library (e.g. build/varB/libr0hip.so)
+    r0.LIB_PATH = os.path.abspath(os.environ["R0HIP_AB_LIB"])
+
 
 def main():
     ops = sys.argv[1:] or ["hash_rows", "hash_fold", "intt", "ntt", "bitrev", "zk", "evalany"]
