@@ -258,6 +258,15 @@ __device__ __forceinline__ u32 fred64(u64 T) {
   u32 h = (u32)(T >> 32);
   return fred(fsub(h, q));
 }
+// Running 64-bit sums of products of reduced words: four products fit as they are (4 p^2 < 2^64); from then on the high
+// word is brought below p before every second product (total < p 2^32 + 2 p^2 < 2^64, high word < 2p).  The empty asm keeps
+// the re-packed pair opaque, so the following multiply-adds stay single v_mad_u64_u32 on that pair.
+__device__ __forceinline__ u64 dfix(u64 T) {
+  T = ((u64)fred((u32)(T >> 32)) << 32) | (u32)T;
+  asm("" : "+v"(T));
+  return T;
+}
+__device__ __forceinline__ u32 dfinish(u64 T) { return fred64(dfix(T)); }
 #define TAP(g, col, back) g[(size_t)(col) * domain + ((i - 4u * (back)) & mask)]
 )SRC";
 
@@ -304,17 +313,11 @@ static uint32_t tunable(const char* name, uint32_t dflt) {
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
-static void flush_terms(const Plan& pl, std::vector<uint32_t>& pending, std::ostringstream& os) {
-  if (pending.empty()) return;
-  for (int q = 0; q < 4; q++) {
-    os << "  t" << q << " = fadd(t" << q << ", fred64(";
-    for (size_t k = 0; k < pending.size(); k++) {
-      if (k) os << " + ";
-      os << "(u64)mixpow[" << 4 * (size_t)pl.terms[pending[k]].pow + q << "] * w" << pending[k];
-    }
-    os << "));\n";
-  }
-  pending.clear();
+// tot += poly_mix^pow * w as four running 64-bit sums (one per extension component), see dfix in the prelude
+static void emit_accumulate(const Plan& pl, uint32_t term, uint32_t position, std::ostringstream& os) {
+  if (position >= 4 && position % 2 == 0) os << "  T0 = dfix(T0); T1 = dfix(T1); T2 = dfix(T2); T3 = dfix(T3);\n";
+  for (int q = 0; q < 4; q++)
+    os << "  T" << q << (position ? " += " : " = ") << "(u64)mixpow[" << 4 * (size_t)pl.terms[term].pow + q << "] * w" << term << ";\n";
 }
 
 static std::string emit_source(const r0h_circuit* c) {
@@ -332,12 +335,11 @@ static std::string emit_source(const r0h_circuit* c) {
           "    const u32* __restrict__ inv_van, u32 po2, u32 accumulate) {\n"
           "  const u32 domain = 4u << po2, mask = domain - 1u;\n"
           "  const u32 i = blockIdx.x * 256u + threadIdx.x;\n"
-          "  u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;\n";
+          "  u64 T0 = 0, T1 = 0, T2 = 0, T3 = 0;\n";
     // Terms are emitted in register scopes: every scope re-loads the taps and re-derives the sub-expressions it needs, and
     // a scheduling barrier keeps the compiler from hoisting the next scope's loads, so the live set is bounded by the
     // scope, not by the circuit.
     std::vector<bool> done(c->fp_step.size(), false);
-    std::vector<uint32_t> pending;
     uint32_t in_scope = 0;
     os << "  {\n";
     for (uint32_t t = pl.cut[k]; t < pl.cut[k + 1]; t++) {
@@ -355,12 +357,11 @@ static std::string emit_source(const r0h_circuit* c) {
       val << "v" << tm.v;
       for (size_t g = 0; g < tm.conds.size(); g++) val << ")";
       os << "  const u32 w" << t << " = " << val.str() << ";\n";
-      pending.push_back(t);
+      emit_accumulate(pl, t, t - pl.cut[k], os);
       in_scope++;
-      // poly_mix^p * value products are summed four at a time in 64 bits and reduced once per component
-      if (pending.size() == 4 || t + 1 == pl.cut[k + 1] || (scope_terms && in_scope == scope_terms)) flush_terms(pl, pending, os);
     }
     os << "  }\n";
+    os << "  u32 t0 = dfinish(T0), t1 = dfinish(T1), t2 = dfinish(T2), t3 = dfinish(T3);\n";
     os << "  const u32 iv = inv_van[i & 3u];\n"
           "  t0 = fmul(t0, iv); t1 = fmul(t1, iv); t2 = fmul(t2, iv); t3 = fmul(t3, iv);\n"
           "  if (accumulate) {\n"
