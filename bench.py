@@ -155,10 +155,11 @@ def main():
                         "alg_bytes_per_launch": round(st["alg_bytes"] / launches),
                         "share_of_device_time": round(st["total_ms"] / max(sum(v["total_ms"] for v in kstats.values()), 1e-9), 4),
                         "note": "this kernel is VALU-integer bound (Poseidon2: ~1.36k Montgomery products per permutation, "
-                                "~3.3 G permutations/s chip ceiling); its HBM fraction is reported because the metric asks for it: DESIGN.md 6"}
+                                "the static VALU issue floor of the permutation is in valu_view); its HBM fraction is reported because the metric asks for it: DESIGN.md 6"}
         if roofline and roofline["kernel"] == "hash_rows_kernel":
-            # secondary view: the bound this kernel actually sits on.  Issue slots per permutation from the instruction mix
-            # (1,356 Montgomery products x ~11.6 slots, 426 of their reductions elided, + ~2,400 modular adds x 3 slots), peak = 256 CUs x 128 lanes/clk.
+            # secondary view: the bound this kernel actually sits on -- the VALU issue rate.  SIMD cycles one wave spends per
+            # permutation (1024 SIMDs, in-kernel clock 2.37 GHz: profiles/r01/fpmul_microbench.txt) against the static issue floor of
+            # the compiled permutation (instruction counts x measured issue costs: tools/p2_issue_floor.py).
             rows = 4 << po2
             perms = rows * sum(-(-g // 16) for g in circuit.group_size) + rows  # three groups + CHECK (16 columns)
             d = 1 << po2
@@ -166,10 +167,16 @@ def main():
                 perms += (4 * d // 16) * 4
                 d //= 16
             st = kstats["hash_rows_kernel"]
-            gslots = perms * steps * 22.5e3 / (st["total_ms"] * 1e-3) / 1e9
-            roofline["valu_view"] = {"permutations_per_segment": perms, "slots_per_permutation": 22500,
-                                     "achieved_Gslots_per_s": round(gslots, 1), "peak_Gslots_per_s_at_2.4GHz": 78643.2,
-                                     "frac": round(gslots / 78643.2, 4)}
+            cyc = st["total_ms"] * 1e-3 * 2.37e9 * 1024 / (perms * steps / 64.0)
+            view = {"permutations_per_segment": perms, "G_permutations_per_s": round(perms * steps / (st["total_ms"] * 1e-3) / 1e9, 3),
+                    "simd_cycles_per_wave_permutation": round(cyc, 1), "issue_floor_simd_cycles": None, "frac": None}
+            floor_path = os.path.join(ROOT, "profiles", "r01", "p2_issue_floor.json")
+            if os.path.exists(floor_path):
+                fl = json.load(open(floor_path))
+                view["issue_floor_simd_cycles"] = fl["issue_floor_simd_cycles_per_wave_permutation"]
+                view["valu_instructions_per_permutation"] = fl["valu_instructions_per_permutation"]
+                view["frac"] = round(view["issue_floor_simd_cycles"] / cyc, 4)
+            roofline["valu_view"] = view
         cols = sum(circuit.group_size)
         seg_bytes = (68 * cols + 3132) * (1 << po2)  # Bytes(C) = 68 MiB*C + 3132 MiB at 2^20 rows
         line = {
