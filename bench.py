@@ -196,6 +196,9 @@ def main():
                                   "frac_of_8TBs": round(seg_bytes * value / env.world / 1e9 / HBM_PEAK_GBS, 5)},
             "phases_ms_last_segment": {n: round(ms, 3) for n, ms in phases},
             "kernels_ms_per_segment": {k: round(v["total_ms"] / steps, 3) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
+            # algorithmic bytes / device time of each kernel family (per-kernel achieved GB/s)
+            "kernels_alg_GBs": {k: round(v["alg_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])
+                                if v["total_ms"] > 0 and v.get("alg_bytes")},
         }
         print(json.dumps(line))
     for ln in lanes:
