@@ -74,6 +74,16 @@ _SIGNATURES = {
     "r0h_proof_finish": [_vp, _vp, _vp, _sz, _c.POINTER(_sz)],
     "r0h_proof_abort": [_vp],
     "r0h_verify_seal": [_vp, _sz, _vp, _vp, _vp, _sz, _c.POINTER(_c.c_int), _c.POINTER(_u32)],
+    "r0h_serde_encode_str": [_vp, _sz, _vp, _sz, _c.POINTER(_sz)],
+    "r0h_serde_decode_str": [_vp, _sz, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_sz)],
+    "r0h_journal_commitment_span": [_vp, _sz, _c.POINTER(_sz), _c.POINTER(_sz)],
+    "r0h_receipt_parse": [_vp, _sz, _pp],
+    "r0h_receipt_new": [_c.c_int, _vp, _sz, _pp],
+    "r0h_receipt_add_segment": [_vp, _vp, _sz, _u32],
+    "r0h_receipt_free": [_vp],
+    "r0h_receipt_journal": [_vp, _pp, _c.POINTER(_sz)],
+    "r0h_receipt_segment": [_vp, _sz, _pp, _c.POINTER(_sz), _c.POINTER(_u32)],
+    "r0h_receipt_to_json": [_vp, _pp],
     "r0h_kernel_timing": [_vp, _c.c_int],
     "r0h_kernel_stats": [_vp, _vp, _sz],
     "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],
@@ -81,6 +91,8 @@ _SIGNATURES = {
 _PLAIN = {
     "r0h_free_error": ([_vp], None),
     "r0h_version": ([], _cp),
+    "r0h_receipt_kind": ([_vp], _c.c_int),
+    "r0h_receipt_n_segments": ([_vp], _sz),
     "r0h_verify_reason": ([_c.c_int], _cp),
     "r0h_buf_device_ptr": ([_vp], _vp),
     "r0h_buf_bytes": ([_vp], _sz),
@@ -208,6 +220,93 @@ def verify_seal(blob, seal, poseidon2_consts=None):
     verdict, po2 = _c.c_int(-1), _u32(0)
     _check(lib().r0h_verify_seal(pb, b.size, prc, pdg, ps, s_.size, ctypes.byref(verdict), ctypes.byref(po2)))
     return verdict.value, lib().r0h_verify_reason(verdict.value).decode(), po2.value
+
+
+def serde_encode_str(text):
+    """risc0 serde word stream of a String ([u32 LE length][utf8][zero padding to 4]): ExecutorEnv inputs and journal.bytes."""
+    raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    n = _sz(0)
+    _check(lib().r0h_serde_encode_str(raw, len(raw), None, 0, ctypes.byref(n)))
+    out = (ctypes.c_uint8 * n.value)()
+    _check(lib().r0h_serde_encode_str(raw, len(raw), out, n.value, ctypes.byref(n)))
+    return bytes(out)
+
+
+def serde_decode_str(data):
+    """Inverse of serde_encode_str: returns (bytes of the string, bytes consumed); raises R0HipError on bad framing."""
+    data = bytes(data)
+    off, ln, used = _sz(0), _sz(0), _sz(0)
+    _check(lib().r0h_serde_decode_str(data, len(data), ctypes.byref(off), ctypes.byref(ln), ctypes.byref(used)))
+    return data[off.value:off.value + ln.value], used.value
+
+
+def journal_commitment(data):
+    """The commitment JSON text hyperfridge reads out of journal.bytes: first '{' .. last '}' (host/src/main.rs:258-267)."""
+    data = bytes(data)
+    off, ln = _sz(0), _sz(0)
+    _check(lib().r0h_journal_commitment_span(data, len(data), ctypes.byref(off), ctypes.byref(ln)))
+    return data[off.value:off.value + ln.value]
+
+
+class Receipt:
+    """Receipt JSON envelope (host/src/main.rs:251-252 writes it, verifier/src/main.rs:118-119 reads it)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @classmethod
+    def parse(cls, text):
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        h = _vp()
+        _check(lib().r0h_receipt_parse(raw, len(raw), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def new(cls, journal, seals=None):
+        journal = bytes(journal)
+        h = _vp()
+        _check(lib().r0h_receipt_new(0 if seals is None else 1, journal, len(journal), ctypes.byref(h)))
+        rc = cls(h)
+        for i, seal in enumerate(seals or []):
+            a, pa = _u32arr(seal)
+            _check(lib().r0h_receipt_add_segment(h, pa, a.size, i))
+        return rc
+
+    @property
+    def kind(self):
+        return "Fake" if lib().r0h_receipt_kind(self.handle) == 0 else "Composite"
+
+    @property
+    def journal(self):
+        p, n = _vp(), _sz(0)
+        _check(lib().r0h_receipt_journal(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p, n.value) if n.value else b""
+
+    def seals(self):
+        out = []
+        for i in range(lib().r0h_receipt_n_segments(self.handle)):
+            p, n, idx = _vp(), _sz(0), _u32(0)
+            _check(lib().r0h_receipt_segment(self.handle, i, ctypes.byref(p), ctypes.byref(n), ctypes.byref(idx)))
+            out.append((idx.value, np.frombuffer(ctypes.string_at(p, n.value * 4), dtype=np.uint32).copy()))
+        return out
+
+    def to_json(self):
+        p = _vp()
+        _check(lib().r0h_receipt_to_json(self.handle, ctypes.byref(p)))
+        text = ctypes.cast(p, ctypes.c_char_p).value.decode("utf-8")
+        lib().r0h_free_error(p)
+        return text
+
+    def close(self):
+        if self.handle:
+            lib().r0h_receipt_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Hal:

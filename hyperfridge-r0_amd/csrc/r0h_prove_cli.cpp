@@ -2,7 +2,7 @@
 // witness on the device, prove K segments, print throughput and a digest of the seal.
 // It stands where hyperfridge's `host prove-camt53` stands relative to risc0 (host/src/main.rs:420-423 obtains a prover and
 // calls prove once); everything risc0-specific above the segment prover (executor, receipts) is out of scope.
-//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1]
+//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json --journal text]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,10 +26,10 @@ static void die(const char* what, const char* err) {
 
 int main(int argc, char** argv) {
   if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) {
-    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1]\n%s\n", r0h_version());
+    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json --journal text]\n%s\n", r0h_version());
     return argc < 2 ? 1 : 0;
   }
-  std::string blob_path = argv[1], co_path, seal_out;
+  std::string blob_path = argv[1], co_path, seal_out, receipt_out, journal_text;
   unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
@@ -41,6 +41,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--contexts")) contexts = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--seal-out")) seal_out = argv[i + 1];
     else if (!strcmp(argv[i], "--verify")) verify = (unsigned)atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--receipt-out")) receipt_out = argv[i + 1];
+    else if (!strcmp(argv[i], "--journal")) journal_text = argv[i + 1];
     else { fprintf(stderr, "r0h_prove: unknown option %s\n", argv[i]); return 1; }
   }
   FILE* f = fopen(blob_path.c_str(), "rb");
@@ -58,6 +60,7 @@ int main(int argc, char** argv) {
   struct Lane {
     r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; r0h_buf* code = nullptr; r0h_buf* data = nullptr;
     std::vector<uint32_t> global, seal; size_t words = 0; unsigned proved = 0;
+    std::vector<std::pair<unsigned, std::vector<uint32_t>>> kept;  // (segment index, seal) when a receipt is to be written
   };
   std::vector<Lane> lanes(contexts);
   const size_t n = (size_t)1 << po2;
@@ -77,6 +80,7 @@ int main(int argc, char** argv) {
       if (s >= contexts) CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + s, ln.code, ln.data, ln.global.data()));  // next segment of this lane
       CHECK(r0h_prove_segment(ln.ctx, ln.circ, po2, ln.code, ln.data, ln.global.data(), ln.seal.data(), ln.seal.size(), &ln.words));
       ln.proved++;
+      if (!receipt_out.empty()) ln.kept.emplace_back(s, std::vector<uint32_t>(ln.seal.begin(), ln.seal.begin() + ln.words));
     }
   };
   auto t0 = std::chrono::steady_clock::now();
@@ -99,6 +103,27 @@ int main(int argc, char** argv) {
       if (verdict != R0H_VERIFY_OK) { fprintf(stderr, "r0h_prove: the verifier rejects the seal: %s\n", r0h_verify_reason(verdict)); return 3; }
     }
     fprintf(stderr, "r0h_prove: seals verified\n");
+  }
+  if (!receipt_out.empty()) {
+    // the Receipt JSON `host` writes (host/src/main.rs:251-252, 299-316): all segment seals in order + the journal, which for the
+    // hyperfridge guest is the serde word stream of the committed JSON string (host/src/main.rs:258-267)
+    std::vector<uint8_t> journal(journal_text.size() + 8);
+    size_t jn = 0;
+    CHECK(r0h_serde_encode_str((const uint8_t*)journal_text.data(), journal_text.size(), journal.data(), journal.size(), &jn));
+    r0h_receipt* rc = nullptr;
+    CHECK(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, journal.data(), jn, &rc));
+    for (unsigned s = 0; s < segments; s++) {
+      const Lane& ln = lanes[s % contexts];
+      for (const auto& kv : ln.kept)
+        if (kv.first == s) CHECK(r0h_receipt_add_segment(rc, kv.second.data(), kv.second.size(), s));
+    }
+    char* text = nullptr;
+    CHECK(r0h_receipt_to_json(rc, &text));
+    FILE* o = fopen(receipt_out.c_str(), "wb");
+    if (!o || fwrite(text, 1, strlen(text), o) != strlen(text)) { fprintf(stderr, "r0h_prove: cannot write %s\n", receipt_out.c_str()); return 1; }
+    fclose(o);
+    r0h_free_error(text);
+    CHECK(r0h_receipt_free(rc));
   }
   if (!seal_out.empty()) {
     FILE* o = fopen(seal_out.c_str(), "wb");

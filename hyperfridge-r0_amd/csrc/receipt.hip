@@ -1,0 +1,382 @@
+// Data formats either side of the proving path (host-only, no device work) -- SURVEY.md 8(a) rows a0', a0'', a18:
+//   * the risc0 serde word stream of a String, as `ExecutorEnv::builder().write(&s)` feeds the guest its 13 inputs
+//     (host/src/main.rs:389-417) and as `env::commit(&String)` leaves it in `receipt.journal.bytes`
+//     (`[u32 LE length][utf8][zero padding to 4]`, host/src/main.rs:258-267; fixtures data/test/test.xml-Receipt-*.json);
+//   * hyperfridge's own reading of the commitment: first '{' to last '}' of the journal (host/src/main.rs:258-267,
+//     verifier/src/main.rs:176-185);
+//   * the Receipt JSON envelope `serde_json::to_string(&receipt)` writes and `serde_json::from_slice` reads
+//     (host/src/main.rs:251-252, verifier/src/main.rs:118-119): {"inner": ..., "journal": {"bytes": [...]}}.
+// What the reference's fixtures pin: the envelope with "inner":"Fake" and the journal framing.  The composite layout
+// (segments with seal / index / hashfn) follows risc0-zkvm 3.x as recalled; its claim is written as null ("parity unpinned").
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/r0hip.h"
+#include "internal.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------- a small JSON reader (objects, arrays, strings, integers)
+struct Json {
+  enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+  bool b = false;
+  double num = 0;
+  bool integral = false;
+  uint64_t u = 0;
+  std::string str;
+  std::vector<Json> arr;
+  std::vector<std::pair<std::string, Json>> obj;
+  const Json* get(const char* key) const {
+    if (kind != Obj) return nullptr;
+    for (const auto& kv : obj)
+      if (kv.first == key) return &kv.second;
+    return nullptr;
+  }
+};
+
+struct Parser {
+  const char* p;
+  const char* end;
+  std::string err;
+  int depth = 0;
+  bool fail(const char* what) {
+    if (err.empty()) err = std::string(what) + " at byte " + std::to_string((size_t)(p - start));
+    return false;
+  }
+  const char* start;
+  void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+  bool lit(const char* s) {
+    size_t n = strlen(s);
+    if ((size_t)(end - p) < n || memcmp(p, s, n) != 0) return fail("unexpected token");
+    p += n;
+    return true;
+  }
+  bool string(std::string& out) {
+    if (p >= end || *p != '"') return fail("expected a string");
+    p++;
+    while (p < end && *p != '"') {
+      unsigned char c = (unsigned char)*p++;
+      if (c < 0x20) return fail("control character in string");
+      if (c != '\\') { out.push_back((char)c); continue; }
+      if (p >= end) return fail("truncated escape");
+      char e = *p++;
+      switch (e) {
+        case '"': out.push_back('"'); break;
+        case '\\': out.push_back('\\'); break;
+        case '/': out.push_back('/'); break;
+        case 'b': out.push_back('\b'); break;
+        case 'f': out.push_back('\f'); break;
+        case 'n': out.push_back('\n'); break;
+        case 'r': out.push_back('\r'); break;
+        case 't': out.push_back('\t'); break;
+        case 'u': {
+          if (end - p < 4) return fail("truncated \\u escape");
+          unsigned v = 0;
+          for (int i = 0; i < 4; i++) {
+            char h = *p++;
+            v = v * 16 + (h >= '0' && h <= '9' ? h - '0' : h >= 'a' && h <= 'f' ? h - 'a' + 10 : h >= 'A' && h <= 'F' ? h - 'A' + 10 : 256);
+            if (v >= 0x10000) return fail("bad \\u escape");
+          }
+          if (v >= 0xD800 && v < 0xE000) return fail("surrogate escapes are not supported");
+          if (v < 0x80) out.push_back((char)v);
+          else if (v < 0x800) { out.push_back((char)(0xC0 | (v >> 6))); out.push_back((char)(0x80 | (v & 63))); }
+          else { out.push_back((char)(0xE0 | (v >> 12))); out.push_back((char)(0x80 | ((v >> 6) & 63))); out.push_back((char)(0x80 | (v & 63))); }
+          break;
+        }
+        default: return fail("unknown escape");
+      }
+    }
+    if (p >= end) return fail("unterminated string");
+    p++;
+    return true;
+  }
+  bool value(Json& out) {
+    if (++depth > 64) return fail("nesting too deep");
+    ws();
+    if (p >= end) return fail("unexpected end");
+    bool ok = true;
+    if (*p == '{') {
+      out.kind = Json::Obj;
+      p++;
+      ws();
+      if (p < end && *p == '}') { p++; depth--; return true; }
+      while (ok) {
+        ws();
+        std::string key;
+        if (!string(key)) return false;
+        ws();
+        if (p >= end || *p != ':') return fail("expected ':'");
+        p++;
+        out.obj.emplace_back(key, Json());
+        if (!value(out.obj.back().second)) return false;
+        ws();
+        if (p < end && *p == ',') { p++; continue; }
+        if (p < end && *p == '}') { p++; break; }
+        return fail("expected ',' or '}'");
+      }
+    } else if (*p == '[') {
+      out.kind = Json::Arr;
+      p++;
+      ws();
+      if (p < end && *p == ']') { p++; depth--; return true; }
+      while (ok) {
+        out.arr.emplace_back();
+        if (!value(out.arr.back())) return false;
+        ws();
+        if (p < end && *p == ',') { p++; continue; }
+        if (p < end && *p == ']') { p++; break; }
+        return fail("expected ',' or ']'");
+      }
+    } else if (*p == '"') {
+      out.kind = Json::Str;
+      ok = string(out.str);
+    } else if (*p == 't') { out.kind = Json::Bool; out.b = true; ok = lit("true"); }
+    else if (*p == 'f') { out.kind = Json::Bool; out.b = false; ok = lit("false"); }
+    else if (*p == 'n') { out.kind = Json::Null; ok = lit("null"); }
+    else {
+      const char* s = p;
+      bool neg = p < end && *p == '-';
+      if (neg) p++;
+      if (p >= end || *p < '0' || *p > '9') return fail("unexpected character");
+      uint64_t u = 0;
+      bool integral = !neg, overflow = false;
+      while (p < end && *p >= '0' && *p <= '9') {
+        if (u > (UINT64_MAX - 9) / 10) overflow = true;
+        u = u * 10 + (uint64_t)(*p++ - '0');
+      }
+      if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) {
+        integral = false;
+        while (p < end && (*p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-' || (*p >= '0' && *p <= '9'))) p++;
+      }
+      out.kind = Json::Num;
+      out.integral = integral && !overflow;
+      out.u = u;
+      out.num = strtod(std::string(s, p).c_str(), nullptr);
+    }
+    depth--;
+    return ok;
+  }
+};
+
+}  // namespace
+
+struct r0h_receipt {
+  int kind = R0H_RECEIPT_FAKE;
+  std::vector<uint8_t> journal;
+  struct Segment { std::vector<uint32_t> seal; uint32_t index = 0; std::string hashfn; };
+  std::vector<Segment> segments;
+};
+
+namespace {
+
+const char* u32_array(const Json* j, uint64_t limit, const char* what, std::vector<uint64_t>& out) {
+  R0H_REQUIRE(j && j->kind == Json::Arr, "receipt JSON: %s is not an array", what);
+  out.reserve(j->arr.size());
+  for (const Json& v : j->arr) {
+    R0H_REQUIRE(v.kind == Json::Num && v.integral && v.u <= limit, "receipt JSON: %s holds something other than an integer in [0, %llu]", what,
+                (unsigned long long)limit);
+    out.push_back(v.u);
+  }
+  return nullptr;
+}
+
+const char* parse_receipt(const Json& root, r0h_receipt& rc) {
+  R0H_REQUIRE(root.kind == Json::Obj, "receipt JSON: top level is not an object");
+  const Json* journal = root.get("journal");
+  R0H_REQUIRE(journal && journal->kind == Json::Obj, "receipt JSON: no \"journal\" object");
+  std::vector<uint64_t> bytes;
+  R0H_TRY(u32_array(journal->get("bytes"), 255, "journal.bytes", bytes));
+  rc.journal.assign(bytes.begin(), bytes.end());
+  const Json* inner = root.get("inner");
+  R0H_REQUIRE(inner, "receipt JSON: no \"inner\"");
+  if (inner->kind == Json::Str) {  // unit variant, risc0 0.19 style: "inner":"Fake"
+    R0H_REQUIRE(inner->str == "Fake", "receipt JSON: unsupported inner receipt \"%s\"", inner->str.c_str());
+    rc.kind = R0H_RECEIPT_FAKE;
+    return nullptr;
+  }
+  R0H_REQUIRE(inner->kind == Json::Obj && inner->obj.size() == 1, "receipt JSON: \"inner\" is neither a variant name nor a one-key object");
+  const std::string& variant = inner->obj[0].first;
+  const Json& body = inner->obj[0].second;
+  if (variant == "Fake") { rc.kind = R0H_RECEIPT_FAKE; return nullptr; }
+  R0H_REQUIRE(variant == "Composite", "receipt JSON: unsupported inner receipt \"%s\"", variant.c_str());
+  rc.kind = R0H_RECEIPT_COMPOSITE;
+  const Json* segs = body.get("segments");
+  R0H_REQUIRE(segs && segs->kind == Json::Arr, "receipt JSON: Composite without \"segments\"");
+  for (const Json& s : segs->arr) {
+    R0H_REQUIRE(s.kind == Json::Obj, "receipt JSON: a segment is not an object");
+    r0h_receipt::Segment seg;
+    std::vector<uint64_t> words;
+    R0H_TRY(u32_array(s.get("seal"), 0xffffffffull, "segment.seal", words));
+    seg.seal.assign(words.begin(), words.end());
+    const Json* idx = s.get("index");
+    R0H_REQUIRE(idx && idx->kind == Json::Num && idx->integral && idx->u <= 0xffffffffull, "receipt JSON: segment without an integer \"index\"");
+    seg.index = (uint32_t)idx->u;
+    const Json* hf = s.get("hashfn");
+    R0H_REQUIRE(hf && hf->kind == Json::Str, "receipt JSON: segment without \"hashfn\"");
+    seg.hashfn = hf->str;
+    rc.segments.push_back(std::move(seg));
+  }
+  return nullptr;
+}
+
+void append_escaped(std::string& s, const std::string& v) {
+  for (unsigned char c : v) {
+    if (c == '"' || c == '\\') { s += '\\'; s += (char)c; }
+    else if (c < 0x20) { char tmp[8]; snprintf(tmp, sizeof tmp, "\\u%04x", c); s += tmp; }
+    else s += (char)c;
+  }
+}
+
+void append_u(std::string& s, uint64_t v) {
+  char tmp[24];
+  snprintf(tmp, sizeof tmp, "%llu", (unsigned long long)v);
+  s += tmp;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* r0h_serde_encode_str(const uint8_t* utf8, size_t len, uint8_t* out, size_t capacity, size_t* out_len) {
+  R0H_REQUIRE((utf8 || len == 0) && out_len, "r0h_serde_encode_str: NULL argument");
+  R0H_REQUIRE(len <= 0xffffffffull, "r0h_serde_encode_str: a serde length prefix is 32 bits");
+  const size_t total = 4 + ((len + 3) & ~(size_t)3);
+  *out_len = total;
+  if (!out) return nullptr;  // size query
+  R0H_REQUIRE(capacity >= total, "r0h_serde_encode_str: %zu bytes needed, capacity is %zu", total, capacity);
+  out[0] = (uint8_t)len; out[1] = (uint8_t)(len >> 8); out[2] = (uint8_t)(len >> 16); out[3] = (uint8_t)(len >> 24);
+  if (len) memcpy(out + 4, utf8, len);
+  memset(out + 4 + len, 0, total - 4 - len);
+  return nullptr;
+}
+
+const char* r0h_serde_decode_str(const uint8_t* bytes, size_t n, size_t* str_off, size_t* str_len, size_t* consumed) {
+  R0H_REQUIRE(bytes && str_off && str_len, "r0h_serde_decode_str: NULL argument");
+  R0H_REQUIRE(n >= 4, "serde string: %zu bytes cannot hold the length word", n);
+  const size_t len = (size_t)bytes[0] | ((size_t)bytes[1] << 8) | ((size_t)bytes[2] << 16) | ((size_t)bytes[3] << 24);
+  const size_t total = 4 + ((len + 3) & ~(size_t)3);
+  R0H_REQUIRE(total <= n, "serde string: length word says %zu bytes, only %zu follow", len, n - 4);
+  for (size_t i = 4 + len; i < total; i++) R0H_REQUIRE(bytes[i] == 0, "serde string: non-zero padding byte at offset %zu", i);
+  *str_off = 4;
+  *str_len = len;
+  if (consumed) *consumed = total;
+  return nullptr;
+}
+
+const char* r0h_journal_commitment_span(const uint8_t* bytes, size_t n, size_t* off, size_t* len) {
+  R0H_REQUIRE((bytes || n == 0) && off && len, "r0h_journal_commitment_span: NULL argument");
+  size_t first = 0, last = n;  // the reference's defaults when a brace is missing: position(..).unwrap_or(0), rposition(..).unwrap_or(len)
+  for (size_t i = 0; i < n; i++)
+    if (bytes[i] == '{') { first = i; break; }
+  for (size_t i = n; i-- > 0;)
+    if (bytes[i] == '}') { last = i; break; }
+  R0H_REQUIRE(last < n && first <= last, "journal: no JSON object between the first '{' and the last '}'");
+  *off = first;
+  *len = last - first + 1;
+  return nullptr;
+}
+
+const char* r0h_receipt_parse(const char* json, size_t n, r0h_receipt** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(json && out, "r0h_receipt_parse: NULL argument");
+  Parser ps{json, json + n, std::string(), 0, json};
+  Json root;
+  bool ok = ps.value(root);
+  if (ok) { ps.ws(); if (ps.p != ps.end) ok = ps.fail("trailing characters"); }
+  R0H_REQUIRE(ok, "receipt JSON: %s", ps.err.c_str());
+  std::unique_ptr<r0h_receipt> rc(new r0h_receipt);
+  R0H_TRY(parse_receipt(root, *rc));
+  *out = rc.release();
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_receipt_new(int kind, const uint8_t* journal, size_t journal_len, r0h_receipt** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(out && (journal || journal_len == 0), "r0h_receipt_new: NULL argument");
+  R0H_REQUIRE(kind == R0H_RECEIPT_FAKE || kind == R0H_RECEIPT_COMPOSITE, "r0h_receipt_new: unknown kind %d", kind);
+  r0h_receipt* rc = new r0h_receipt;
+  rc->kind = kind;
+  rc->journal.assign(journal, journal + journal_len);
+  *out = rc;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_receipt_add_segment(r0h_receipt* rc, const uint32_t* seal, size_t seal_words, uint32_t index) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(rc && seal, "r0h_receipt_add_segment: NULL argument");
+  R0H_REQUIRE(rc->kind == R0H_RECEIPT_COMPOSITE, "r0h_receipt_add_segment: a Fake receipt has no segments");
+  r0h_receipt::Segment s;
+  s.seal.assign(seal, seal + seal_words);
+  s.index = index;
+  s.hashfn = "poseidon2";
+  rc->segments.push_back(std::move(s));
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_receipt_free(r0h_receipt* rc) {
+  delete rc;
+  return nullptr;
+}
+
+int r0h_receipt_kind(const r0h_receipt* rc) { return rc ? rc->kind : -1; }
+size_t r0h_receipt_n_segments(const r0h_receipt* rc) { return rc ? rc->segments.size() : 0; }
+
+const char* r0h_receipt_journal(const r0h_receipt* rc, const uint8_t** bytes, size_t* n) {
+  R0H_REQUIRE(rc && bytes && n, "r0h_receipt_journal: NULL argument");
+  *bytes = rc->journal.data();
+  *n = rc->journal.size();
+  return nullptr;
+}
+
+const char* r0h_receipt_segment(const r0h_receipt* rc, size_t i, const uint32_t** seal, size_t* seal_words, uint32_t* index) {
+  R0H_REQUIRE(rc && seal && seal_words, "r0h_receipt_segment: NULL argument");
+  R0H_REQUIRE(i < rc->segments.size(), "r0h_receipt_segment: segment %zu of %zu", i, rc->segments.size());
+  *seal = rc->segments[i].seal.data();
+  *seal_words = rc->segments[i].seal.size();
+  if (index) *index = rc->segments[i].index;
+  return nullptr;
+}
+
+// serde_json's compact form (no spaces, keys in struct order): byte-identical to the reference's fixtures for Fake receipts
+const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(rc && json_out, "r0h_receipt_to_json: NULL argument");
+  std::string s = "{\"inner\":";
+  if (rc->kind == R0H_RECEIPT_FAKE) {
+    s += "\"Fake\"";
+  } else {
+    s += "{\"Composite\":{\"segments\":[";
+    for (size_t i = 0; i < rc->segments.size(); i++) {
+      const r0h_receipt::Segment& g = rc->segments[i];
+      if (i) s += ',';
+      s += "{\"seal\":[";
+      for (size_t w = 0; w < g.seal.size(); w++) { if (w) s += ','; append_u(s, g.seal[w]); }
+      s += "],\"index\":";
+      append_u(s, g.index);
+      s += ",\"hashfn\":\"";
+      append_escaped(s, g.hashfn);
+      s += "\",\"verifier_parameters\":[0,0,0,0,0,0,0,0],\"claim\":null}";
+    }
+    s += "],\"assumption_receipts\":[],\"verifier_parameters\":[0,0,0,0,0,0,0,0]}}";
+  }
+  s += ",\"journal\":{\"bytes\":[";
+  for (size_t i = 0; i < rc->journal.size(); i++) { if (i) s += ','; append_u(s, rc->journal[i]); }
+  s += "]}}";
+  char* out = (char*)malloc(s.size() + 1);
+  R0H_REQUIRE(out, "r0h_receipt_to_json: out of memory");
+  memcpy(out, s.c_str(), s.size() + 1);
+  *json_out = out;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+}  // extern "C"

@@ -162,6 +162,31 @@ const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint3
                             uint32_t* po2_out);
 const char* r0h_verify_reason(int verdict); /* static string, do not free */
 
+/* ---- data formats either side of the path (SURVEY.md 8(a) a0', a0'', a18): pure host code ----
+ * serde word stream of a String: [u32 LE length][utf8][zero padding to 4] -- what `ExecutorEnv::builder().write(&s)` feeds the
+ * guest (host/src/main.rs:389-417) and what `env::commit(&String)` leaves in `receipt.journal.bytes` (host/src/main.rs:258-267).
+ * r0h_serde_encode_str with out == NULL only reports the size. */
+const char* r0h_serde_encode_str(const uint8_t* utf8, size_t len, uint8_t* out, size_t capacity, size_t* out_len);
+const char* r0h_serde_decode_str(const uint8_t* bytes, size_t n, size_t* str_off, size_t* str_len, size_t* consumed /* may be NULL */);
+/* hyperfridge's reading of the commitment in a journal: first '{' .. last '}' (host/src/main.rs:258-267, verifier/src/main.rs:176-185) */
+const char* r0h_journal_commitment_span(const uint8_t* bytes, size_t n, size_t* off, size_t* len);
+/* Receipt JSON envelope as `serde_json::to_string(&receipt)` writes it (host/src/main.rs:251-252) and
+ * `serde_json::from_slice` reads it (verifier/src/main.rs:118-119): {"inner": "Fake" | {"Fake": ..} | {"Composite": {"segments":
+ * [{"seal": [u32..], "index": n, "hashfn": ".."}, ..]}}, "journal": {"bytes": [u8..]}}.  r0h_receipt_to_json's output is
+ * serde_json's compact form (caller frees it with r0h_free_error). */
+#define R0H_RECEIPT_FAKE 0
+#define R0H_RECEIPT_COMPOSITE 1
+typedef struct r0h_receipt r0h_receipt;
+const char* r0h_receipt_parse(const char* json, size_t n, r0h_receipt** out);
+const char* r0h_receipt_new(int kind, const uint8_t* journal, size_t journal_len, r0h_receipt** out);
+const char* r0h_receipt_add_segment(r0h_receipt* rc, const uint32_t* seal, size_t seal_words, uint32_t index);
+const char* r0h_receipt_free(r0h_receipt* rc);
+int r0h_receipt_kind(const r0h_receipt* rc);
+size_t r0h_receipt_n_segments(const r0h_receipt* rc);
+const char* r0h_receipt_journal(const r0h_receipt* rc, const uint8_t** bytes, size_t* n);
+const char* r0h_receipt_segment(const r0h_receipt* rc, size_t i, const uint32_t** seal, size_t* seal_words, uint32_t* index);
+const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out);
+
 /* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
  * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */
 const char* r0h_kernel_timing(r0h_ctx* ctx, int enable);
