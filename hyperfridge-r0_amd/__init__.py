@@ -67,6 +67,8 @@ _SIGNATURES = {
     "r0h_circuit_load": [_vp, _vp, _sz, _cp, _pp],
     "r0h_circuit_free": [_vp],
     "r0h_witgen": [_vp, _vp, _u32, _u64, _vp, _vp, _vp],
+    "r0h_witgen_public": [_vp, _vp, _u32, _u64, _vp, _vp, _vp],
+    "r0h_seal_digest": [_vp, _sz, _vp],
     "r0h_accum": [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
     "r0h_eval_check": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "r0h_prove_segment": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)],
@@ -248,6 +250,14 @@ def journal_commitment(data):
     return data[off.value:off.value + ln.value]
 
 
+def seal_digest(seal):
+    """8-word Poseidon2 name of a seal (r0h_seal_digest): what a recursion step's public inputs carry."""
+    a, pa = _u32arr(seal)
+    out = np.zeros(8, dtype=np.uint32)
+    _check(lib().r0h_seal_digest(pa, a.size, out.ctypes.data_as(_vp)))
+    return out
+
+
 class Receipt:
     """Receipt JSON envelope (host/src/main.rs:251-252 writes it, verifier/src/main.rs:118-119 reads it)."""
 
@@ -425,10 +435,17 @@ class Hal:
         _check(lib().r0h_circuit_load(self.ctx, p, a.size, path, ctypes.byref(h)))
         return Circuit(self, h, a)
 
-    def witgen(self, circuit, po2, seed):
+    def witgen(self, circuit, po2, seed, globals_in=None):
+        """Synthetic witness; with globals_in the caller's public inputs are planted (r0h_witgen_public)."""
         n = 1 << po2
         code = self.alloc(circuit.group_size[GROUP_CODE] * n)
         data = self.alloc(circuit.group_size[GROUP_DATA] * n)
+        if globals_in is not None:
+            g, pg = _u32arr(globals_in)
+            if g.size != circuit.n_global:
+                raise R0HipError("witgen: %d public inputs given, the circuit has %d" % (g.size, circuit.n_global))
+            _check(lib().r0h_witgen_public(self.ctx, circuit.handle, po2, seed, pg, code.handle, data.handle))
+            return code, data, g.copy()
         glob = np.zeros(max(circuit.n_global, 1), dtype=np.uint32)
         _check(lib().r0h_witgen(self.ctx, circuit.handle, po2, seed, code.handle, data.handle, glob.ctypes.data_as(_vp)))
         return code, data, glob[:circuit.n_global]

@@ -532,7 +532,8 @@ uint32_t r0h_circuit_n_global(const r0h_circuit* c) { return c ? c->n_global : 0
 uint32_t r0h_circuit_n_mix(const r0h_circuit* c) { return c ? c->n_mix : 0; }
 uint32_t r0h_circuit_n_taps(const r0h_circuit* c) { return c ? (uint32_t)c->taps.size() : 0; }
 
-const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, r0h_buf* code, r0h_buf* data, uint32_t* global_out) {
+static const char* witgen_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, const uint32_t* global_in, r0h_buf* code,
+                               r0h_buf* data, uint32_t* global_out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && c && code && data, "r0h_witgen: NULL argument");
   R0H_REQUIRE(c->has_column_program, "r0h_witgen: this circuit carries no synthetic column program (WITGEN/ACCUM sections); supply the witness");
@@ -547,6 +548,12 @@ const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_
   const uint32_t* dk = (const uint32_t*)ctx->scratch;
   hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nc), dim3(threads), 0, ctx->stream, u32(code), dk, po2, splitmix64_host(0xC0DEull));
   hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nd), dim3(threads), 0, ctx->stream, u32(data), dk + 2 * nc, po2, splitmix64_host(seed));
+  if (global_in) {  // caller-chosen public inputs: row 0 of the (free) columns the globals are read from, before anything is derived from them
+    for (uint32_t k = 0; k < c->n_global; k++) {
+      R0H_REQUIRE(global_in[k] < P, "r0h_witgen_public: global %u is not a canonical field word", k);
+      R0H_TRY(stage_h2d(ctx, u32(data) + ((size_t)c->global_cols[k] << po2), global_in + k, 4));
+    }
+  }
   for (uint32_t k = 0; k < nd; k++) {
     const DataCol& d = c->data_cols[k];
     if (d.kind == 0) continue;
@@ -565,6 +572,15 @@ const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_
   R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
   return nullptr;
   R0H_GUARD_END
+}
+
+const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, r0h_buf* code, r0h_buf* data, uint32_t* global_out) {
+  return witgen_impl(ctx, c, po2, seed, nullptr, code, data, global_out);
+}
+
+const char* r0h_witgen_public(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, const uint32_t* global_in, r0h_buf* code, r0h_buf* data) {
+  R0H_REQUIRE(global_in || r0h_circuit_n_global(c) == 0, "r0h_witgen_public: global_in is NULL");
+  return witgen_impl(ctx, c, po2, seed, global_in, code, data, nullptr);
 }
 
 const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data, const uint32_t* mix, r0h_buf* accum) {

@@ -321,6 +321,18 @@ const char* r0h_verify_reason(int verdict) {
   return verdict >= 0 && verdict <= R0H_VERIFY_BAD_ELEM ? names[verdict] : "unknown";
 }
 
+const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t digest_out[8]) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE((seal || seal_words == 0) && digest_out, "r0h_seal_digest: NULL argument");
+  std::unique_ptr<P2Consts> k(new P2Consts);
+  p2_default_host(*k);
+  std::vector<uint32_t> elems(seal, seal + seal_words);
+  for (uint32_t& w : elems) w %= P;  // a seal's words are field words or 32-bit indices/positions; the sponge absorbs field words
+  p2_hash_elems_host(*k, elems.data(), elems.size(), digest_out);
+  return nullptr;
+  R0H_GUARD_END
+}
+
 const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
                             const uint32_t* seal, size_t seal_words, int* verdict_out, uint32_t* po2_out) {
   R0H_GUARD_BEGIN

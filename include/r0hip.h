@@ -116,6 +116,11 @@ uint32_t r0h_circuit_n_mix(const r0h_circuit* c);
 uint32_t r0h_circuit_n_taps(const r0h_circuit* c);
 const char* r0h_witgen(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, r0h_buf* code, r0h_buf* data,
                        uint32_t* global_out_host);
+/* the same with the public inputs chosen by the caller: global_in[k] (a canonical Montgomery word) is planted at row 0 of the
+ * column global k is read from, before the dependent columns are derived -- how a recursion-shaped segment is bound to the
+ * digests of the seals it stands for (hyperfridge-r0_amd/recursion.py) */
+const char* r0h_witgen_public(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, const uint32_t* global_in_host,
+                              r0h_buf* code, r0h_buf* data);
 const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
                       const uint32_t* mix_host, r0h_buf* accum);
 const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* eval_accum,
@@ -161,6 +166,8 @@ const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint3
                             const uint32_t* p2_diag_m1, const uint32_t* seal, size_t seal_words, int* verdict_out,
                             uint32_t* po2_out);
 const char* r0h_verify_reason(int verdict); /* static string, do not free */
+/* Poseidon2 sponge (compiled-in table) over a seal's words, each taken mod p: the 8-word name a recursion step commits to */
+const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t digest_out[8]);
 
 /* ---- data formats either side of the path (SURVEY.md 8(a) a0', a0'', a18): pure host code ----
  * serde word stream of a String: [u32 LE length][utf8][zero padding to 4] -- what `ExecutorEnv::builder().write(&s)` feeds the

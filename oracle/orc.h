@@ -89,6 +89,8 @@ uint32_t orc_circuit_n_global(const orc_circuit_t* c);
 uint32_t orc_circuit_n_mix(const orc_circuit_t* c);
 uint32_t orc_circuit_n_combos(const orc_circuit_t* c);
 void orc_witgen(const orc_circuit_t* c, uint32_t po2, uint64_t seed, uint32_t* code, uint32_t* data, uint32_t* global);
+void orc_witgen_public(const orc_circuit_t* c, uint32_t po2, uint64_t seed, const uint32_t* global_in, uint32_t* code, uint32_t* data,
+                       uint32_t* global);
 void orc_accum(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, const uint32_t* mix,
                uint32_t* accum);
 void orc_eval_check(const orc_circuit_t* c, uint32_t po2, const uint32_t* eval_accum, const uint32_t* eval_code,

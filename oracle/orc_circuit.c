@@ -145,6 +145,12 @@ static inline fp_t synth_word(uint64_t seed, uint32_t stream, uint32_t row) {
 #define CODE_SEED 0xC0DEull
 
 void orc_witgen(const orc_circuit_t* c, uint32_t po2, uint64_t seed, uint32_t* code, uint32_t* data, uint32_t* global) {
+  orc_witgen_public(c, po2, seed, NULL, code, data, global);
+}
+
+/* global_in != NULL: the caller's public inputs are planted at row 0 of the columns the globals are read from */
+void orc_witgen_public(const orc_circuit_t* c, uint32_t po2, uint64_t seed, const uint32_t* global_in, uint32_t* code, uint32_t* data,
+                       uint32_t* global) {
   size_t n = (size_t)1 << po2;
   for (uint32_t k = 0; k < c->n_code; k++) {
     fp_t* col = code + (size_t)k * n;
@@ -165,6 +171,9 @@ void orc_witgen(const orc_circuit_t* c, uint32_t po2, uint64_t seed, uint32_t* c
     if (d->kind == 0) {
 #pragma omp parallel for
       for (size_t r = 0; r < n; r++) col[r] = synth_word(seed, (2u << 16) | k, (uint32_t)r);
+      if (global_in)
+        for (uint32_t g = 0; g < c->n_global; g++)
+          if (c->global_cols[g] == k) col[0] = global_in[g];
       continue;
     }
     const uint32_t refs[4] = {d->a, d->b, d->c, d->e};

@@ -43,6 +43,7 @@ class Oracle:
         L.orc_verify_segment.argtypes = [_vp, _vp, _sz, _vp, _sz]
         L.orc_verify_strerror.restype = ctypes.c_char_p
         L.orc_witgen.argtypes = [_vp, _u32, _u64, _vp, _vp, _vp]
+        L.orc_witgen_public.argtypes = [_vp, _u32, _u64, _vp, _vp, _vp, _vp]
         L.orc_accum.argtypes = [_vp, _u32, _vp, _vp, _vp, _vp]
         L.orc_eval_check.argtypes = [_vp, _u32] + [_vp] * 7
         L.orc_poly_ext.argtypes = [_vp] * 6
@@ -207,11 +208,16 @@ class OrcCircuit:
         self.n_taps, self.n_global = L.orc_circuit_n_taps(self.h), L.orc_circuit_n_global(self.h)
         self.n_mix, self.n_combos = L.orc_circuit_n_mix(self.h), L.orc_circuit_n_combos(self.h)
 
-    def witgen(self, po2, seed):
+    def witgen(self, po2, seed, globals_in=None):
         n = 1 << po2
         code, data = np.zeros(self.group_size[1] * n, np.uint32), np.zeros(self.group_size[2] * n, np.uint32)
         glob = np.zeros(max(self.n_global, 1), np.uint32)
-        self.o.L.orc_witgen(self.h, po2, seed, _ptr(code), _ptr(data), _ptr(glob))
+        if globals_in is not None:
+            gin = u32(globals_in)
+            assert gin.size == self.n_global
+            self.o.L.orc_witgen_public(self.h, po2, seed, _ptr(gin), _ptr(code), _ptr(data), _ptr(glob))
+        else:
+            self.o.L.orc_witgen(self.h, po2, seed, _ptr(code), _ptr(data), _ptr(glob))
         return code, data, glob[:self.n_global]
 
     def accum(self, po2, code, data, mix):

@@ -1,0 +1,144 @@
+"""lift + join tree (hyperfridge-r0_amd/recursion.py; SURVEY.md 8(a) a19, 8(e), BASELINE.json configs[4]): the schedule and
+the point-to-point exchange are checked on CPU (in-process and with two gloo ranks); the proofs themselves on the GPU, against
+the oracle, with a recursion-shaped circuit (risc0's own recursion circuit cannot be reproduced: see recursion.py)."""
+import hashlib
+import os
+import queue
+import threading
+
+import numpy as np
+import pytest
+
+import hyperfridge_r0_amd as r0
+from hyperfridge_r0_amd import recursion
+from conftest import ROOT, circuit_path
+
+P = 2013265921
+
+
+def _blob(name):
+    return np.fromfile(circuit_path(name), dtype=np.uint32)
+
+
+@pytest.mark.parametrize("world", range(1, 10))
+def test_tree_schedule_is_a_binary_join_tree(world):
+    plan = recursion.tree_schedule(world)
+    assert len(plan) == world - 1  # one join per hand-over
+    senders = [s for _, _, s in plan]
+    assert sorted(senders) == list(range(1, world))  # every rank but 0 hands its subtree up exactly once
+    alive = set(range(world))
+    for level, receiver, sender in plan:
+        assert receiver < sender and sender - receiver == 1 << level and receiver in alive and sender in alive
+        alive.discard(sender)
+    assert alive == {0}
+    assert max([lvl for lvl, _, _ in plan], default=-1) + 1 == (world - 1).bit_length()
+
+
+class _HashRecursor:
+    """Stand-in prover for the transport tests: a 'seal' is 8 words of SHA-256 over its children."""
+
+    @staticmethod
+    def leaf(i):
+        return recursion.Node(np.frombuffer(hashlib.sha256(b"leaf%d" % i).digest(), dtype=np.uint32), None, None)
+
+    def join(self, a, b):
+        return recursion.Node(np.frombuffer(hashlib.sha256(a.seal.tobytes() + b.seal.tobytes()).digest(), dtype=np.uint32), a.seal, b.seal)
+
+
+def _expected_root(world):
+    rec, nodes = _HashRecursor(), {r: _HashRecursor.leaf(r) for r in range(world)}
+    for _, receiver, sender in recursion.tree_schedule(world):
+        nodes[receiver] = rec.join(nodes[receiver], nodes.pop(sender))
+    return nodes[0].seal
+
+
+@pytest.mark.parametrize("world", [1, 2, 5, 8])
+def test_join_across_ranks_with_an_in_memory_transport(world):
+    boxes = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+    results = [None] * world
+
+    def run(rank):
+        send = lambda words, dst: boxes[(rank, dst)].put(words.copy())
+        recv = lambda src: boxes[(src, rank)].get(timeout=10)
+        results[rank] = recursion.join_across_ranks(_HashRecursor(), _HashRecursor.leaf(rank), rank, world, send, recv)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(20) for t in threads]
+    assert all(r is None for r in results[1:]) and np.array_equal(results[0].seal, _expected_root(world))
+
+
+def _gloo_rank(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        send, recv = recursion.torch_transport()
+        root = recursion.join_across_ranks(_HashRecursor(), _HashRecursor.leaf(rank), rank, world, send, recv)
+        if rank == 0:
+            out.put(root.seal.tolist())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_exchange_seals_point_to_point():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_rank, args=(r, 2, 29533, out)) for r in range(2)]
+    [p.start() for p in procs]
+    got = out.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got == _expected_root(2).tolist()
+
+
+def test_oracle_public_inputs_are_planted_and_committed(orc):
+    """orc_witgen_public: the witness still satisfies the circuit, and the seal opens with exactly those 16 words."""
+    blob = _blob("recursion")
+    c = orc.circuit(blob)
+    public = (np.arange(16, dtype=np.uint64) * 123456789 % P).astype(np.uint32)
+    code, data, glob = c.witgen(10, 5, globals_in=public)
+    assert np.array_equal(glob, public)
+    seal = c.prove(10, code, data, glob)
+    assert c.verify(seal) == (0, "ok") and r0.verify_seal(blob, seal) == (0, "ok", 10)
+    assert np.array_equal(seal[:16], public)
+    forged = seal.copy()
+    forged[3] = (int(forged[3]) + 1) % P  # claim another digest: the transcript no longer matches
+    assert c.verify(forged)[0] != 0 and r0.verify_seal(blob, forged)[0] != 0
+    assert r0.seal_digest(seal).tolist() == orc.hash_elem_slice(seal % P).tolist()
+
+
+@pytest.mark.gpu
+def test_lift_and_join_on_the_device(hal, orc):
+    seg_blob, rec_blob = _blob("small"), _blob("recursion")
+    seg = hal.load_circuit(seg_blob)
+    seals = []
+    for seed in (1, 2, 3):
+        code, data, glob = hal.witgen(seg, 10, seed)
+        seals.append(hal.prove_segment(seg, 10, code, data, glob))
+    rec = recursion.Recursor(hal, rec_blob, seg_blob, po2=12)
+    lifted = [rec.lift(s) for s in seals]
+    oc = orc.circuit(rec_blob)
+    for node, s in zip(lifted, seals):
+        assert np.array_equal(node.left, r0.seal_digest(s)) and not node.right.any()
+        left, right = recursion.public_inputs_of(rec_blob, node.seal)
+        assert np.array_equal(left, node.left) and np.array_equal(right, node.right)
+        assert r0.verify_seal(rec_blob, node.seal) == (0, "ok", 12) and oc.verify(node.seal) == (0, "ok")
+    # bit-exact against the oracle proving the same step
+    public = np.concatenate([lifted[0].left, lifted[0].right])
+    seed = int(public[0]) | (int(public[8]) << 32)
+    ocode, odata, oglob = oc.witgen(12, seed, globals_in=public)
+    assert np.array_equal(oc.prove(12, ocode, odata, oglob), lifted[0].seal)
+    root = rec.fold(lifted)  # join(join(l0, l1), l2)
+    assert r0.verify_seal(rec_blob, root.seal)[0] == 0 and oc.verify(root.seal) == (0, "ok")
+    inner = rec.join(lifted[0], lifted[1])
+    assert np.array_equal(root.left, r0.seal_digest(inner.seal)) and np.array_equal(root.right, lifted[2].digest)
+    bad = seals[0].copy()
+    bad[-1] ^= 1
+    with pytest.raises(r0.R0HipError, match="does not verify"):
+        rec.lift(bad)
+    with pytest.raises(r0.R0HipError, match="does not verify"):
+        rec.join(lifted[0], seals[1])  # a segment seal is not a recursion seal
+    rec.close()

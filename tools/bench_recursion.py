@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] in shape: every rank proves its share of segments, lifts each seal, folds its own nodes, and the
+ranks join pairwise up a binary tree over torch.distributed point-to-point (RCCL on a GPU node).  Rank 0 prints one JSON
+line with the tree latency.  The recursion circuit is recursion-SHAPED only (hyperfridge-r0_amd/recursion.py): the seals a
+step consumes are checked by the host-side verifier beside the proof, not inside it.
+
+  python tools/bench_recursion.py --segments 8                                    one GPU, whole tree in-process
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         tools/bench_recursion.py --segments 64 [--backend gloo --share-device]    N ranks, segments sharded
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--segments", type=int, default=8, help="segment seals over all ranks")
+    ap.add_argument("--segment-po2", type=int, default=20)
+    ap.add_argument("--recursion-po2", type=int, default=18)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal on a one-GPU box; needs --backend gloo)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as entry
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if local == 0:
+        entry.ensure_built()
+    device = 0 if args.share_device else local
+    torch.cuda.set_device(device)
+    torch.zeros(1, device="cuda")  # torch initialises HIP before libr0hip.so is loaded
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", device) if args.backend == "nccl" else None)
+    import hyperfridge_r0_amd as r0
+    from hyperfridge_r0_amd import driver, recursion
+
+    hal = r0.Hal(device)
+    seg_blob = np.fromfile(entry.circuit_blob_path("bench"), dtype=np.uint32)
+    rec_blob = np.fromfile(entry.circuit_blob_path("recursion"), dtype=np.uint32)
+    seg = hal.load_circuit(seg_blob, entry.code_object_path("bench"))
+    rec = recursion.Recursor(hal, rec_blob, seg_blob, entry.code_object_path("recursion"), po2=args.recursion_po2)
+    mine = driver.shard_segments(args.segments, world, rank)
+
+    def barrier():
+        hal.sync()
+        if world > 1:
+            dist.barrier()
+
+    # warm-up: one of everything (code objects loaded, pools filled)
+    code, data, glob = hal.witgen(seg, args.segment_po2, 999)
+    warm = hal.prove_segment(seg, args.segment_po2, code, data, glob)
+    rec.join(rec.lift(warm), rec.lift(warm))
+
+    barrier()
+    t0 = time.perf_counter()
+    seals = []
+    for s in mine:
+        c2, d2, g2 = hal.witgen(seg, args.segment_po2, 1000 + s)
+        seals.append(hal.prove_segment(seg, args.segment_po2, c2, d2, g2))
+        c2.free(); d2.free()
+    barrier()
+    t1 = time.perf_counter()
+    nodes = [rec.lift(s) for s in seals]
+    node = rec.fold(nodes) if nodes else None
+    barrier()
+    t2 = time.perf_counter()
+    if world > 1:
+        send, recv = recursion.torch_transport(torch.device("cuda", device))
+        node = recursion.join_across_ranks(rec, node, rank, world, send, recv)
+    barrier()
+    t3 = time.perf_counter()
+    if rank == 0:
+        verdict = r0.verify_seal(rec_blob, node.seal)
+        steps = len(recursion.tree_schedule(world))
+        print(json.dumps({
+            "metric": "lift+join tree over segment seals (configs[4] in shape; recursion-shaped circuit, see hyperfridge-r0_amd/recursion.py)",
+            "n_gpus": world, "segments": args.segments, "segment_po2": args.segment_po2, "recursion_po2": args.recursion_po2,
+            "prove_segments_s": round(t1 - t0, 4), "lift_and_local_fold_s": round(t2 - t1, 4), "cross_rank_joins_s": round(t3 - t2, 4),
+            "cross_rank_join_steps": steps, "tree_latency_s": round(t3 - t1, 4), "end_to_end_s": round(t3 - t0, 4),
+            "root_verifies": verdict[0] == 0, "root_seal_words": int(node.seal.size), "backend": args.backend if world > 1 else "none",
+            "data": "synthetic"}))
+    code.free(); data.free()
+    rec.close(); seg.free()
+    hal.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

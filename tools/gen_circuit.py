@@ -12,6 +12,7 @@ Shapes:
   tiny   W=(8 accum, 4 code, 12 data)      unit tests (CPU oracle in milliseconds)
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
+  recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
 """
 import argparse
 import struct
@@ -248,6 +249,9 @@ SHAPES = {
     "tiny": dict(n_code=4, n_data=12, n_acc=2, n_free=4, n_pad=6, n_global=2, seed=1, comp=6),
     "small": dict(n_code=8, n_data=40, n_acc=4, n_free=8, n_pad=60, n_global=4, seed=2, comp=10),
     "bench": dict(n_code=16, n_data=192, n_acc=12, n_free=24, n_pad=2600, n_global=8, seed=3, comp=16),
+    # recursion-SHAPED: a smaller trace (proved at po2 = 18) whose 16 public inputs carry the two 8-word digests a lift/join step
+    # stands for (hyperfridge-r0_amd/recursion.py).  It does not verify seals in-circuit: risc0's recursion circuit is not reproducible here.
+    "recursion": dict(n_code=8, n_data=96, n_acc=6, n_free=20, n_pad=900, n_global=16, seed=4, comp=12),
 }
 
 
