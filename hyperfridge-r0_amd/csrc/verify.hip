@@ -7,12 +7,26 @@
 #include "circuit.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
+#include <thread>
 
 namespace r0h {
 namespace {
 
 struct Reject { int code; };  // unwinds the verifier; never crosses the C ABI
+
+// A position in the seal; the queries each get their own (their openings have a fixed size, so query q starts at a known word).
+struct Cursor {
+  const uint32_t* w;
+  size_t n, pos;
+  const uint32_t* take(size_t count) {
+    if (count > n - pos) throw Reject{R0H_VERIFY_TRUNCATED};
+    const uint32_t* p = w + pos;
+    pos += count;
+    return p;
+  }
+};
 
 class SealReader {
  public:
@@ -30,6 +44,8 @@ class SealReader {
     return p;
   }
   bool exhausted() const { return pos_ == n_; }
+  Cursor cursor() const { return Cursor{w_, n_, pos_}; }
+  void skip_to(size_t pos) { pos_ = pos < n_ ? pos : n_; }
   void commit(const uint32_t digest[8]) {
     if (used_ != 0) { p2_mix_host(k_, cells_); used_ = 0; }
     for (int i = 0; i < 8; i++) cells_[i] = add(cells_[i], digest[i] % P);
@@ -87,23 +103,25 @@ class TreeVerifier {
     io.commit(&top_[8]);
   }
   // the opened row (cols_ canonical words) if its path leads to the committed top layer
-  const uint32_t* open(SealReader& io, size_t row) const {
+  const uint32_t* open(Cursor& io, const P2Consts& k, size_t row) const {
     if (row >= rows_) throw Reject{reject_};
     const uint32_t* values = io.take(cols_);
     for (size_t i = 0; i < cols_; i++)
       if (values[i] >= P) throw Reject{reject_};
     uint32_t cur[8];
-    p2_hash_elems_host(io.consts(), values, cols_, cur);
+    p2_hash_elems_host(k, values, cols_, cur);
     size_t node = row + rows_;
     for (; node >= 2 * top_size_; node >>= 1) {
       const uint32_t* sibling = io.take(8);
       uint32_t parent[8];
-      if (node & 1) hash_pair(io.consts(), sibling, cur, parent); else hash_pair(io.consts(), cur, sibling, parent);
+      if (node & 1) hash_pair(k, sibling, cur, parent); else hash_pair(k, cur, sibling, parent);
       memcpy(cur, parent, 32);
     }
     if (memcmp(&top_[node * 8], cur, 32) != 0) throw Reject{reject_};
     return values;
   }
+
+  size_t opening_words() const { return cols_ + 8 * (log2_exact(rows_) - log2_exact(top_size_)); }
 
  private:
   size_t rows_, cols_, top_size_ = 1;
@@ -258,13 +276,21 @@ void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_
       for (uint32_t kq = 0; kq < R0H_FRI_FOLD; kq++) idft[j][kq] = mul(inv16, fpow(zeta_inv, (uint64_t)j * kq));
   }
   const uint32_t w_domain = rou_fwd(log2_exact(domain)), w_final = rou_fwd(log2_exact(dom));
-  std::vector<Fp4> combo_tot(n_combos + 1);
-  for (uint32_t q = 0; q < R0H_QUERIES; q++) {
-    size_t pos = io.bits(log2_exact(domain)) % domain;
+  // The query positions depend only on the transcript, and every query's openings have the same size: the 50 queries are
+  // independent and run on a few host threads.  The verdict is that of the first failing query, as in a sequential walk.
+  size_t pos_of[R0H_QUERIES];
+  for (uint32_t q = 0; q < R0H_QUERIES; q++) pos_of[q] = io.bits(log2_exact(domain)) % domain;
+  size_t words_per_query = 0;
+  for (int g = 0; g < 4; g++) words_per_query += group[g]->opening_words();
+  for (const Round& rd : rounds) words_per_query += rd.tree->opening_words();
+  const Cursor base = io.cursor();
+  auto one_query = [&](uint32_t q) {
+    Cursor cur{base.w, base.n, base.pos + (size_t)q * words_per_query < base.n ? base.pos + (size_t)q * words_per_query : base.n};
+    std::vector<Fp4> combo_tot(n_combos + 1, fp4_zero());
+    size_t pos = pos_of[q];
     const uint32_t* row[4];
-    for (int g = 0; g < 4; g++) row[g] = group[g]->open(io, pos);
+    for (int g = 0; g < 4; g++) row[g] = group[g]->open(cur, k, pos);
     const Fp4 x = lift(fpow(w_domain, pos));
-    std::fill(combo_tot.begin(), combo_tot.end(), fp4_zero());
     for (uint32_t r = 0; r < n_regs; r++) {
       Fp4& t = combo_tot[c.regs[r].combo];
       t = t + scale(reg_weight[r], row[c.regs[r].group][c.regs[r].offset]);
@@ -282,7 +308,7 @@ void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_
     size_t rows_above = domain;
     for (const Round& rd : rounds) {
       const size_t quot = pos / rd.rows, grp = pos % rd.rows;
-      const uint32_t* col = rd.tree->open(io, grp);
+      const uint32_t* col = rd.tree->open(cur, k, grp);
       Fp4 v[R0H_FRI_FOLD];
       for (uint32_t i = 0; i < R0H_FRI_FOLD; i++)
         for (int e = 0; e < 4; e++) v[i].e[e] = col[e * R0H_FRI_FOLD + i];
@@ -303,7 +329,24 @@ void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_
       rows_above = rd.rows;
     }
     if (!(horner(final_poly.data(), degree, lift(fpow(w_final, pos))) == goal)) throw Reject{R0H_VERIFY_FRI_FINAL};
-  }
+  };
+  int verdict_of[R0H_QUERIES];
+  std::atomic<uint32_t> next{0};
+  auto worker = [&]() {
+    for (uint32_t q; (q = next.fetch_add(1)) < R0H_QUERIES;) {
+      try { one_query(q); verdict_of[q] = R0H_VERIFY_OK; }
+      catch (const Reject& r) { verdict_of[q] = r.code; }
+    }
+  };
+  unsigned n_threads = std::thread::hardware_concurrency();
+  n_threads = n_threads < 1 ? 1 : n_threads > 16 ? 16 : n_threads;
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(worker);
+  worker();
+  for (std::thread& t : pool) t.join();
+  for (uint32_t q = 0; q < R0H_QUERIES; q++)
+    if (verdict_of[q] != R0H_VERIFY_OK) throw Reject{verdict_of[q]};
+  io.skip_to(base.pos + (size_t)R0H_QUERIES * words_per_query);
   if (!io.exhausted()) throw Reject{R0H_VERIFY_TRAILING};
 }
 
