@@ -35,6 +35,27 @@ OP2(SubCoCnd, "v_sub_co_u32 %0, vcc, %1, %2\n v_cndmask_b32 %0, %0, %1, vcc")
 OP2(CmpCnd, "v_cmp_lt_u32 vcc, %1, %2\n v_cndmask_b32 %0, %2, %1, vcc")
 OP2(AddcPair, "v_add_co_u32 %0, vcc, %1, %2\n v_addc_co_u32 %0, vcc, %0, %2, vcc")
 
+struct LshlAdd64 {  // 64-bit add in one instruction
+  static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b, uint32_t) {
+    uint64_t r, x = ((uint64_t)b << 32) | a, y = ((uint64_t)a << 32) | b;
+    asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(y));
+    return (uint32_t)(r >> 32) ^ (uint32_t)r;
+  }
+};
+struct Lshl64 {
+  static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b, uint32_t) {
+    uint64_t r, x = ((uint64_t)b << 32) | a;
+    asm volatile("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
+    return (uint32_t)(r >> 32) ^ (uint32_t)r;
+  }
+};
+struct Mad64Zero {  // zero addend
+  static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b, uint32_t) {
+    uint64_t r;
+    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
+    return (uint32_t)(r >> 32) ^ (uint32_t)r;
+  }
+};
 struct Mad64 {
   static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b, uint32_t) {
     uint64_t r, c = ((uint64_t)b << 32) | a;
@@ -103,6 +124,9 @@ int main() {
   run<MulU24>("v_mul_u32_u24", d, 1);
   run<MadU24>("v_mad_u32_u24", d, 1);
   run<Mad64>("v_mad_u64_u32", d, 1);
+  run<Mad64Zero>("v_mad_u64 (+0) +xor", d, 2);
+  run<LshlAdd64>("v_lshl_add_u64 +xor", d, 2);
+  run<Lshl64>("v_lshlrev_b64 +xor", d, 2);
   run<SubCoCnd>("sub_co+cndmask", d, 2);
   run<CmpCnd>("cmp+cndmask", d, 2);
   run<AddcPair>("add_co+addc", d, 2);
