@@ -79,6 +79,11 @@ _SIGNATURES = {
     "r0h_serde_encode_str": [_vp, _sz, _vp, _sz, _c.POINTER(_sz)],
     "r0h_serde_decode_str": [_vp, _sz, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_sz)],
     "r0h_journal_commitment_span": [_vp, _sz, _c.POINTER(_sz), _c.POINTER(_sz)],
+    "r0h_env_new": [_pp],
+    "r0h_env_write_str": [_vp, _vp, _sz],
+    "r0h_env_write_u8_seq": [_vp, _vp, _sz],
+    "r0h_env_words": [_vp, _pp, _c.POINTER(_sz)],
+    "r0h_env_free": [_vp],
     "r0h_receipt_parse": [_vp, _sz, _pp],
     "r0h_receipt_new": [_c.c_int, _vp, _sz, _pp],
     "r0h_receipt_add_segment": [_vp, _vp, _sz, _u32],
@@ -240,6 +245,26 @@ def serde_decode_str(data):
     off, ln, used = _sz(0), _sz(0), _sz(0)
     _check(lib().r0h_serde_decode_str(data, len(data), ctypes.byref(off), ctypes.byref(ln), ctypes.byref(used)))
     return data[off.value:off.value + ln.value], used.value
+
+
+def env_input_words(items):
+    """The u32 words `ExecutorEnv::builder().write(&x)...` produces for a list of inputs (host/src/main.rs:389-417):
+    str -> String frame, bytes -> Vec<u8> (one word per byte)."""
+    h = _vp()
+    _check(lib().r0h_env_new(ctypes.byref(h)))
+    try:
+        for it in items:
+            if isinstance(it, str):
+                raw = it.encode("utf-8")
+                _check(lib().r0h_env_write_str(h, raw, len(raw)))
+            else:
+                raw = bytes(it)
+                _check(lib().r0h_env_write_u8_seq(h, raw, len(raw)))
+        p, n = _vp(), _sz(0)
+        _check(lib().r0h_env_words(h, ctypes.byref(p), ctypes.byref(n)))
+        return np.frombuffer(ctypes.string_at(p, n.value * 4), dtype=np.uint32).copy()
+    finally:
+        lib().r0h_env_free(h)
 
 
 def journal_commitment(data):

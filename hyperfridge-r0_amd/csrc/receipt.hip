@@ -166,6 +166,10 @@ struct Parser {
 
 }  // namespace
 
+struct r0h_env {
+  std::vector<uint32_t> words;
+};
+
 struct r0h_receipt {
   int kind = R0H_RECEIPT_FAKE;
   std::vector<uint8_t> journal;
@@ -266,6 +270,49 @@ const char* r0h_serde_decode_str(const uint8_t* bytes, size_t n, size_t* str_off
   *str_off = 4;
   *str_len = len;
   if (consumed) *consumed = total;
+  return nullptr;
+}
+
+// ---- the ExecutorEnv input stream: host/src/main.rs:389-417 writes 12 Strings and one Vec<u8> (the decrypted transaction key),
+// the guest reads them back in the same order (methods/guest/src/main.rs:159-171).  A String is the frame above; a Vec<u8>
+// without serde_bytes goes element by element, one u32 word per byte (risc0 serde `serialize_u8`, as recalled: unpinned).
+const char* r0h_env_new(r0h_env** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(out, "r0h_env_new: NULL argument");
+  *out = new r0h_env;
+  return nullptr;
+  R0H_GUARD_END
+}
+const char* r0h_env_write_str(r0h_env* e, const uint8_t* utf8, size_t len) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && (utf8 || len == 0), "r0h_env_write_str: NULL argument");
+  R0H_REQUIRE(len <= 0xffffffffull, "r0h_env_write_str: a serde length prefix is 32 bits");
+  e->words.push_back((uint32_t)len);
+  for (size_t i = 0; i < len; i += 4) {
+    uint32_t w = 0;
+    for (size_t b = 0; b < 4 && i + b < len; b++) w |= (uint32_t)utf8[i + b] << (8 * b);
+    e->words.push_back(w);
+  }
+  return nullptr;
+  R0H_GUARD_END
+}
+const char* r0h_env_write_u8_seq(r0h_env* e, const uint8_t* bytes, size_t len) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && (bytes || len == 0), "r0h_env_write_u8_seq: NULL argument");
+  R0H_REQUIRE(len <= 0xffffffffull, "r0h_env_write_u8_seq: a serde length prefix is 32 bits");
+  e->words.push_back((uint32_t)len);
+  for (size_t i = 0; i < len; i++) e->words.push_back(bytes[i]);
+  return nullptr;
+  R0H_GUARD_END
+}
+const char* r0h_env_words(const r0h_env* e, const uint32_t** words, size_t* n_words) {
+  R0H_REQUIRE(e && words && n_words, "r0h_env_words: NULL argument");
+  *words = e->words.data();
+  *n_words = e->words.size();
+  return nullptr;
+}
+const char* r0h_env_free(r0h_env* e) {
+  delete e;
   return nullptr;
 }
 

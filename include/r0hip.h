@@ -175,6 +175,14 @@ const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t di
  * r0h_serde_encode_str with out == NULL only reports the size. */
 const char* r0h_serde_encode_str(const uint8_t* utf8, size_t len, uint8_t* out, size_t capacity, size_t* out_len);
 const char* r0h_serde_decode_str(const uint8_t* bytes, size_t n, size_t* str_off, size_t* str_len, size_t* consumed /* may be NULL */);
+/* The input stream `ExecutorEnv::builder().write(..)` builds (host/src/main.rs:389-417: 12 Strings and one Vec<u8>), as the u32
+ * words the guest's `env::read()` calls consume (methods/guest/src/main.rs:159-171).  A Vec<u8> goes one word per byte. */
+typedef struct r0h_env r0h_env;
+const char* r0h_env_new(r0h_env** out);
+const char* r0h_env_write_str(r0h_env* e, const uint8_t* utf8, size_t len);
+const char* r0h_env_write_u8_seq(r0h_env* e, const uint8_t* bytes, size_t len);
+const char* r0h_env_words(const r0h_env* e, const uint32_t** words, size_t* n_words);
+const char* r0h_env_free(r0h_env* e);
 /* hyperfridge's reading of the commitment in a journal: first '{' .. last '}' (host/src/main.rs:258-267, verifier/src/main.rs:176-185) */
 const char* r0h_journal_commitment_span(const uint8_t* bytes, size_t n, size_t* off, size_t* len);
 /* Receipt JSON envelope as `serde_json::to_string(&receipt)` writes it (host/src/main.rs:251-252) and
