@@ -2,7 +2,8 @@
 // witness on the device, prove K segments, print throughput and a digest of the seal.
 // It stands where hyperfridge's `host prove-camt53` stands relative to risc0 (host/src/main.rs:420-423 obtains a prover and
 // calls prove once); everything risc0-specific above the segment prover (executor, receipts) is out of scope.
-//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json --journal text]
+//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json --journal text] [--receipts R]
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,11 +27,11 @@ static void die(const char* what, const char* err) {
 
 int main(int argc, char** argv) {
   if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) {
-    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json --journal text]\n%s\n", r0h_version());
+    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json --journal text] [--receipts R]\n%s\n", r0h_version());
     return argc < 2 ? 1 : 0;
   }
   std::string blob_path = argv[1], co_path, seal_out, receipt_out, journal_text;
-  unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0;
+  unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0, receipts = 1;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--code-object")) co_path = argv[i + 1];
@@ -43,6 +44,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--verify")) verify = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--receipt-out")) receipt_out = argv[i + 1];
     else if (!strcmp(argv[i], "--journal")) journal_text = argv[i + 1];
+    else if (!strcmp(argv[i], "--receipts")) receipts = (unsigned)atoi(argv[i + 1]);
     else { fprintf(stderr, "r0h_prove: unknown option %s\n", argv[i]); return 1; }
   }
   FILE* f = fopen(blob_path.c_str(), "rb");
@@ -53,13 +55,17 @@ int main(int argc, char** argv) {
   std::vector<uint32_t> blob((size_t)sz / 4);
   if (fread(blob.data(), 4, blob.size(), f) != blob.size()) { fprintf(stderr, "r0h_prove: short read\n"); return 1; }
   fclose(f);
-  if (contexts < 1 || contexts > 8) { fprintf(stderr, "r0h_prove: --contexts must be 1..8\n"); return 1; }
+  if (contexts < 1 || contexts > 16) { fprintf(stderr, "r0h_prove: --contexts must be 1..16\n"); return 1; }
+  if (receipts < 1 || (receipts > 1 && !receipt_out.empty())) { fprintf(stderr, "r0h_prove: --receipts R > 1 is a throughput run (no --receipt-out)\n"); return 1; }
+  // BASELINE.json configs[3]: a batch of independent receipts of `segments` segments each -- receipts x segments units on one
+  // work queue, every lane takes the next unit when it is free
+  const unsigned units = receipts * segments;
 
   // one context (+ circuit + resident witness) per in-flight lane, each driven by its own host thread: segments are
   // independent, so the lanes never talk to each other
   struct Lane {
     r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; r0h_buf* code = nullptr; r0h_buf* data = nullptr;
-    std::vector<uint32_t> global, seal; size_t words = 0; unsigned proved = 0;
+    std::vector<uint32_t> global, seal; size_t words = 0; unsigned proved = 0, loaded = 0;  // loaded: unit whose witness the buffers hold
     std::vector<std::pair<unsigned, std::vector<uint32_t>>> kept;  // (segment index, seal) when a receipt is to be written
   };
   std::vector<Lane> lanes(contexts);
@@ -73,11 +79,17 @@ int main(int argc, char** argv) {
     ln.global.resize(r0h_circuit_n_global(ln.circ) + 1);
     ln.seal.resize((size_t)1 << 20);
     CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + k, ln.code, ln.data, ln.global.data()));
+    ln.loaded = k;
   }
+  std::atomic<unsigned> next_unit{0};
   auto work = [&](unsigned k) {
     Lane& ln = lanes[k];
-    for (unsigned s = k; s < segments; s += contexts) {
-      if (s >= contexts) CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + s, ln.code, ln.data, ln.global.data()));  // next segment of this lane
+    for (unsigned u; (u = next_unit.fetch_add(1)) < units;) {
+      const unsigned s = u % segments;  // segment index within its receipt
+      if (u != ln.loaded) {
+        CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + u, ln.code, ln.data, ln.global.data()));
+        ln.loaded = u;
+      }
       CHECK(r0h_prove_segment(ln.ctx, ln.circ, po2, ln.code, ln.data, ln.global.data(), ln.seal.data(), ln.seal.size(), &ln.words));
       ln.proved++;
       if (!receipt_out.empty()) ln.kept.emplace_back(s, std::vector<uint32_t>(ln.seal.begin(), ln.seal.begin() + ln.words));
@@ -89,12 +101,13 @@ int main(int argc, char** argv) {
   work(0);
   for (auto& t : threads) t.join();
   const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  // report the seal of the last segment proved by lane 0 (segment index = largest s < segments with s % contexts == 0)
+  // report the seal lane 0 proved last (with one lane: the last unit; with several, whichever unit the queue handed it)
   const Lane& l0 = lanes[0];
   uint64_t h = 1469598103934665603ull;  // FNV-1a, to compare runs
   for (size_t i = 0; i < l0.words; i++) { h ^= l0.seal[i]; h *= 1099511628211ull; }
-  printf("{\"segments\": %u, \"contexts\": %u, \"po2\": %u, \"seal_words\": %zu, \"seal_fnv1a\": \"%016llx\", \"seconds\": %.6f, \"segments_per_s\": %.4f}\n",
-         segments, contexts, po2, l0.words, (unsigned long long)h, total, segments / total);
+  printf("{\"segments\": %u, \"receipts\": %u, \"contexts\": %u, \"po2\": %u, \"seal_words\": %zu, \"seal_fnv1a\": \"%016llx\", \"seconds\": %.6f, "
+         "\"segments_per_s\": %.4f, \"receipts_per_s\": %.4f}\n",
+         segments, receipts, contexts, po2, l0.words, (unsigned long long)h, total, units / total, receipts / total);
   if (verify) {  // outside the timed region: the host-side verifier on every lane's last seal
     for (const Lane& ln : lanes) {
       if (!ln.proved) continue;
@@ -112,11 +125,10 @@ int main(int argc, char** argv) {
     CHECK(r0h_serde_encode_str((const uint8_t*)journal_text.data(), journal_text.size(), journal.data(), journal.size(), &jn));
     r0h_receipt* rc = nullptr;
     CHECK(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, journal.data(), jn, &rc));
-    for (unsigned s = 0; s < segments; s++) {
-      const Lane& ln = lanes[s % contexts];
-      for (const auto& kv : ln.kept)
-        if (kv.first == s) CHECK(r0h_receipt_add_segment(rc, kv.second.data(), kv.second.size(), s));
-    }
+    for (unsigned s = 0; s < segments; s++)
+      for (const Lane& ln : lanes)
+        for (const auto& kv : ln.kept)
+          if (kv.first == s) CHECK(r0h_receipt_add_segment(rc, kv.second.data(), kv.second.size(), s));
     char* text = nullptr;
     CHECK(r0h_receipt_to_json(rc, &text));
     FILE* o = fopen(receipt_out.c_str(), "wb");

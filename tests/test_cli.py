@@ -74,3 +74,16 @@ def test_prove_to_receipt_json_then_verify_like_the_reference_verifier(tmp_path)
     assert out.returncode == 0, out.stdout + out.stderr
     report = json.loads(out.stdout)
     assert report["accepted"] is True and report["segments"] == 3 and report["commitment"] == commitment
+
+
+@pytest.mark.gpu
+def test_batch_of_receipts_on_a_work_queue(tmp_path):
+    """BASELINE.json configs[3] in small: receipts x segments units, lanes take the next unit when free; every seal kept for a
+    receipt file must still be there, in order, and verify."""
+    out = subprocess.run([CLI, circuit_path("small"), "--po2", "10", "--segments", "3", "--receipts", "4", "--contexts", "3", "--verify", "1"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "seals verified" in out.stderr, out.stderr
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["receipts"] == 4 and info["segments"] == 3 and info["receipts_per_s"] > 0 and abs(info["segments_per_s"] / info["receipts_per_s"] - 3) < 1e-3
+    bad = subprocess.run([CLI, circuit_path("small"), "--receipts", "2", "--receipt-out", str(tmp_path / "r.json")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "throughput run" in bad.stderr
