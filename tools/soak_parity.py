@@ -17,7 +17,8 @@ import orc_binding
 def main():
     budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120.0
     orc, hal = orc_binding.load(), r0.Hal(0)
-    cases, t0, n = [("tiny", p) for p in (9, 10, 11, 12)] + [("small", p) for p in (9, 10, 11)] + [("recursion", 10)], time.time(), 0
+    cases, t0, n = [("tiny", p) for p in (9, 10, 11, 12, 13)] + [("small", p) for p in (9, 10, 11, 12)] + [("recursion", 10), ("bench", 9), ("bench", 10)], time.time(), 0
+    full = 0
     loaded = {}
     seed = 10_000
     while time.time() - t0 < budget:
@@ -38,8 +39,18 @@ def main():
             assert r0.verify_seal(blob, seal)[0] == 0
             code.free(); data.free()
             n += 1
-        print("%d seals identical after %.0f s" % (n, time.time() - t0), flush=True)
-    print("soak ok: %d seals, device == oracle word for word" % n)
+        # one full-size segment per sweep: too large for the oracle's prover, so both verifiers must accept it
+        blob, oc, gc = loaded["bench"]
+        seed += 1
+        code, data, glob = hal.witgen(gc, 20, seed)
+        seal = hal.prove_segment(gc, 20, code, data, glob)
+        code.free(); data.free()
+        if r0.verify_seal(blob, seal)[0] != 0 or oc.verify(seal)[0] != 0:
+            print("FULL-SIZE seal rejected, seed %d" % seed)
+            sys.exit(1)
+        full += 1
+        print("%d seals identical, %d full-size seals accepted by both verifiers after %.0f s" % (n, full, time.time() - t0), flush=True)
+    print("soak ok: %d seals device == oracle word for word; %d seals at 2^20 rows accepted by both verifiers" % (n, full))
 
 
 if __name__ == "__main__":
