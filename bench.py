@@ -101,6 +101,19 @@ def main():
                 t.join()
         return n_ctx
 
+    def steps_back_to_back(n):
+        """n steps = n segments on every lane; a lane starts its next segment as soon as its previous one is out (no join
+        between steps: the lanes are independent provers, exactly as r0h_prove runs them)."""
+        def run(lane):
+            for _ in range(n):
+                prove_on(lane)
+        ts = [threading.Thread(target=run, args=(ln,)) for ln in lanes]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return n * n_ctx
+
     def device_sync():
         for ln in lanes:
             ln["hal"].sync()
@@ -128,7 +141,7 @@ def main():
         elapsed, units = driver.run_timed(env, drain, 1, 0, device_sync)
         args.steps, scaling = 1, "strong"
     else:
-        elapsed, units = driver.run_timed(env, step, args.steps, args.warmup, device_sync)
+        elapsed, units = driver.run_timed(env, step, args.steps, args.warmup, device_sync, many_fn=steps_back_to_back if n_ctx > 1 else None)
         scaling = "weak"
     # per-kernel accounting: HIP events around every launch, on one context running alone, over as many segments as were
     # timed (outside the timed region, so the events neither perturb `value` nor see another context's kernels)

@@ -57,16 +57,24 @@ class DistEnv:
             self.dist.destroy_process_group()
 
 
-def run_timed(env, step_fn, steps, warmup, device_sync=lambda: None):
+def run_timed(env, step_fn, steps, warmup, device_sync=lambda: None, many_fn=None):
     """`warmup` untimed calls of step_fn(i), then exactly `steps` timed ones bracketed by barrier + device sync on both
-    sides; returns (max-over-ranks seconds, units processed by all ranks), where step_fn returns the units it processed."""
-    for i in range(warmup):
-        step_fn(-1 - i)
+    sides; returns (max-over-ranks seconds, units processed by all ranks), where step_fn returns the units it processed.
+    many_fn(n), when given, performs n steps in one call (e.g. every in-flight lane running its n segments back to back,
+    without a join between steps) and returns the units; it replaces the per-step loop for both phases."""
+    if many_fn is not None:
+        if warmup:
+            many_fn(warmup)
+    else:
+        for i in range(warmup):
+            step_fn(-1 - i)
     device_sync()
     env.barrier()
     t0 = time.perf_counter()
     units = 0
-    for i in range(steps):
+    if many_fn is not None:
+        units = int(many_fn(steps) or 0)
+    for i in range(steps if many_fn is None else 0):
         units += int(step_fn(i) or 0)
     device_sync()
     env.barrier()

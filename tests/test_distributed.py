@@ -71,3 +71,15 @@ def test_two_rank_gloo_driver_aggregates_units_and_takes_the_slowest_rank():
     assert e0 == e1 and u0 == u1 == total              # every rank sees the same reduced numbers
     assert sorted(p0 + p1) == list(range(total))        # all segments proved exactly once
     assert e0 >= 3 * 0.04 - 1e-3                        # the slow rank's time (3 steps x 40 ms) bounds the result
+
+
+def test_run_timed_with_a_many_steps_callable():
+    """many_fn(n) stands for n steps in one call (lanes running back to back): warm-up and the timed region each call it once."""
+    from hyperfridge_r0_amd import driver
+    calls = []
+    env = driver.DistEnv(backend=None)
+    elapsed, units = driver.run_timed(env, lambda i: 1 / 0, 5, 2, many_fn=lambda n: calls.append(n) or 3 * n)
+    assert calls == [2, 5] and units == 15 and elapsed >= 0
+    calls.clear()
+    driver.run_timed(env, lambda i: 1 / 0, 4, 0, many_fn=lambda n: calls.append(n) or n)
+    assert calls == [4]
