@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <memory>
+#include <stdexcept>
 #include <thread>
 
 namespace r0h {
@@ -336,6 +337,7 @@ void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_
     for (uint32_t q; (q = next.fetch_add(1)) < R0H_QUERIES;) {
       try { one_query(q); verdict_of[q] = R0H_VERIFY_OK; }
       catch (const Reject& r) { verdict_of[q] = r.code; }
+      catch (...) { verdict_of[q] = -1; }  // e.g. bad_alloc: reported below, never left to terminate the thread
     }
   };
   unsigned n_threads = std::thread::hardware_concurrency();
@@ -344,8 +346,10 @@ void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_
   for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(worker);
   worker();
   for (std::thread& t : pool) t.join();
-  for (uint32_t q = 0; q < R0H_QUERIES; q++)
+  for (uint32_t q = 0; q < R0H_QUERIES; q++) {
+    if (verdict_of[q] == -1) throw std::runtime_error("r0h_verify_seal: a query worker failed (out of memory?)");
     if (verdict_of[q] != R0H_VERIFY_OK) throw Reject{verdict_of[q]};
+  }
   io.skip_to(base.pos + (size_t)R0H_QUERIES * words_per_query);
   if (!io.exhausted()) throw Reject{R0H_VERIFY_TRAILING};
 }
