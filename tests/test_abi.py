@@ -93,3 +93,48 @@ def test_blob_parser_survives_random_corruption():
             assert str(e)
             rejected += 1
     assert rejected > 50 and accepted + rejected == 300
+
+
+def test_header_is_plain_c_and_a_c_program_can_drive_the_library(tmp_path):
+    """include/r0hip.h must compile as C99 (no C++ in the boundary) and a C caller must be able to link and use the host-only
+    entry points: version, serde framing, the receipt parser and the seal verifier on the frozen golden seal."""
+    import subprocess
+    seal = np.load(os.path.join(ROOT, "tests", "golden", "seal_tiny_po2_9_seed_1.npy"))
+    seal_path, blob_path = str(tmp_path / "seal.bin"), circuit_path("tiny")
+    seal.tofile(seal_path)
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "r0hip.h"
+#include "r0hip_circuit.h"
+static uint32_t* slurp(const char* path, size_t* words) {
+  FILE* f = fopen(path, "rb"); if (!f) return NULL;
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+  uint32_t* p = (uint32_t*)malloc((size_t)n); *words = (size_t)n / 4;
+  if (fread(p, 1, (size_t)n, f) != (size_t)n) return NULL;
+  fclose(f); return p;
+}
+int main(int argc, char** argv) {
+  size_t nb, ns, len = 0, off = 0, slen = 0; int verdict = -1; uint32_t po2 = 0; uint8_t frame[16];
+  uint32_t* blob = slurp(argv[1], &nb); uint32_t* seal = slurp(argv[2], &ns);
+  if (!blob || !seal || blob[0] != R0H_BLOB_MAGIC) return 2;
+  const char* err = r0h_verify_seal(blob, nb, NULL, NULL, seal, ns, &verdict, &po2);
+  if (err) { fprintf(stderr, "%s\n", err); r0h_free_error(err); return 3; }
+  if (r0h_serde_encode_str((const uint8_t*)"abcde", 5, frame, sizeof frame, &len) || len != 12) return 4;
+  if (r0h_serde_decode_str(frame, len, &off, &slen, NULL) || slen != 5 || memcmp(frame + off, "abcde", 5)) return 5;
+  r0h_receipt* rc = NULL;
+  const char* json = "{\"inner\":\"Fake\",\"journal\":{\"bytes\":[1,0,0,0,65,0,0,0]}}";
+  if (r0h_receipt_parse(json, strlen(json), &rc) || r0h_receipt_kind(rc) != R0H_RECEIPT_FAKE) return 6;
+  r0h_receipt_free(rc);
+  printf("%s verdict=%d (%s) po2=%u\n", r0h_version(), verdict, r0h_verify_reason(verdict), po2);
+  return verdict == R0H_VERIFY_OK ? 0 : 1;
+}
+''')
+    exe = str(tmp_path / "caller")
+    libdir = os.path.join(ROOT, "hyperfridge-r0_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L", libdir, "-lr0hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, blob_path, seal_path], capture_output=True, text=True)
+    assert out.returncode == 0 and "verdict=0 (ok) po2=9" in out.stdout, out.stdout + out.stderr
