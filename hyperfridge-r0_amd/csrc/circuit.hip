@@ -270,7 +270,31 @@ __device__ __forceinline__ u32 dfinish(u64 T) { return fred64(dfix(T)); }
 #define TAP(g, col, back) g[(size_t)(col) * domain + ((i - 4u * (back)) & mask)]
 )SRC";
 
-static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& done, std::ostringstream& os) {
+// Additions whose every use is an operand of a product need no correction: a + b < 2p is a valid Montgomery operand as long as
+// the other operand is reduced (a b + 2^32 p < 2^64 still holds, the product comes out below 2p and is corrected as usual).
+static std::vector<bool> lazy_additions(const r0h_circuit* c) {
+  const size_t nf = c->fp_step.size();
+  std::vector<bool> lazy(nf, false), needs_reduced(nf, false);
+  for (size_t v = 0; v < nf; v++) lazy[v] = c->steps[c->fp_step[v]].op == R0H_OP_ADD;
+  for (const Step& s : c->steps) {
+    if (s.op == R0H_OP_ADD || s.op == R0H_OP_SUB) needs_reduced[s.a] = needs_reduced[s.b] = true;
+    if (s.op == R0H_OP_AND_EQZ || s.op == R0H_OP_AND_COND) needs_reduced[s.b] = true;  // constraint values and gates
+  }
+  for (const Term& t : c->plan.terms) {
+    needs_reduced[t.v] = true;
+    for (uint32_t g : t.conds) needs_reduced[g] = true;
+  }
+  for (size_t v = 0; v < nf; v++)
+    if (needs_reduced[v]) lazy[v] = false;
+  for (const Step& s : c->steps)  // at most one uncorrected operand per product
+    if (s.op == R0H_OP_MUL) {
+      if (s.a == s.b) lazy[s.a] = false;
+      else if (lazy[s.a] && lazy[s.b]) lazy[s.b] = false;
+    }
+  return lazy;
+}
+
+static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& done, const std::vector<bool>& lazy, std::ostringstream& os) {
   // iterative post-order emission of the expression DAG below `root`
   std::vector<std::pair<uint32_t, int>> stack;
   stack.push_back({root, 0});
@@ -296,7 +320,10 @@ static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& don
         break;
       }
       case R0H_OP_GET_GLOBAL: os << (s.a == 0 ? "glob[" : "mix[") << s.b << "]"; break;
-      case R0H_OP_ADD: os << "fadd(v" << s.a << ", v" << s.b << ")"; break;
+      case R0H_OP_ADD:
+        if (lazy[v]) os << "v" << s.a << " + v" << s.b;  // < 2p: only ever multiplied
+        else os << "fadd(v" << s.a << ", v" << s.b << ")";
+        break;
       case R0H_OP_SUB: os << "fsub(v" << s.a << ", v" << s.b << ")"; break;
       case R0H_OP_MUL: os << "fmul(v" << s.a << ", v" << s.b << ")"; break;
       default: break;
@@ -322,6 +349,7 @@ static void emit_accumulate(const Plan& pl, uint32_t term, uint32_t position, st
 
 static std::string emit_source(const r0h_circuit* c) {
   const Plan& pl = c->plan;
+  const std::vector<bool> lazy = lazy_additions(c);
   const uint32_t scope_terms = tunable("R0H_EC_SCOPE", 0), waves = tunable("R0H_EC_WAVES", 0);
   std::ostringstream os;
   os << PRELUDE;
@@ -349,8 +377,8 @@ static std::string emit_source(const r0h_circuit* c) {
         in_scope = 0;
       }
       const Term& tm = pl.terms[t];
-      emit_var(c, tm.v, done, os);
-      for (uint32_t g : tm.conds) emit_var(c, g, done, os);
+      emit_var(c, tm.v, done, lazy, os);
+      for (uint32_t g : tm.conds) emit_var(c, g, done, lazy, os);
       // value of the term: the constraint times its enclosing gates
       std::ostringstream val;
       for (size_t g = 0; g < tm.conds.size(); g++) val << "fmul(v" << tm.conds[g] << ", ";
