@@ -207,7 +207,7 @@ const char* r0h_ctx_create(int device, r0h_ctx** out) {
     uint32_t w22 = d == 0 ? rou_fwd(MAX_DOMAIN_PO2) : rou_rev(MAX_DOMAIN_PO2);
     R0H_TRY(upload_pow_table(&ctx->tw_lo[d], w22, TW_SIZE));
     R0H_TRY(upload_pow_table(&ctx->tw_hi[d], fpow(w22, TW_SIZE), TW_SIZE));
-    R0H_TRY(upload_pow_table(&ctx->tw12[d], d == 0 ? rou_fwd(12) : rou_rev(12), 2048));
+    R0H_TRY(upload_pow_table(&ctx->tw12[d], d == 0 ? rou_fwd(TWL_BITS) : rou_rev(TWL_BITS), 1u << (TWL_BITS - 1)));
   }
   R0H_TRY(upload_pow_table(&ctx->pow3_lo, enc(3), TW_SIZE));
   R0H_TRY(upload_pow_table(&ctx->pow3_hi, fpow(enc(3), TW_SIZE), TW_SIZE));

@@ -41,6 +41,7 @@ constexpr int P2_CELLS = 24, P2_RATE = 16, P2_OUT = 8, P2_HALF_FULL = 4, P2_PART
 constexpr int P2_PART_SIGMA_WORDS = (P2_PARTIAL - 1) * (P2_CELLS - 1) + (P2_PARTIAL - 1) * P2_PARTIAL / 2;  // sum_{r=1}^{20} (23 + r) = 670
 constexpr uint32_t TW_BITS = 11;            // two-level twiddle tables of 2^11 entries each
 constexpr uint32_t TW_SIZE = 1u << TW_BITS;
+constexpr uint32_t TWL_BITS = 13;           // in-chunk twiddle table: ROU[13]^i, i < 2^12 (chunks of up to 2^13 words)
 constexpr uint32_t MAX_DOMAIN_PO2 = 22;
 constexpr size_t POOL_LIMIT = (size_t)48 << 30;  // one po2 = 20 segment parks about 8 GiB     // 2^R0H_MAX_PO2 rows x INV_RATE
 

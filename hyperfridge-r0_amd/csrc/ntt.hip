@@ -9,6 +9,8 @@
 //            local DIFs with the 1/N normalisation folded into the final store.
 // The strided pass stages a [2^H][T] tile (T consecutive residues, 64-byte rows at T=16) so every global access is a
 // run of T words; the local pass moves whole contiguous chunks.  Column-major batches map to blockIdx.y.
+#include <atomic>
+
 #include "internal.hpp"
 
 namespace r0h {
@@ -16,7 +18,7 @@ namespace r0h {
 struct TwTables {
   const uint32_t* lo;    // w22^i
   const uint32_t* hi;    // w22^(i << 11)
-  const uint32_t* tw12;  // ROU[12]^i
+  const uint32_t* tw12;  // ROU[TWL_BITS]^i, i < 2^(TWL_BITS - 1): the twiddles of every layer inside a contiguous chunk
 };
 
 __device__ __forceinline__ uint32_t omega_n(const TwTables& t, uint32_t e, uint32_t n) {
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void ntt_local_kernel(uint32_t* out, const uin
       const uint32_t half = 1u << (l - 1);
       for (uint32_t b = tid; b < size / 2; b += 256) {
         uint32_t j = b & (half - 1), i0 = ((b >> (l - 1)) << l) + j;
-        uint32_t a = s[i0], t = mul(s[i0 + half], tw12[j << (12 - l)]);
+        uint32_t a = s[i0], t = mul(s[i0 + half], tw12[j << (TWL_BITS - l)]);
         s[i0] = add(a, t);
         s[i0 + half] = sub(a, t);
       }
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void ntt_local_kernel(uint32_t* out, const uin
         uint32_t j = b & (half - 1), i0 = ((b >> (l - 1)) << l) + j;
         uint32_t a = s[i0], t = s[i0 + half];
         s[i0] = add(a, t);
-        s[i0 + half] = mul(sub(a, t), tw12[j << (12 - l)]);
+        s[i0 + half] = mul(sub(a, t), tw12[j << (TWL_BITS - l)]);
       }
       __syncthreads();
     }
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(512) void ntt_strided_kernel(uint32_t* io, uint32_t
       for (uint32_t b = tid; b < total / 2; b += 512) {
         uint32_t lo = b & (T - 1), jj = b >> tlog, j = jj & (half - 1);
         uint32_t i0 = ((((jj >> (l - 1)) << l) + j) << tlog) + lo, i1 = i0 + (half << tlog);
-        uint32_t a = s[i0], t = mul(s[i1], tw.tw12[j << (12 - l)]);
+        uint32_t a = s[i0], t = mul(s[i1], tw.tw12[j << (TWL_BITS - l)]);
         s[i0] = add(a, t);
         s[i1] = sub(a, t);
       }
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(512) void ntt_strided_kernel(uint32_t* io, uint32_t
         uint32_t i0 = ((((jj >> (l - 1)) << l) + j) << tlog) + lo, i1 = i0 + (half << tlog);
         uint32_t a = s[i0], t = s[i1];
         s[i0] = add(a, t);
-        s[i1] = mul(sub(a, t), tw.tw12[j << (12 - l)]);
+        s[i1] = mul(sub(a, t), tw.tw12[j << (TWL_BITS - l)]);
       }
       __syncthreads();
     }
@@ -138,7 +140,7 @@ __device__ __forceinline__ void field_layers(uint32_t (&x)[16], uint32_t rest0, 
       const int l = DIR == 0 ? step : W - 1 - step;
       if (DIR == 0 && l < LO_LAYER) continue;
       uint32_t a_tw = ONE;
-      if (B != 0) a_tw = tw12[low << (12 - (B + l + 1))];
+      if (B != 0) a_tw = tw12[low << (TWL_BITS - (B + l + 1))];
 #pragma unroll
       for (int j0 = 0; j0 < (1 << W); j0++) {
         if (j0 & (1 << l)) continue;
@@ -182,78 +184,114 @@ __device__ __forceinline__ void interpass_twiddles(uint32_t (&t)[16], const TwTa
   for (int j = 0; j < 16; j++) t[j] = gp[((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3)];
 }
 
-// [2^H][16] tile, H = 8 + WL: forward = DIT over the chunk index with the inter-pass twiddle on load,
-// inverse = DIF with the twiddle on store.  Block = 16 << (H - 4) threads.
-template <int WL, int DIR>
-__global__ __launch_bounds__(1024) void ntt_strided16_kernel(uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, TwTables tw, W16 c) {
+// [2^H][T] tile, H = 8 + WL, T = 16 * WORDS consecutive residues: forward = DIT over the chunk index with the inter-pass
+// twiddle on load, inverse = DIF with the twiddle on store.  Block = 16 << (H - 4) threads; a thread owns WORDS adjacent
+// residues (one radix-16 column each).  WORDS = 2 makes every global access a 128-byte row: 4.8 TB/s against 3.2 TB/s for
+// 64-byte rows in a plain copy of the same shape (tools/microbench/tile_copy_bench.hip).  The tile has to stay small enough
+// for two blocks per CU (load, butterflies and store of different blocks overlap): H <= 9, i.e. the contiguous pass takes
+// up to 2^13 words.  LDS rows are padded by two words so that the four row groups of a wave fall into different banks.
+template <int WL, int DIR, int WORDS>
+__global__ __launch_bounds__(16 << (4 + WL)) void ntt_strided16_kernel(uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, TwTables tw, W16 c) {
   extern __shared__ uint32_t s[];
   constexpr uint32_t H = 8 + WL;
-  const uint32_t t = threadIdx.x & 15, q = threadIdx.x >> 4, lo = (blockIdx.x << 4) + t;
+  constexpr uint32_t S = WORDS == 1 ? 16 : 16 * WORDS + 2;  // LDS row stride in words
+  const uint32_t t = threadIdx.x & 15, q = threadIdx.x >> 4, lo = ((blockIdx.x << 4) + t) * WORDS;
   uint32_t* col = io + ((size_t)blockIdx.y << n);
   const uint32_t* src = in + ((size_t)blockIdx.y << n);  // may alias col (in-place): every word is read before its tile is written
-  uint32_t x[16];
+  uint32_t x[WORDS][16];
+  auto gload = [&](const uint32_t* base, uint32_t row, int j) {
+    const uint32_t* p = base + ((size_t)row << L) + lo;
+    if (WORDS == 1) x[0][j] = p[0];
+    else { const uint2 v = *(const uint2*)p; x[0][j] = v.x; x[WORDS - 1][j] = v.y; }
+  };
+  auto gstore = [&](uint32_t row, int j) {
+    uint32_t* p = col + ((size_t)row << L) + lo;
+    if (WORDS == 1) p[0] = x[0][j];
+    else *(uint2*)p = make_uint2(x[0][j], x[WORDS - 1][j]);
+  };
+  auto sput = [&](uint32_t row, int j) {
+    uint32_t* p = s + row * S + t * WORDS;
+    if (WORDS == 1) p[0] = x[0][j];
+    else *(uint2*)p = make_uint2(x[0][j], x[WORDS - 1][j]);
+  };
+  auto sget = [&](uint32_t row, int j) {
+    const uint32_t* p = s + row * S + t * WORDS;
+    if (WORDS == 1) x[0][j] = p[0];
+    else { const uint2 v = *(const uint2*)p; x[0][j] = v.x; x[WORDS - 1][j] = v.y; }
+  };
+  constexpr int WLs = WL == 0 ? 1 : WL, SETS = 16 >> WLs;
   if (DIR == 0) {
-    {
+#pragma unroll
+    for (int j = 0; j < 16; j++) gload(src, q * 16 + j, j);
+#pragma unroll
+    for (int w = 0; w < WORDS; w++) {
       uint32_t tws[16];
-      interpass_twiddles<H>(tws, tw, q, lo, n);
+      interpass_twiddles<H>(tws, tw, q, lo + w, n);
 #pragma unroll
-      for (int j = 0; j < 16; j++) x[j] = mul(src[((size_t)(q * 16 + j) << L) + lo], tws[j]);
+      for (int j = 0; j < 16; j++) x[w][j] = mul(x[w][j], tws[j]);
+      field_layers<4, 0, 0, 0>(x[w], q, tw.tw12, c);
     }
-    field_layers<4, 0, 0, 0>(x, q, tw.tw12, c);
 #pragma unroll
-    for (int j = 0; j < 16; j++) s[(q * 16 + j) * 16 + t] = x[j];
+    for (int j = 0; j < 16; j++) sput(q * 16 + j, j);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = s[field_index<4, 4>(q, 0, j) * 16 + t];
-    field_layers<4, 4, 0, 0>(x, q, tw.tw12, c);
+    for (int j = 0; j < 16; j++) sget(field_index<4, 4>(q, 0, j), j);
+#pragma unroll
+    for (int w = 0; w < WORDS; w++) field_layers<4, 4, 0, 0>(x[w], q, tw.tw12, c);
     if (WL == 0) {
 #pragma unroll
-      for (int j = 0; j < 16; j++) col[((size_t)field_index<4, 4>(q, 0, j) << L) + lo] = x[j];
+      for (int j = 0; j < 16; j++) gstore(field_index<4, 4>(q, 0, j), j);
       return;
     }
 #pragma unroll
-    for (int j = 0; j < 16; j++) s[field_index<4, 4>(q, 0, j) * 16 + t] = x[j];
+    for (int j = 0; j < 16; j++) sput(field_index<4, 4>(q, 0, j), j);
     __syncthreads();
-    constexpr int WLs = WL == 0 ? 1 : WL, SETS = 16 >> WLs;
 #pragma unroll
     for (int ss = 0; ss < SETS; ss++)
 #pragma unroll
-      for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = s[field_index<WLs, 8>(q * SETS, ss, j) * 16 + t];
-    field_layers<WLs, 8, 0, 0>(x, q * SETS, tw.tw12, c);
+      for (int j = 0; j < (1 << WLs); j++) sget(field_index<WLs, 8>(q * SETS, ss, j), ss * (1 << WLs) + j);
+#pragma unroll
+    for (int w = 0; w < WORDS; w++) field_layers<WLs, 8, 0, 0>(x[w], q * SETS, tw.tw12, c);
 #pragma unroll
     for (int ss = 0; ss < SETS; ss++)
 #pragma unroll
-      for (int j = 0; j < (1 << WLs); j++) col[((size_t)field_index<WLs, 8>(q * SETS, ss, j) << L) + lo] = x[ss * (1 << WLs) + j];
+      for (int j = 0; j < (1 << WLs); j++) gstore(field_index<WLs, 8>(q * SETS, ss, j), ss * (1 << WLs) + j);
   } else {
-    constexpr int WLs = WL == 0 ? 1 : WL, SETS = 16 >> WLs;
     if (WL != 0) {
 #pragma unroll
       for (int ss = 0; ss < SETS; ss++)
 #pragma unroll
-        for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = src[((size_t)field_index<WLs, 8>(q * SETS, ss, j) << L) + lo];
-      field_layers<WLs, 8, 1, 0>(x, q * SETS, tw.tw12, c);
+        for (int j = 0; j < (1 << WLs); j++) gload(src, field_index<WLs, 8>(q * SETS, ss, j), ss * (1 << WLs) + j);
+#pragma unroll
+      for (int w = 0; w < WORDS; w++) field_layers<WLs, 8, 1, 0>(x[w], q * SETS, tw.tw12, c);
 #pragma unroll
       for (int ss = 0; ss < SETS; ss++)
 #pragma unroll
-        for (int j = 0; j < (1 << WLs); j++) s[field_index<WLs, 8>(q * SETS, ss, j) * 16 + t] = x[ss * (1 << WLs) + j];
+        for (int j = 0; j < (1 << WLs); j++) sput(field_index<WLs, 8>(q * SETS, ss, j), ss * (1 << WLs) + j);
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 16; j++) x[j] = s[field_index<4, 4>(q, 0, j) * 16 + t];
+      for (int j = 0; j < 16; j++) sget(field_index<4, 4>(q, 0, j), j);
     } else {
 #pragma unroll
-      for (int j = 0; j < 16; j++) x[j] = src[((size_t)field_index<4, 4>(q, 0, j) << L) + lo];
+      for (int j = 0; j < 16; j++) gload(src, field_index<4, 4>(q, 0, j), j);
     }
-    field_layers<4, 4, 1, 0>(x, q, tw.tw12, c);
 #pragma unroll
-    for (int j = 0; j < 16; j++) s[field_index<4, 4>(q, 0, j) * 16 + t] = x[j];
+    for (int w = 0; w < WORDS; w++) field_layers<4, 4, 1, 0>(x[w], q, tw.tw12, c);
+#pragma unroll
+    for (int j = 0; j < 16; j++) sput(field_index<4, 4>(q, 0, j), j);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = s[(q * 16 + j) * 16 + t];
-    field_layers<4, 0, 1, 0>(x, q, tw.tw12, c);
-    uint32_t tws[16];
-    interpass_twiddles<H>(tws, tw, q, lo, n);
+    for (int j = 0; j < 16; j++) sget(q * 16 + j, j);
 #pragma unroll
-    for (int j = 0; j < 16; j++) col[((size_t)(q * 16 + j) << L) + lo] = mul(x[j], tws[j]);
+    for (int w = 0; w < WORDS; w++) {
+      field_layers<4, 0, 1, 0>(x[w], q, tw.tw12, c);
+      uint32_t tws[16];
+      interpass_twiddles<H>(tws, tw, q, lo + w, n);
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[w][j] = mul(x[w][j], tws[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) gstore(q * 16 + j, j);
   }
 }
 
@@ -269,11 +307,12 @@ struct ZkShift {        // optional fused f(x) -> f(3x) on the inverse transform
 };
 
 template <int WL, int DIR, int EXP_BITS, int ZK>
-__global__ __launch_bounds__(256) void ntt_local16_kernel(uint32_t* out, const uint32_t* in /* may alias out */, uint32_t n_out,
+__global__ __launch_bounds__(1 << (4 + (WL < 4 ? 4 : WL))) void ntt_local16_kernel(uint32_t* out, const uint32_t* in /* may alias out */, uint32_t n_out,
                                                            const uint32_t* __restrict__ tw12, W16 c, uint32_t scale, ZkShift zk) {
   extern __shared__ uint32_t s[];
   constexpr uint32_t L = 8 + WL;
-  constexpr int WLs = WL == 0 ? 1 : WL, SETS = 16 >> WLs;
+  // rounds: bits 0-3, 4-7, then WLs more bits at 8; L = 13 (WL = 5) adds a one-layer round at bit 12
+  constexpr int WLs = WL == 0 ? 1 : (WL > 4 ? 4 : WL), SETS = 16 >> WLs;
   const uint32_t q = threadIdx.x;
   const size_t colid = blockIdx.y;
   const uint32_t base = blockIdx.x << L;
@@ -313,6 +352,21 @@ __global__ __launch_bounds__(256) void ntt_local16_kernel(uint32_t* out, const u
 #pragma unroll
       for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = s[lds_pad(field_index<WLs, 8>(q * SETS, ss, j))];
     field_layers<WLs, 8, 0, 0>(x, q * SETS, tw12, c);
+    if (WL == 5) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) s[lds_pad(field_index<4, 8>(q, 0, j))] = x[j];
+      __syncthreads();
+#pragma unroll
+      for (int ss = 0; ss < 8; ss++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) x[ss * 2 + j] = s[lds_pad(field_index<1, 12>(q * 8, ss, j))];
+      field_layers<1, 12, 0, 0>(x, q * 8, tw12, c);
+#pragma unroll
+      for (int ss = 0; ss < 8; ss++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) dst[field_index<1, 12>(q * 8, ss, j)] = x[ss * 2 + j];
+      return;
+    }
 #pragma unroll
     for (int ss = 0; ss < SETS; ss++)
 #pragma unroll
@@ -320,10 +374,26 @@ __global__ __launch_bounds__(256) void ntt_local16_kernel(uint32_t* out, const u
   } else {
     const uint32_t* src = in + (colid << n_out) + base;
     if (WL != 0) {
+      if (WL == 5) {  // the one-layer round at bit 12 first, then through LDS into the bit-8 layout
 #pragma unroll
-      for (int ss = 0; ss < SETS; ss++)
+        for (int ss = 0; ss < 8; ss++)
 #pragma unroll
-        for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = src[field_index<WLs, 8>(q * SETS, ss, j)];
+          for (int j = 0; j < 2; j++) x[ss * 2 + j] = src[field_index<1, 12>(q * 8, ss, j)];
+        field_layers<1, 12, 1, 0>(x, q * 8, tw12, c);
+#pragma unroll
+        for (int ss = 0; ss < 8; ss++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) s[lds_pad(field_index<1, 12>(q * 8, ss, j))] = x[ss * 2 + j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = s[lds_pad(field_index<4, 8>(q, 0, j))];
+        __syncthreads();  // the next exchange reuses the buffer
+      } else {
+#pragma unroll
+        for (int ss = 0; ss < SETS; ss++)
+#pragma unroll
+          for (int j = 0; j < (1 << WLs); j++) x[ss * (1 << WLs) + j] = src[field_index<WLs, 8>(q * SETS, ss, j)];
+      }
       field_layers<WLs, 8, 1, 0>(x, q * SETS, tw12, c);
 #pragma unroll
       for (int ss = 0; ss < SETS; ss++)
@@ -454,8 +524,8 @@ static Split16 split16_for(uint32_t n) {
   if (n >= 8 && n <= 12) { sp.use16 = true; return sp; }
   if (n >= 16 && n <= MAX_DOMAIN_PO2) {
     sp.use16 = true;
-    sp.L = n - 8 < 12 ? n - 8 : 12;
-    sp.H = n - sp.L;
+    sp.H = n <= 20 ? 8 : 9;  // strided tiles of at most 2^9 rows (two blocks per CU); the contiguous pass takes up to 2^13 words
+    sp.L = n - sp.H;
   }
   return sp;
 }
@@ -477,17 +547,32 @@ static void launch_local16(r0h_ctx* ctx, uint32_t L, dim3 grid, uint32_t* out, c
     case 9: hipLaunchKernelGGL((ntt_local16_kernel<1, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
     case 10: hipLaunchKernelGGL((ntt_local16_kernel<2, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
     case 11: hipLaunchKernelGGL((ntt_local16_kernel<3, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
-    default: hipLaunchKernelGGL((ntt_local16_kernel<4, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
+    case 12: hipLaunchKernelGGL((ntt_local16_kernel<4, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
+    default: hipLaunchKernelGGL((ntt_local16_kernel<5, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
   }
+}
+template <int WL, int DIR>
+static void launch_strided16_wl(r0h_ctx* ctx, dim3 grid, uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, const TwTables& tw, const W16& c) {
+  constexpr uint32_t H = 8 + WL;
+  const dim3 block(16u << (H - 4));
+  if (L >= 5) {  // two residues per thread: 128-byte rows
+    constexpr size_t lds = ((size_t)1 << H) * (16 * 2 + 2) * 4;
+    if (lds > 65536) {  // beyond the default limit LDS has to be asked for (per kernel instantiation; repeating it is harmless)
+      static std::atomic<bool> raised{false};
+      if (!raised.exchange(true))
+        (void)hipFuncSetAttribute((const void*)ntt_strided16_kernel<WL, DIR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL((ntt_strided16_kernel<WL, DIR, 2>), dim3(grid.x / 2, grid.y), block, lds, ctx->stream, io, in, n, L, tw, c);
+    return;
+  }
+  hipLaunchKernelGGL((ntt_strided16_kernel<WL, DIR, 1>), grid, block, ((size_t)16 << H) * 4, ctx->stream, io, in, n, L, tw, c);
 }
 template <int DIR>
 static void launch_strided16(r0h_ctx* ctx, uint32_t H, dim3 grid, uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, const TwTables& tw, const W16& c) {
-  const size_t lds = ((size_t)16 << H) * 4;
-  const dim3 block(16u << (H - 4));
   switch (H) {
-    case 8: hipLaunchKernelGGL((ntt_strided16_kernel<0, DIR>), grid, block, lds, ctx->stream, io, in, n, L, tw, c); break;
-    case 9: hipLaunchKernelGGL((ntt_strided16_kernel<1, DIR>), grid, block, lds, ctx->stream, io, in, n, L, tw, c); break;
-    default: hipLaunchKernelGGL((ntt_strided16_kernel<2, DIR>), grid, block, lds, ctx->stream, io, in, n, L, tw, c); break;
+    case 8: launch_strided16_wl<0, DIR>(ctx, grid, io, in, n, L, tw, c); break;
+    case 9: launch_strided16_wl<1, DIR>(ctx, grid, io, in, n, L, tw, c); break;
+    default: launch_strided16_wl<2, DIR>(ctx, grid, io, in, n, L, tw, c); break;
   }
 }
 
