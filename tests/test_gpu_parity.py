@@ -14,7 +14,7 @@ def rnd(rng, n):
     return rng.integers(0, P, size=n, dtype=np.uint32)
 
 
-@pytest.mark.parametrize("po2,count", [(1, 3), (4, 2), (9, 5), (12, 3), (13, 2), (14, 4), (17, 3), (20, 2)])
+@pytest.mark.parametrize("po2,count", [(1, 3), (4, 2), (9, 5), (12, 3), (13, 2), (14, 4), (17, 3), (20, 2), (21, 2), (22, 1)])
 def test_interpolate_ntt(hal, orc, po2, count):
     rng = np.random.default_rng(100 + po2)
     x = rnd(rng, count << po2)
@@ -23,7 +23,7 @@ def test_interpolate_ntt(hal, orc, po2, count):
     assert np.array_equal(buf.to_host(), orc.batch_interpolate_ntt(x, count, po2))
 
 
-@pytest.mark.parametrize("in_po2,expand,count", [(3, 0, 2), (5, 2, 3), (10, 2, 4), (12, 0, 2), (11, 2, 3), (14, 2, 2), (16, 2, 3), (20, 2, 1), (18, 0, 2)])
+@pytest.mark.parametrize("in_po2,expand,count", [(3, 0, 2), (5, 2, 3), (10, 2, 4), (12, 0, 2), (11, 2, 3), (14, 2, 2), (16, 2, 3), (20, 2, 1), (18, 0, 2), (19, 2, 2), (21, 0, 1), (22, 0, 1)])
 def test_expand_into_evaluate_ntt(hal, orc, in_po2, expand, count):
     rng = np.random.default_rng(200 + in_po2)
     x = rnd(rng, count << in_po2)
