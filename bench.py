@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--circuit", default="bench")
     ap.add_argument("--contexts", type=int, default=8, help="segments in flight per GPU (one context + host thread each)")
-    ap.add_argument("--cpu-po2", type=int, default=17, help="po2 of the bounded CPU-baseline sample (0 disables)")
+    ap.add_argument("--cpu-po2", type=int, default=18, help="po2 of the bounded CPU-baseline sample: 18 = BASELINE.json configs[0] (0 disables)")
     ap.add_argument("--segments", type=int, default=0, help="BASELINE configs[2]/[3]: prove a fixed batch of this many segments, sharded "
                                                               "round-robin over the ranks (strong scaling); 0 = the default weak-scaling steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rehearsing ranks on one box)")
