@@ -126,7 +126,7 @@ const char* r0h_hash_fold(r0h_ctx* ctx, r0h_buf* nodes, uint32_t output_size) {
   R0H_REQUIRE(((uintptr_t)nodes->ptr & 15) == 0, "r0h_hash_fold: node buffer must be 16-byte aligned");
   if (!output_size) return nullptr;
   KScope ks(ctx, "hash_fold_kernel", (double)output_size * 96);
-  if (output_size <= 1024) {  // far fewer parents than lanes (32x the instructions per permutation, ~7x less latency): spread each permutation over 24 lanes (latency, not throughput)
+  if (output_size <= 8192) {  // fewer parents than the chip has SIMD slots (measured up to 8 K: 1.47 vs 1.52 ms per tree) (32x the instructions per permutation, ~7x less latency): spread each permutation over 24 lanes (latency, not throughput)
     hipLaunchKernelGGL(hash_fold_lanes_kernel, dim3((output_size * 32 + 255) / 256), dim3(256), 0, ctx->stream, u32(nodes), output_size, ctx->p2);
     hipError_t e = hipGetLastError();
     R0H_REQUIRE(e == hipSuccess, "hash_fold_lanes_kernel: %s", hipGetErrorString(e));

@@ -79,7 +79,7 @@ def test_hash_rows_of_an_empty_matrix_is_one_permutation_of_zero(hal, orc):
     assert np.array_equal(dig.to_host().reshape(4, 8), np.tile(want, (4, 1)))
 
 
-@pytest.mark.parametrize("rows,cols", [(2, 3), (64, 16), (2048, 20), (1 << 14, 64)])
+@pytest.mark.parametrize("rows,cols", [(2, 3), (64, 16), (2048, 20), (1 << 14, 64), (1 << 16, 5), (1 << 18, 2)])  # levels on both fold kernels (cross-lane up to 8 K parents)
 def test_hash_fold_and_merkle_build(hal, orc, rows, cols):
     rng = np.random.default_rng(rows)
     m = rnd(rng, rows * cols)
