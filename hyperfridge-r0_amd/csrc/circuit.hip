@@ -187,7 +187,9 @@ static uint32_t flatten(const r0h_circuit* c, uint32_t m, uint32_t base_pow, std
 
 static uint32_t tunable_budget() {
   const char* v = getenv("R0H_EC_BUDGET");
-  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : 5000u;
+  // expression nodes per kernel; measured on the bench circuit (tools/tune_evalcheck.py): 3,000 -> 11.0 ms, 5,000 -> 10.4, 8,000 -> 10.2,
+  // 12,000 -> 9.9, 16,000 -> 9.7 (three kernels, 166 VGPRs), 24,000 -> 11.7 (197 VGPRs: too few waves per SIMD)
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : 16000u;
 }
 
 static void make_plan(r0h_circuit* c) {
