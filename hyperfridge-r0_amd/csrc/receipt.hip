@@ -24,13 +24,14 @@ namespace {
 
 // ---------------------------------------------------------------- a small JSON reader (objects, arrays, strings, integers)
 struct Json {
-  enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+  enum Kind { Null, Bool, Num, Str, Arr, Obj, NumArr } kind = Null;  // NumArr: an array of non-negative integers, kept flat (seals are long)
   bool b = false;
   double num = 0;
   bool integral = false;
   uint64_t u = 0;
   std::string str;
   std::vector<Json> arr;
+  std::vector<uint64_t> nums;
   std::vector<std::pair<std::string, Json>> obj;
   const Json* get(const char* key) const {
     if (kind != Obj) return nullptr;
@@ -125,6 +126,30 @@ struct Parser {
       p++;
       ws();
       if (p < end && *p == ']') { p++; depth--; return true; }
+      if (p < end && *p >= '0' && *p <= '9') {  // flat path for arrays of non-negative integers (seal words, journal bytes)
+        const char* save = p;
+        bool flat = true;
+        while (true) {
+          ws();
+          if (p >= end || *p < '0' || *p > '9') { flat = false; break; }
+          uint64_t u = 0;
+          bool overflow = false;
+          while (p < end && *p >= '0' && *p <= '9') {
+            if (u > (UINT64_MAX - 9) / 10) overflow = true;
+            u = u * 10 + (uint64_t)(*p++ - '0');
+          }
+          if (overflow || (p < end && (*p == '.' || *p == 'e' || *p == 'E'))) { flat = false; break; }
+          out.nums.push_back(u);
+          ws();
+          if (p < end && *p == ',') { p++; continue; }
+          if (p < end && *p == ']') { p++; break; }
+          flat = false;
+          break;
+        }
+        if (flat) { out.kind = Json::NumArr; depth--; return true; }
+        p = save;  // something else in there: parse it the general way
+        out.nums.clear();
+      }
       while (ok) {
         out.arr.emplace_back();
         if (!value(out.arr.back())) return false;
@@ -180,7 +205,13 @@ struct r0h_receipt {
 namespace {
 
 const char* u32_array(const Json* j, uint64_t limit, const char* what, std::vector<uint64_t>& out) {
-  R0H_REQUIRE(j && j->kind == Json::Arr, "receipt JSON: %s is not an array", what);
+  R0H_REQUIRE(j && (j->kind == Json::Arr || j->kind == Json::NumArr), "receipt JSON: %s is not an array", what);
+  if (j->kind == Json::NumArr) {
+    for (uint64_t u : j->nums)
+      R0H_REQUIRE(u <= limit, "receipt JSON: %s holds something other than an integer in [0, %llu]", what, (unsigned long long)limit);
+    out = j->nums;
+    return nullptr;
+  }
   out.reserve(j->arr.size());
   for (const Json& v : j->arr) {
     R0H_REQUIRE(v.kind == Json::Num && v.integral && v.u <= limit, "receipt JSON: %s holds something other than an integer in [0, %llu]", what,
