@@ -557,9 +557,10 @@ static void launch_strided16_wl(r0h_ctx* ctx, dim3 grid, uint32_t* io, const uin
   const dim3 block(16u << (H - 4));
   if (L >= 5) {  // two residues per thread: 128-byte rows
     constexpr size_t lds = ((size_t)1 << H) * (16 * 2 + 2) * 4;
-    if (lds > 65536) {  // beyond the default limit LDS has to be asked for (per kernel instantiation; repeating it is harmless)
-      static std::atomic<bool> raised{false};
-      if (!raised.exchange(true))
+    if (lds > 65536) {  // beyond the default limit LDS has to be asked for: once per kernel instantiation and device
+      static std::atomic<uint64_t> raised{0};
+      const uint64_t bit = (uint64_t)1 << (ctx->device & 63);
+      if (!(raised.fetch_or(bit) & bit))
         (void)hipFuncSetAttribute((const void*)ntt_strided16_kernel<WL, DIR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     hipLaunchKernelGGL((ntt_strided16_kernel<WL, DIR, 2>), dim3(grid.x / 2, grid.y), block, lds, ctx->stream, io, in, n, L, tw, c);
