@@ -117,6 +117,9 @@ struct KScope {
   r0h_ctx* ctx;
   KTimer* t = nullptr;
   KScope(r0h_ctx* c, const char* name, double alg_bytes) : ctx(c) {
+    // every operation opens a scope before it launches: also the place where the calling thread is pointed at the context's
+    // device (a host thread may drive contexts on several devices; allocations and function attributes go to the current one)
+    (void)hipSetDevice(c->device);
     if (!c->ktime_on) return;
     t = &c->ktimers[name];
     if (t->ev.size() < t->used + 2) {
