@@ -62,24 +62,41 @@ class Recursor:
             code.free()
             data.free()
 
-    def _check(self, seal, blob, what):
-        verdict, reason, _ = verify_seal(blob, seal)
-        if verdict != 0:
-            raise R0HipError("%s: the seal to be consumed does not verify: %s" % (what, reason))
+    def _checked(self, checks, prove):
+        """Run `prove()` on the device while host threads verify the seals this step consumes (checks = [(seal, blob, what)]);
+        the step only counts if every check passed.  The proof needs the digests, not the verdicts, so the two overlap."""
+        import threading
+        verdicts = [None] * len(checks)
+
+        def run(k):
+            verdicts[k] = verify_seal(checks[k][1], checks[k][0])
+
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(len(checks))]
+        for t in threads:
+            t.start()
+        try:
+            seal = prove()
+        finally:
+            for t in threads:
+                t.join()
+        for (_, _, what), v in zip(checks, verdicts):
+            if v is None or v[0] != 0:
+                raise R0HipError("%s: the seal to be consumed does not verify: %s" % (what, v[1] if v else "verifier did not run"))
+        return seal
 
     def lift(self, segment_seal):
         """risc0 `lift`: one recursion-circuit proof standing for one segment seal."""
-        self._check(segment_seal, self.segment_blob, "lift")
         d = seal_digest(segment_seal)
-        return Node(self._prove(d, np.zeros(8, dtype=np.uint32)), d, np.zeros(8, dtype=np.uint32))
+        zero = np.zeros(8, dtype=np.uint32)
+        seal = self._checked([(segment_seal, self.segment_blob, "lift")], lambda: self._prove(d, zero))
+        return Node(seal, d, zero)
 
     def join(self, a, b):
         """risc0 `join`: one recursion-circuit proof standing for two recursion proofs (seals given as arrays or Nodes)."""
         sa, sb = (a.seal if isinstance(a, Node) else a), (b.seal if isinstance(b, Node) else b)
-        self._check(sa, self.recursion_blob, "join (left)")
-        self._check(sb, self.recursion_blob, "join (right)")
         da, db = seal_digest(sa), seal_digest(sb)
-        return Node(self._prove(da, db), da, db)
+        seal = self._checked([(sa, self.recursion_blob, "join (left)"), (sb, self.recursion_blob, "join (right)")], lambda: self._prove(da, db))
+        return Node(seal, da, db)
 
     def fold(self, nodes):
         """Left-to-right binary fold of this rank's own nodes (log depth)."""
