@@ -43,6 +43,49 @@ def pmc_traffic(kernel):
     return best
 
 
+def spawn_ranks(script, argv, n, extra_env=None):
+    """`python bench.py --gpus N` typed as such: this process -- which has not touched torch, HIP or the GPU -- starts N fresh
+    child processes of the same command line, one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays
+    rank 0's stdout (the JSON line) and returns non-zero if any rank failed.  Nothing is re-exec'd from a process that has
+    initialised the GPU.  (The driver's `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE itself and
+    never reaches this function.)"""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that dies before a barrier would leave its peers waiting in it (RCCL: until the watchdog's timeout): as soon as one
+    # rank has failed, the others -- exactly the processes started above -- are ended
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            time.sleep(2.0)  # let the peers notice by themselves first (their own error message is the better one)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    codes = [p.wait() for p in procs]
+    reader.join(10)
+    out = b"".join(c for c in chunks if c)
+    sys.stdout.write(out.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % ", ".join("rank %d exit %d" % rc for rc in bad))
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,18 +97,31 @@ def main():
     ap.add_argument("--cpu-po2", type=int, default=18, help="po2 of the bounded CPU-baseline sample: 18 = BASELINE.json configs[0] (0 disables)")
     ap.add_argument("--segments", type=int, default=0, help="BASELINE configs[2]/[3]: prove a fixed batch of this many segments, sharded "
                                                               "round-robin over the ranks (strong scaling); 0 = the default weak-scaling steps")
+    ap.add_argument("--seal-dir", default="", help="with --segments: write the seal of every --keep-every-th segment there (seal_<index>.npy) for checking")
+    ap.add_argument("--keep-every", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rehearsing ranks on one box)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--rehearse-without-gpu", type=float, default=0.0, metavar="MS",
+                    help="TEST ONLY: exercise the multi-process harness (spawn, rendezvous, barrier, reductions, JSON relay) on a box "
+                         "without a GPU -- a step sleeps MS milliseconds instead of proving and the line printed says so; implies gloo")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="TEST ONLY (with --rehearse-without-gpu): this rank raises inside its step")
     args = ap.parse_args()
+
+    import __graft_entry__ as entry
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no outer launcher: build once here (the ranks then load finished binaries), then one fresh process per GPU
+        entry.ensure_built()
+        raise SystemExit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    if args.rehearse_without_gpu > 0:
+        return rehearse(args)
 
     import numpy as np
     import torch
 
-    import __graft_entry__ as entry
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         entry.ensure_built()  # no-op when the binaries travelled with the snapshot
-    import hyperfridge_r0_amd as r0
-    from hyperfridge_r0_amd import driver
+    from hyperfridge_r0_amd import driver  # (importing the package does not load libr0hip.so yet)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -73,7 +129,9 @@ def main():
     torch.cuda.set_device(local_rank)
     env = driver.DistEnv(backend=args.backend, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     if env.world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, env.world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, env.world))
+    env.barrier()  # local rank 0 may have been building: nobody loads the library before it is finished
+    import hyperfridge_r0_amd as r0
 
     po2, n_ctx = args.po2, max(1, args.contexts)
     blob = np.fromfile(entry.circuit_blob_path(args.circuit), dtype=np.uint32)
@@ -87,19 +145,42 @@ def main():
         hal.sync()
         lanes.append(dict(hal=hal, circuit=circuit, code=code, data=data, glob=glob_, seal_words=0))
 
-    def prove_on(lane):
-        lane["seal_words"] = lane["hal"].prove_segment(lane["circuit"], po2, lane["code"], lane["data"], lane["glob"]).size
+    def prove_on(lane, seed=None, keep_as=None):
+        if seed is not None:  # another segment: its witness is generated on the device, into the lane's buffers
+            lane["glob"] = lane["hal"].witgen_into(lane["circuit"], po2, seed, lane["code"], lane["data"])
+        seal = lane["hal"].prove_segment(lane["circuit"], po2, lane["code"], lane["data"], lane["glob"])
+        lane["seal_words"] = seal.size
+        lane["proved"] = lane.get("proved", 0) + 1
+        if keep_as is not None:
+            lane.setdefault("kept", []).append((keep_as, seal))
 
-    def step(_i):
-        if n_ctx == 1:
-            prove_on(lanes[0])
-        else:  # ctypes releases the GIL inside the library: the contexts' streams overlap on the device
-            ts = [threading.Thread(target=prove_on, args=(ln,)) for ln in lanes]
+    def run_lanes(work):
+        """work(lane) on every lane, one host thread each (ctypes releases the GIL inside the library: the contexts' streams
+        overlap on the device).  Returns the number of segments actually proved; the first exception of any lane is re-raised
+        here, on the main thread, so a failed lane can neither inflate the count nor let the process exit 0."""
+        before = sum(ln.get("proved", 0) for ln in lanes)
+        errors = []
+
+        def guarded(lane):
+            try:
+                work(lane)
+            except BaseException as exc:  # noqa: BLE001 -- reported below
+                errors.append(exc)
+
+        if len(lanes) == 1:
+            guarded(lanes[0])
+        else:
+            ts = [threading.Thread(target=guarded, args=(ln,)) for ln in lanes]
             for t in ts:
                 t.start()
             for t in ts:
                 t.join()
-        return n_ctx
+        if errors:
+            raise errors[0]
+        return sum(ln.get("proved", 0) for ln in lanes) - before
+
+    def step(_i):
+        return run_lanes(prove_on)
 
     def steps_back_to_back(n):
         """n steps = n segments on every lane; a lane starts its next segment as soon as its previous one is out (no join
@@ -107,12 +188,7 @@ def main():
         def run(lane):
             for _ in range(n):
                 prove_on(lane)
-        ts = [threading.Thread(target=run, args=(ln,)) for ln in lanes]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        return n * n_ctx
+        return run_lanes(run)
 
     def device_sync():
         for ln in lanes:
@@ -120,29 +196,46 @@ def main():
         torch.cuda.synchronize()
 
     if args.segments:
-        # fixed batch: rank r owns segments r, r + world, ...; each in-flight context drains its share of them.  The proving
-        # cost does not depend on the witness values, so the resident witnesses are reused instead of regenerating 0.8 GiB
-        # per segment inside the timed region.
+        # fixed batch (BASELINE.json configs[2]): rank r owns segments r, r + world, ...; each in-flight context drains its share
+        # of them.  Every segment is a different one: its witness (seed 5000 + segment index) is generated on the device inside the
+        # timed region, as a deployment would generate it from the preflight trace.
         mine = driver.shard_segments(args.segments, env.world, env.rank)
         shares = [mine[k::n_ctx] for k in range(n_ctx)]
+        keep = (lambda s: s if (args.seal_dir and args.keep_every > 0 and s % args.keep_every == 0) else None)
 
         def drain(_i):
-            def run(lane, todo):
-                for _ in todo:
-                    prove_on(lane)
-            ts = [threading.Thread(target=run, args=(ln, sh)) for ln, sh in zip(lanes, shares)]
-            for t in ts:
-                t.start()
-            for t in ts:
-                t.join()
-            return len(mine)
+            def run(lane):
+                for s in shares[lanes.index(lane)]:
+                    prove_on(lane, seed=5000 + s, keep_as=keep(s))
+            return run_lanes(run)
 
         step(-1)
         elapsed, units = driver.run_timed(env, drain, 1, 0, device_sync)
         args.steps, scaling = 1, "strong"
+        if args.seal_dir:
+            os.makedirs(args.seal_dir, exist_ok=True)
+            for ln in lanes:
+                for idx, seal in ln.get("kept", []):
+                    np.save(os.path.join(args.seal_dir, "seal_%04d.npy" % idx), seal)
+        incl = None
     else:
         elapsed, units = driver.run_timed(env, step, args.steps, args.warmup, device_sync, many_fn=steps_back_to_back if n_ctx > 1 else None)
         scaling = "weak"
+        # the same K steps once more with witness generation inside the timed region (risc0's prove_segment includes it, SURVEY.md
+        # 3.4 step 2): every segment gets a fresh synthetic witness, generated on the device into the lane's buffers.  Not `value`.
+        counter = [0]
+
+        def steps_with_witgen(n):
+            def run(lane):
+                k = lanes.index(lane)
+                for i in range(n):
+                    prove_on(lane, seed=9000 + (counter[0] + i) * 64 + env.rank * 16 + k)
+            got = run_lanes(run)
+            counter[0] += n
+            return got
+
+        el2, un2 = driver.run_timed(env, lambda i: steps_with_witgen(1), args.steps, 0, device_sync, many_fn=steps_with_witgen if n_ctx > 1 else None)
+        incl = un2 / el2
     # per-kernel accounting: HIP events around every launch, on one context running alone, over as many segments as were
     # timed (outside the timed region, so the events neither perturb `value` nor see another context's kernels)
     lanes[0]["hal"].kernel_timing(True)
@@ -196,10 +289,13 @@ def main():
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
             "value": round(value, 4), "unit": "segments/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "value_with_witgen_in_timed_region": round(value, 4) if incl is None else round(incl, 4),
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "configs[1] shape: 2^%d-row segments, synthetic circuit %s.r0c W=(%d code,%d data,%d accum), %d segment(s) "
-                                   "in flight per GPU, witness resident in HBM; no bundled camt53 trace exists (needs the risc0 executor)" % (
-                                       po2, args.circuit, circuit.group_size[1], circuit.group_size[2], circuit.group_size[0], n_ctx),
+            "config": {"workload": ("configs[2] shape" if args.segments else "configs[1] shape") + ": 2^%d-row segments, synthetic circuit %s.r0c W=(%d code,%d data,%d accum), %d segment(s) "
+                                   "in flight per GPU, %s; no bundled camt53 trace exists (needs the risc0 executor)" % (
+                                       po2, args.circuit, circuit.group_size[1], circuit.group_size[2], circuit.group_size[0], n_ctx,
+                                       "fixed batch of %d distinct segments, witness generated on the device inside the timed region" % args.segments if args.segments
+                                       else "witness resident in HBM"),
                        "po2": po2, "columns": cols, "taps": circuit.n_taps, "seal_words": int(lanes[0]["seal_words"]),
                        "segments_per_step_per_gpu": n_ctx, "fixed_batch_segments": args.segments or None,
                        "parallelism": "segment-parallel x%d" % env.world},
@@ -219,6 +315,30 @@ def main():
             ln[key].free()
         ln["hal"].close()
     env.close()
+
+
+def rehearse(args):
+    """The harness around the proving step, without the proving step (no GPU needed): what tests/test_distributed.py drives
+    through `python bench.py --gpus 2 --rehearse-without-gpu MS`.  The printed line is NOT a measurement and is labelled so."""
+    from hyperfridge_r0_amd import driver
+    env = driver.DistEnv(backend="gloo")
+    if env.world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, env.world))
+    n_ctx = max(1, args.contexts)
+
+    def step(i):
+        if env.rank == args.fail_rank and i >= 0:
+            raise RuntimeError("rehearsal: rank %d fails on purpose" % env.rank)
+        time.sleep(args.rehearse_without_gpu * 1e-3)
+        return n_ctx
+
+    elapsed, units = driver.run_timed(env, step, args.steps, args.warmup)
+    if env.rank == 0:
+        print(json.dumps({"metric": "REHEARSAL of the multi-process harness -- no proving, not a measurement", "value": round(units / elapsed, 4),
+                          "unit": "sleeps/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+                          "data": "none", "scaling": "weak"}))
+    env.close()
+    return 0
 
 
 def cpu_baseline(blob, cpu_po2, po2):
@@ -246,4 +366,4 @@ def cpu_baseline(blob, cpu_po2, po2):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

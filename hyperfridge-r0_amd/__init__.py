@@ -76,6 +76,8 @@ _SIGNATURES = {
     "r0h_proof_finish": [_vp, _vp, _vp, _sz, _c.POINTER(_sz)],
     "r0h_proof_abort": [_vp],
     "r0h_verify_seal": [_vp, _sz, _vp, _vp, _vp, _sz, _c.POINTER(_c.c_int), _c.POINTER(_u32)],
+    "r0h_verify_seal_bound": [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _c.POINTER(_c.c_int), _c.POINTER(_u32), _vp],
+    "r0h_code_root": [_vp, _vp, _u32, _u32, _vp],
     "r0h_serde_encode_str": [_vp, _sz, _vp, _sz, _c.POINTER(_sz)],
     "r0h_serde_decode_str": [_vp, _sz, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_sz)],
     "r0h_journal_commitment_span": [_vp, _sz, _c.POINTER(_sz), _c.POINTER(_sz)],
@@ -212,10 +214,11 @@ def emit_eval_check_source(blob):
     return src
 
 
-def verify_seal(blob, seal, poseidon2_consts=None):
-    """Host-side check of a seal against a circuit blob (r0h_verify_seal; needs no GPU): returns (verdict, reason, po2),
+def verify_seal(blob, seal, poseidon2_consts=None, code_root=None):
+    """Host-side check of a seal against a circuit blob (r0h_verify_seal_bound; needs no GPU): returns (verdict, reason, po2),
     verdict 0 = accepted.  poseidon2_consts = (round_constants[29*24], diag_m1[24]) canonical words, or None for the
-    compiled-in table.  Mirrors `receipt.verify(image_id)` (verifier/src/main.rs:124-126)."""
+    compiled-in table.  code_root = the program's control root at the seal's trace size (Hal.code_root); None leaves the
+    seal unbound to any program (proof-system tests only).  Mirrors `receipt.verify(image_id)` (verifier/src/main.rs:124-126)."""
     b, pb = _u32arr(blob)
     s_, ps = _u32arr(seal)
     prc = pdg = None
@@ -225,8 +228,23 @@ def verify_seal(blob, seal, poseidon2_consts=None):
         if rc.size != 29 * 24 or dg.size != 24:
             raise R0HipError("verify_seal: Poseidon2 tables must hold 29*24 and 24 words")
     verdict, po2 = _c.c_int(-1), _u32(0)
-    _check(lib().r0h_verify_seal(pb, b.size, prc, pdg, ps, s_.size, ctypes.byref(verdict), ctypes.byref(po2)))
+    proot = None
+    if code_root is not None:
+        root, proot = _u32arr(code_root)
+        if root.size != 8:
+            raise R0HipError("verify_seal: a code root is 8 words")
+    _check(lib().r0h_verify_seal_bound(pb, b.size, prc, pdg, ps, s_.size, proot, ctypes.byref(verdict), ctypes.byref(po2), None))
     return verdict.value, lib().r0h_verify_reason(verdict.value).decode(), po2.value
+
+
+def seal_code_root(blob, seal):
+    """The CODE root a seal commits to (read out while verifying it; zeros if the seal is rejected before that point)."""
+    b, pb = _u32arr(blob)
+    s_, ps = _u32arr(seal)
+    verdict, po2 = _c.c_int(-1), _u32(0)
+    out = np.zeros(8, dtype=np.uint32)
+    _check(lib().r0h_verify_seal_bound(pb, b.size, None, None, ps, s_.size, None, ctypes.byref(verdict), ctypes.byref(po2), out.ctypes.data_as(_vp)))
+    return out
 
 
 def serde_encode_str(text):
@@ -475,6 +493,12 @@ class Hal:
         _check(lib().r0h_witgen(self.ctx, circuit.handle, po2, seed, code.handle, data.handle, glob.ctypes.data_as(_vp)))
         return code, data, glob[:circuit.n_global]
 
+    def witgen_into(self, circuit, po2, seed, code, data):
+        """Regenerate the synthetic witness of another segment into existing buffers; returns its public inputs."""
+        glob = np.zeros(max(circuit.n_global, 1), dtype=np.uint32)
+        _check(lib().r0h_witgen(self.ctx, circuit.handle, po2, seed, code.handle, data.handle, glob.ctypes.data_as(_vp)))
+        return glob[:circuit.n_global]
+
     def accum(self, circuit, po2, code, data, mix):
         n = 1 << po2
         m, pm = _u32arr(mix)
@@ -498,6 +522,21 @@ class Hal:
         _check(lib().r0h_prove_segment(self.ctx, circuit.handle, po2, code.handle, data.handle, pg,
                                        seal.ctypes.data_as(_vp), seal.size, ctypes.byref(n)))
         return seal[:n.value].copy()
+
+    def code_root(self, circuit, po2, code=None):
+        """Control root of the circuit at 2^po2 rows: Merkle root of its committed CODE group (r0h_code_root).  Synthetic
+        circuits regenerate their fixed CODE columns; pass `code` for a circuit that brings its own."""
+        own = None
+        if code is None:
+            code, own, _ = self.witgen(circuit, po2, seed=0)
+        out = np.zeros(8, dtype=np.uint32)
+        try:
+            _check(lib().r0h_code_root(self.ctx, code.handle, circuit.group_size[GROUP_CODE], po2, out.ctypes.data_as(_vp)))
+        finally:
+            if own is not None:
+                own.free()
+                code.free()
+        return out
 
     def proof_begin(self, circuit, po2, code, data, glob):
         """Commit CODE and DATA; returns (proof handle, accumulation mix words)."""

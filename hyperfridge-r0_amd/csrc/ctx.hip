@@ -200,6 +200,7 @@ const char* r0h_ctx_create(int device, r0h_ctx** out) {
   R0H_TRY_HIP(hipGetDeviceCount(&n));
   R0H_REQUIRE(device >= 0 && device < n, "r0h_ctx_create: device %d not present (%d visible); no CPU fallback exists", device, n);
   R0H_TRY_HIP(hipSetDevice(device));
+  R0H_TRY(ntt_init_device());
   r0h_ctx* ctx = new r0h_ctx();
   ctx->device = device;
   R0H_TRY_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));

@@ -150,6 +150,8 @@ const char* evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, cons
                          r0h_buf* out, bool bitrev_coeffs);
 // in-place bit reversal of `count` columns of 2^po2 extension elements (16-byte units)
 const char* bit_reverse_ext(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
+// per-device kernel attributes of the NTT family (LDS limits); called by r0h_ctx_create with the device current
+const char* ntt_init_device();
 void ctx_retain(r0h_ctx* ctx);
 void ctx_release(r0h_ctx* ctx);
 // host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table

@@ -9,8 +9,6 @@
 //            local DIFs with the 1/N normalisation folded into the final store.
 // The strided pass stages a [2^H][T] tile (T consecutive residues, 64-byte rows at T=16) so every global access is a
 // run of T words; the local pass moves whole contiguous chunks.  Column-major batches map to blockIdx.y.
-#include <atomic>
-
 #include "internal.hpp"
 
 namespace r0h {
@@ -557,12 +555,7 @@ static void launch_strided16_wl(r0h_ctx* ctx, dim3 grid, uint32_t* io, const uin
   const dim3 block(16u << (H - 4));
   if (L >= 5) {  // two residues per thread: 128-byte rows
     constexpr size_t lds = ((size_t)1 << H) * (16 * 2 + 2) * 4;
-    if (lds > 65536) {  // beyond the default limit LDS has to be asked for: once per kernel instantiation and device
-      static std::atomic<uint64_t> raised{0};
-      const uint64_t bit = (uint64_t)1 << (ctx->device & 63);
-      if (!(raised.fetch_or(bit) & bit))
-        (void)hipFuncSetAttribute((const void*)ntt_strided16_kernel<WL, DIR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    // tiles above 64 KB of LDS: the limit was raised for this device when its first context was created (ntt_init_device)
     hipLaunchKernelGGL((ntt_strided16_kernel<WL, DIR, 2>), dim3(grid.x / 2, grid.y), block, lds, ctx->stream, io, in, n, L, tw, c);
     return;
   }
@@ -575,6 +568,26 @@ static void launch_strided16(r0h_ctx* ctx, uint32_t H, dim3 grid, uint32_t* io, 
     case 9: launch_strided16_wl<1, DIR>(ctx, grid, io, in, n, L, tw, c); break;
     default: launch_strided16_wl<2, DIR>(ctx, grid, io, in, n, L, tw, c); break;
   }
+}
+
+// Dynamic LDS above the 64 KB default has to be asked for per kernel instantiation and device.  Done for every instantiation
+// that needs it when a context is created (r0h_ctx_create, after hipSetDevice), so no launch can race the request and a
+// refusal is reported instead of surfacing later as "launch failed".
+template <int WL, int DIR>
+static const char* raise_lds_limit() {
+  constexpr size_t lds = ((size_t)1 << (8 + WL)) * (16 * 2 + 2) * 4;
+  if (lds <= 65536) return nullptr;
+  R0H_TRY_HIP(hipFuncSetAttribute((const void*)ntt_strided16_kernel<WL, DIR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return nullptr;
+}
+const char* ntt_init_device() {
+  R0H_TRY((raise_lds_limit<0, 0>()));
+  R0H_TRY((raise_lds_limit<0, 1>()));
+  R0H_TRY((raise_lds_limit<1, 0>()));
+  R0H_TRY((raise_lds_limit<1, 1>()));
+  R0H_TRY((raise_lds_limit<2, 0>()));
+  R0H_TRY((raise_lds_limit<2, 1>()));
+  return nullptr;
 }
 
 static const char* launch_check(const char* what) {

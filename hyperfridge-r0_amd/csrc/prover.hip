@@ -45,7 +45,7 @@ struct Rng {
   explicit Rng(const P2Consts* kk) : k(kk), pool_used(0) { memset(cells, 0, sizeof cells); }
   void mix(const uint32_t digest[8]) {
     if (pool_used != 0) { p2_mix_host(*k, cells); pool_used = 0; }
-    for (int i = 0; i < 8; i++) cells[i] = add(cells[i], digest[i] % P);
+    for (int i = 0; i < 8; i++) cells[i] = add(cells[i], digest[i]);  // digests come from the device or the host sponge: canonical
     p2_mix_host(*k, cells);
   }
   uint32_t elem() {
@@ -559,6 +559,21 @@ const char* r0h_proof_finish(r0h_proof* proof, const r0h_buf* accum, uint32_t* s
 const char* r0h_proof_abort(r0h_proof* proof) {
   delete proof;
   return nullptr;
+}
+
+// The control root of a program at one trace size: the Merkle root of its committed CODE group (risc0 keeps one such root per
+// po2 -- the control id -- and `verify` compares the seal's CODE commitment with it).  Same steps as the sequencer's commit_code.
+const char* r0h_code_root(r0h_ctx* ctx, const r0h_buf* code, uint32_t count, uint32_t po2, uint32_t root_out[8]) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && code && root_out, "r0h_code_root: NULL argument");
+  R0H_REQUIRE(count >= 1, "r0h_code_root: the CODE group has no columns");
+  R0H_REQUIRE(po2 >= 9 && po2 <= R0H_MAX_PO2, "r0h_code_root: po2 %u outside [9, %u]", po2, R0H_MAX_PO2);
+  R0H_TRY_HIP(hipSetDevice(ctx->device));
+  Scope sc;
+  Group g(count, (size_t)4 << po2);
+  R0H_TRY(group_from_witness(ctx, sc, g, code, po2));
+  return r0h_buf_d2h(ctx, g.tree.nodes, 32, root_out, 32);
+  R0H_GUARD_END
 }
 
 const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out) {

@@ -49,7 +49,7 @@ class SealReader {
   void skip_to(size_t pos) { pos_ = pos < n_ ? pos : n_; }
   void commit(const uint32_t digest[8]) {
     if (used_ != 0) { p2_mix_host(k_, cells_); used_ = 0; }
-    for (int i = 0; i < 8; i++) cells_[i] = add(cells_[i], digest[i] % P);
+    for (int i = 0; i < 8; i++) cells_[i] = add(cells_[i], digest[i]);  // canonical: every digest is checked when it is read
     p2_mix_host(k_, cells_);
   }
   void commit_elems(const uint32_t* e, size_t n) {
@@ -99,7 +99,7 @@ class TreeVerifier {
     }
     top_size_ = (size_t)1 << top_layer;
     top_.assign(2 * top_size_ * 8, 0);
-    memcpy(&top_[top_size_ * 8], io.take(top_size_ * 8), top_size_ * 32);
+    memcpy(&top_[top_size_ * 8], io.take_elems(top_size_ * 8), top_size_ * 32);  // digest words are field elements
     for (size_t i = top_size_; i-- > 1;) hash_pair(io.consts(), &top_[2 * i * 8], &top_[(2 * i + 1) * 8], &top_[i * 8]);
     io.commit(&top_[8]);
   }
@@ -114,6 +114,8 @@ class TreeVerifier {
     size_t node = row + rows_;
     for (; node >= 2 * top_size_; node >>= 1) {
       const uint32_t* sibling = io.take(8);
+      for (int i = 0; i < 8; i++)
+        if (sibling[i] >= P) throw Reject{R0H_VERIFY_BAD_ELEM};  // two word sequences must not name one digest
       uint32_t parent[8];
       if (node & 1) hash_pair(k, sibling, cur, parent); else hash_pair(k, cur, sibling, parent);
       memcpy(cur, parent, 32);
@@ -122,6 +124,7 @@ class TreeVerifier {
     return values;
   }
 
+  const uint32_t* root() const { return &top_[8]; }
   size_t opening_words() const { return cols_ + 8 * (log2_exact(rows_) - log2_exact(top_size_)); }
 
  private:
@@ -161,7 +164,8 @@ Fp4 constraint_at_z(const r0h_circuit& c, const Fp4& poly_mix, const std::vector
   return mx[c.ret].tot;
 }
 
-void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_t seal_words, uint32_t* po2_out) {
+void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_t seal_words, uint32_t* po2_out, const uint32_t* expected_code_root,
+            uint32_t* code_root_out) {
   SealReader io(k, seal, seal_words);
   {
     static const char proof_system_info[] = "RISC0_STARK:v1__";
@@ -183,6 +187,10 @@ void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_
   // commitments, in the order the prover made them
   std::unique_ptr<TreeVerifier> group[4];  // ACCUM, CODE, DATA, CHECK
   group[R0H_GROUP_CODE].reset(new TreeVerifier(io, domain, c.group_size[R0H_GROUP_CODE], R0H_VERIFY_MERKLE_GROUP));
+  // risc0-zkp verify/mod.rs `check_code(po2, root)`: the CODE commitment is the program's identity at this trace size.  Without
+  // this comparison a prover may commit any CODE columns (e.g. selectors that switch constraints off).
+  if (code_root_out) memcpy(code_root_out, group[R0H_GROUP_CODE]->root(), 32);
+  if (expected_code_root && memcmp(expected_code_root, group[R0H_GROUP_CODE]->root(), 32) != 0) throw Reject{R0H_VERIFY_CODE_ROOT};
   group[R0H_GROUP_DATA].reset(new TreeVerifier(io, domain, c.group_size[R0H_GROUP_DATA], R0H_VERIFY_MERKLE_GROUP));
   std::vector<uint32_t> mix(c.n_mix);
   for (uint32_t& m : mix) m = io.elem();
@@ -364,8 +372,8 @@ extern "C" {
 const char* r0h_verify_reason(int verdict) {
   static const char* const names[] = {"ok", "seal truncated", "bad po2", "group merkle path rejected", "constraint check mismatch at z",
                                       "fri merkle path rejected", "fri fold goal mismatch", "fri final polynomial mismatch",
-                                      "trailing words in seal", "non-canonical field element"};
-  return verdict >= 0 && verdict <= R0H_VERIFY_BAD_ELEM ? names[verdict] : "unknown";
+                                      "trailing words in seal", "non-canonical field element", "code root is not the expected control root"};
+  return verdict >= 0 && verdict <= R0H_VERIFY_CODE_ROOT ? names[verdict] : "unknown";
 }
 
 const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t digest_out[8]) {
@@ -373,18 +381,22 @@ const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t di
   R0H_REQUIRE((seal || seal_words == 0) && digest_out, "r0h_seal_digest: NULL argument");
   std::unique_ptr<P2Consts> k(new P2Consts);
   p2_default_host(*k);
-  std::vector<uint32_t> elems(seal, seal + seal_words);
-  for (uint32_t& w : elems) w %= P;  // a seal's words are field words or 32-bit indices/positions; the sponge absorbs field words
-  p2_hash_elems_host(*k, elems.data(), elems.size(), digest_out);
+  // every word of a well-formed seal is a canonical field element (globals, digests, interpolants, opened columns): reducing
+  // mod p here would give two different word sequences the same name
+  for (size_t i = 0; i < seal_words; i++) R0H_REQUIRE(seal[i] < P, "r0h_seal_digest: word %zu is not a canonical field element", i);
+  p2_hash_elems_host(*k, seal, seal_words, digest_out);
   return nullptr;
   R0H_GUARD_END
 }
 
-const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
-                            const uint32_t* seal, size_t seal_words, int* verdict_out, uint32_t* po2_out) {
+static const char* verify_entry(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
+                                const uint32_t* seal, size_t seal_words, const uint32_t* expected_code_root, int* verdict_out, uint32_t* po2_out,
+                                uint32_t* code_root_out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(blob && (seal || seal_words == 0) && verdict_out, "r0h_verify_seal: NULL argument");
   R0H_REQUIRE((p2_round_constants == nullptr) == (p2_diag_m1 == nullptr), "r0h_verify_seal: pass both Poseidon2 tables or neither");
+  if (expected_code_root)
+    for (int i = 0; i < 8; i++) R0H_REQUIRE(expected_code_root[i] < P, "r0h_verify_seal: expected code root word %d not canonical", i);
   r0h_circuit c;
   R0H_TRY(parse_blob(&c, blob, blob_words));
   std::unique_ptr<P2Consts> k(new P2Consts);
@@ -396,14 +408,26 @@ const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint3
     p2_default_host(*k);
   }
   if (po2_out) *po2_out = 0;
+  if (code_root_out) memset(code_root_out, 0, 32);
   try {
-    verify(c, *k, seal, seal_words, po2_out);
+    verify(c, *k, seal, seal_words, po2_out, expected_code_root, code_root_out);
     *verdict_out = R0H_VERIFY_OK;
   } catch (const Reject& r) {
     *verdict_out = r.code;
   }
   return nullptr;
   R0H_GUARD_END
+}
+
+const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
+                            const uint32_t* seal, size_t seal_words, int* verdict_out, uint32_t* po2_out) {
+  return verify_entry(blob, blob_words, p2_round_constants, p2_diag_m1, seal, seal_words, nullptr, verdict_out, po2_out, nullptr);
+}
+
+const char* r0h_verify_seal_bound(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
+                                  const uint32_t* seal, size_t seal_words, const uint32_t* expected_code_root, int* verdict_out,
+                                  uint32_t* po2_out, uint32_t* code_root_out) {
+  return verify_entry(blob, blob_words, p2_round_constants, p2_diag_m1, seal, seal_words, expected_code_root, verdict_out, po2_out, code_root_out);
 }
 
 }  // extern "C"

@@ -118,16 +118,36 @@ def public_inputs_of(recursion_blob, seal):
     return seal[:8].copy(), seal[8:16].copy()
 
 
+FAILED = np.array([0xFFFFFFFF], dtype=np.uint32)  # handed up instead of a seal by a rank whose subtree could not be proved
+EMPTY = np.zeros(0, dtype=np.uint32)               # handed up by a rank that owns no segment (segments < world)
+
+
 def join_across_ranks(recursor, node, rank, world, send, recv):
     """Run the cross-rank part of the tree.  `send(array, dst)` / `recv(src) -> array` move one seal (uint32 words).
-    Returns the root Node on rank 0 and None elsewhere."""
+    Returns the root Node on rank 0 and None elsewhere.
+
+    Every rank takes part in every exchange the schedule gives it, whatever happened before: a rank without a node (empty
+    share) hands up an empty message and its partner keeps what it has; a rank whose join failed (or whose child reported a
+    failure) hands up a failure marker instead of blocking its partner, so the failure reaches the root, every rank leaves
+    the tree, and the first error is re-raised on the rank where it happened (and as "a child rank failed" above it)."""
+    failed = None
     for _level, receiver, sender in tree_schedule(world):
         if rank == sender:
-            send(node.seal, receiver)
+            send(FAILED if failed is not None else (EMPTY if node is None else node.seal), receiver)
+            if failed is not None:
+                raise failed
             return None  # this rank's subtree has been handed up
         if rank == receiver:
             other = recv(sender)
-            node = recursor.join(node, Node(other, None, None))
+            if other.size == 1 and other[0] == FAILED[0]:
+                failed = failed or R0HipError("join tree: rank %d reported a failure in its subtree" % sender)
+            elif failed is None and other.size:
+                try:
+                    node = Node(other, None, None) if node is None else recursor.join(node, Node(other, None, None))
+                except Exception as exc:  # noqa: BLE001 -- carried up the tree, re-raised below
+                    failed = exc
+    if failed is not None:
+        raise failed
     return node if rank == 0 else None
 
 

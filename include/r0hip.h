@@ -144,6 +144,9 @@ const char* r0h_proof_begin(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, co
 const char* r0h_proof_finish(r0h_proof* proof, const r0h_buf* accum, uint32_t* seal_out, size_t seal_capacity_words,
                              size_t* seal_words_out);
 const char* r0h_proof_abort(r0h_proof* proof);
+/* Control root of a program at trace size 2^po2: Merkle root of the committed CODE group (count columns of 2^po2 words),
+ * computed exactly as the sequencer commits it.  What a verifier passes to r0h_verify_seal_bound. */
+const char* r0h_code_root(r0h_ctx* ctx, const r0h_buf* code, uint32_t count, uint32_t po2, uint32_t root_out[8]);
 /* Per-phase device time of the last r0h_prove_segment on this context (ms), for bench.py; names are static strings. */
 const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out);
 
@@ -162,11 +165,22 @@ const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float*
 #define R0H_VERIFY_FRI_FINAL 7
 #define R0H_VERIFY_TRAILING 8
 #define R0H_VERIFY_BAD_ELEM 9
+#define R0H_VERIFY_CODE_ROOT 10
 const char* r0h_verify_seal(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants,
                             const uint32_t* p2_diag_m1, const uint32_t* seal, size_t seal_words, int* verdict_out,
                             uint32_t* po2_out);
+/* The same check, bound to a program: risc0-zkp verify/mod.rs calls `check_code(po2, root)` on the CODE commitment, which the
+ * rv32im verifier answers from its table of control roots (one per po2).  expected_code_root (8 canonical words, e.g. from
+ * r0h_code_root) is compared with the root the seal commits to; a mismatch is R0H_VERIFY_CODE_ROOT.  NULL skips the comparison
+ * (then nothing ties the seal to a program: r0h_verify_seal is that form and is meant for tests of the proof system alone).
+ * code_root_out (optional) receives the root found in the seal. */
+const char* r0h_verify_seal_bound(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants,
+                                  const uint32_t* p2_diag_m1, const uint32_t* seal, size_t seal_words,
+                                  const uint32_t* expected_code_root, int* verdict_out, uint32_t* po2_out,
+                                  uint32_t* code_root_out);
 const char* r0h_verify_reason(int verdict); /* static string, do not free */
-/* Poseidon2 sponge (compiled-in table) over a seal's words, each taken mod p: the 8-word name a recursion step commits to */
+/* Poseidon2 sponge (compiled-in table) over a seal's words (all canonical field elements, else an error): the 8-word name a
+ * recursion step commits to */
 const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t digest_out[8]);
 
 /* ---- data formats either side of the path (SURVEY.md 8(a) a0', a0'', a18): pure host code ----

@@ -91,6 +91,8 @@ uint32_t orc_circuit_n_combos(const orc_circuit_t* c);
 void orc_witgen(const orc_circuit_t* c, uint32_t po2, uint64_t seed, uint32_t* code, uint32_t* data, uint32_t* global);
 void orc_witgen_public(const orc_circuit_t* c, uint32_t po2, uint64_t seed, const uint32_t* global_in, uint32_t* code, uint32_t* data,
                        uint32_t* global);
+void orc_witgen_foreign_code(const orc_circuit_t* c, uint32_t po2, uint64_t seed, uint64_t code_seed, const uint32_t* global_in,
+                             uint32_t* code, uint32_t* data, uint32_t* global);
 void orc_accum(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, const uint32_t* mix,
                uint32_t* accum);
 void orc_eval_check(const orc_circuit_t* c, uint32_t po2, const uint32_t* eval_accum, const uint32_t* eval_code,
@@ -108,6 +110,11 @@ size_t orc_prove_segment(const orc_circuit_t* c, const uint32_t* blob, size_t bl
 /* 0 = accepted; otherwise a positive error code naming the first failed check. */
 int orc_verify_segment(const orc_circuit_t* c, const uint32_t* blob, size_t blob_words, const uint32_t* seal,
                        size_t seal_words);
+/* the same, with the CODE commitment compared against the program's control root (8 words; NULL = not compared) */
+int orc_verify_segment_bound(const orc_circuit_t* c, const uint32_t* blob, size_t blob_words, const uint32_t* seal,
+                             size_t seal_words, const uint32_t* expected_code_root);
+/* control root of a CODE group: iNTT + zk shift, expand x4, Merkle root -- as commit_group does it */
+void orc_code_root(const uint32_t* code, uint32_t count, uint32_t po2, uint32_t root[8]);
 const char* orc_verify_strerror(int code);
 
 /* ---- Fiat-Shamir transcript (risc0-zkp core/hash/poseidon2/rng.rs, prove/write_iop.rs) ---- */

@@ -151,6 +151,14 @@ void orc_witgen(const orc_circuit_t* c, uint32_t po2, uint64_t seed, uint32_t* c
 /* global_in != NULL: the caller's public inputs are planted at row 0 of the columns the globals are read from */
 void orc_witgen_public(const orc_circuit_t* c, uint32_t po2, uint64_t seed, const uint32_t* global_in, uint32_t* code, uint32_t* data,
                        uint32_t* global) {
+  orc_witgen_foreign_code(c, po2, seed, CODE_SEED, global_in, code, data, global);
+}
+
+/* A witness over CODE columns that are NOT the program's (fixed columns drawn from another seed, DATA derived from them so that
+ * every constraint still holds): what a cheating prover would commit.  Tests use it to show that only the control-root
+ * comparison of the verifier rejects such a seal. */
+void orc_witgen_foreign_code(const orc_circuit_t* c, uint32_t po2, uint64_t seed, uint64_t code_seed, const uint32_t* global_in,
+                             uint32_t* code, uint32_t* data, uint32_t* global) {
   size_t n = (size_t)1 << po2;
   for (uint32_t k = 0; k < c->n_code; k++) {
     fp_t* col = code + (size_t)k * n;
@@ -161,7 +169,7 @@ void orc_witgen_public(const orc_circuit_t* c, uint32_t po2, uint64_t seed, cons
       if (kind == 0) v = r == 0 ? ORC_ONE : 0;
       else if (kind == 1) v = r == n - 1 ? ORC_ONE : 0;
       else if (kind == 2) v = fp_enc((uint32_t)r);
-      else v = synth_word(CODE_SEED, (1u << 16) | k, (uint32_t)r);
+      else v = synth_word(code_seed, (1u << 16) | k, (uint32_t)r);
       col[r] = v;
     }
   }

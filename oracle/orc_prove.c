@@ -91,6 +91,13 @@ static void group_from_witness(group_t* g, const uint32_t* wit, uint32_t count, 
 }
 static void group_free(group_t* g) { free(g->coeffs); free(g->evaluated); free(g->merkle.nodes); }
 
+void orc_code_root(const uint32_t* code, uint32_t count, uint32_t po2, uint32_t root[8]) {
+  group_t g;
+  group_from_witness(&g, code, count, po2);
+  memcpy(root, g.merkle.nodes + 8, 32);
+  group_free(&g);
+}
+
 /* ------------------------------------------------------------------ FRI prover */
 typedef struct { size_t domain; uint32_t* evaluated; merkle_t merkle; } fri_round_t;
 
@@ -270,7 +277,7 @@ size_t orc_prove_segment(const orc_circuit_t* c, const uint32_t* blob, size_t bl
 }
 
 /* ================================================================== verifier */
-typedef struct { const uint32_t* w; size_t n, pos; orc_rng_t rng; int underflow; } riop_t;
+typedef struct { const uint32_t* w; size_t n, pos; orc_rng_t rng; int underflow, bad_elem; } riop_t;
 static const uint32_t* riop_read(riop_t* io, size_t n) {
   static const uint32_t zeros[4096] = {0};
   if (io->pos + n > io->n) { io->underflow = 1; return n <= 4096 ? zeros : NULL; }
@@ -286,6 +293,7 @@ static int vmerkle_new(vmerkle_t* m, riop_t* io, size_t rows, size_t cols) {
   m->top = (uint32_t*)calloc(ts * 2, 32);
   const uint32_t* src = riop_read(io, ts * 8);
   if (io->underflow || !src) return 1;
+  for (size_t i = 0; i < ts * 8; i++) if (src[i] >= ORC_P) return 2; /* digest words are field elements */
   memcpy(m->top + ts * 8, src, ts * 32);
   for (size_t i = ts; i-- > 1;) orc_hash_pair(m->top + 2 * i * 8, m->top + (2 * i + 1) * 8, m->top + i * 8);
   orc_rng_mix(&io->rng, m->top + 8);
@@ -303,6 +311,7 @@ static const uint32_t* vmerkle_verify(vmerkle_t* m, riop_t* io, size_t idx) {
   while (idx >= 2 * m->p.top_size) {
     const uint32_t* other = riop_read(io, 8);
     if (io->underflow) return NULL;
+    for (int i = 0; i < 8; i++) if (other[i] >= ORC_P) { io->bad_elem = 1; return NULL; }
     if (idx & 1) orc_hash_pair(other, cur, nxt); else orc_hash_pair(cur, other, nxt);
     memcpy(cur, nxt, 32);
     idx /= 2;
@@ -318,17 +327,24 @@ static fp4_t poly_eval4(const fp4_t* coeffs, size_t n, fp4_t x) {
 
 enum {
   V_OK = 0, V_TRUNCATED, V_BAD_PO2, V_MERKLE_GROUP, V_CHECK_MISMATCH, V_FRI_MERKLE, V_FRI_GOAL, V_FRI_FINAL, V_TRAILING,
-  V_BAD_ELEM
+  V_BAD_ELEM, V_CODE_ROOT
 };
 const char* orc_verify_strerror(int code) {
   static const char* const names[] = {"ok", "seal truncated", "bad po2", "group merkle path rejected",
                                       "constraint check mismatch at z", "fri merkle path rejected", "fri fold goal mismatch",
-                                      "fri final polynomial mismatch", "trailing words in seal", "non-canonical field element"};
-  return code >= 0 && code <= V_BAD_ELEM ? names[code] : "unknown";
+                                      "fri final polynomial mismatch", "trailing words in seal", "non-canonical field element",
+                                      "code root is not the expected control root"};
+  return code >= 0 && code <= V_CODE_ROOT ? names[code] : "unknown";
 }
 
 int orc_verify_segment(const orc_circuit_t* c, const uint32_t* blob, size_t blob_words, const uint32_t* seal,
                        size_t seal_words) {
+  return orc_verify_segment_bound(c, blob, blob_words, seal, seal_words, NULL);
+}
+
+/* risc0-zkp verify/mod.rs: `check_code(po2, &code_root)` -- the CODE commitment must be the program's control root */
+int orc_verify_segment_bound(const orc_circuit_t* c, const uint32_t* blob, size_t blob_words, const uint32_t* seal,
+                             size_t seal_words, const uint32_t* expected_code_root) {
   riop_t io;
   memset(&io, 0, sizeof io);
   io.w = seal; io.n = seal_words;
@@ -369,12 +385,15 @@ int orc_verify_segment(const orc_circuit_t* c, const uint32_t* blob, size_t blob
   int n_rounds = 0;
   fp4_t* final_poly = NULL;
 
-  if (vmerkle_new(&vm[ORC_GROUP_CODE], &io, domain, c->group_size[ORC_GROUP_CODE]) ||
-      vmerkle_new(&vm[ORC_GROUP_DATA], &io, domain, c->group_size[ORC_GROUP_DATA])) { rc = V_TRUNCATED; goto done; }
+  int mr;
+#define VM_NEW(m, rows, cols) do { if ((mr = vmerkle_new(m, &io, rows, cols)) != 0) { rc = mr == 2 ? V_BAD_ELEM : V_TRUNCATED; goto done; } } while (0)
+  VM_NEW(&vm[ORC_GROUP_CODE], domain, c->group_size[ORC_GROUP_CODE]);
+  if (expected_code_root && memcmp(expected_code_root, vm[ORC_GROUP_CODE].top + 8, 32) != 0) { rc = V_CODE_ROOT; goto done; }
+  VM_NEW(&vm[ORC_GROUP_DATA], domain, c->group_size[ORC_GROUP_DATA]);
   for (uint32_t i = 0; i < c->n_mix; i++) mix[i] = orc_rng_elem(&io.rng);
-  if (vmerkle_new(&vm[ORC_GROUP_ACCUM], &io, domain, c->group_size[ORC_GROUP_ACCUM])) { rc = V_TRUNCATED; goto done; }
+  VM_NEW(&vm[ORC_GROUP_ACCUM], domain, c->group_size[ORC_GROUP_ACCUM]);
   fp4_t poly_mix = rng_ext(&io.rng);
-  if (vmerkle_new(&vm[3], &io, domain, ORC_CHECK_SIZE)) { rc = V_TRUNCATED; goto done; }
+  VM_NEW(&vm[3], domain, ORC_CHECK_SIZE);
   fp4_t z = rng_ext(&io.rng);
   fp_t back_one = orc_rou_rev(po2);
   {
@@ -431,7 +450,7 @@ int orc_verify_segment(const orc_circuit_t* c, const uint32_t* blob, size_t blob
   while (degree > ORC_FRI_MIN_DEGREE) {
     fdomain[n_rounds] = dom / ORC_FRI_FOLD;
     memset(&fm[n_rounds], 0, sizeof(vmerkle_t));
-    if (vmerkle_new(&fm[n_rounds], &io, dom / ORC_FRI_FOLD, ORC_FRI_FOLD * 4)) { n_rounds++; rc = V_TRUNCATED; goto done; }
+    if ((mr = vmerkle_new(&fm[n_rounds], &io, dom / ORC_FRI_FOLD, ORC_FRI_FOLD * 4)) != 0) { n_rounds++; rc = mr == 2 ? V_BAD_ELEM : V_TRUNCATED; goto done; }
     fmix[n_rounds] = rng_ext(&io.rng);
     n_rounds++;
     dom /= ORC_FRI_FOLD;
@@ -456,7 +475,7 @@ int orc_verify_segment(const orc_circuit_t* c, const uint32_t* blob, size_t blob
     const uint32_t* rows[4];
     for (int g = 0; g < 4; g++) {
       rows[g] = vmerkle_verify(&vm[g], &io, pos);
-      if (!rows[g]) { rc = io.underflow ? V_TRUNCATED : V_MERKLE_GROUP; goto done; }
+      if (!rows[g]) { rc = io.underflow ? V_TRUNCATED : io.bad_elem ? V_BAD_ELEM : V_MERKLE_GROUP; goto done; }
     }
     fp_t x = fp_pow(gen_domain, pos);
     fp4_t cur = fp4_one();
@@ -486,7 +505,7 @@ int orc_verify_segment(const orc_circuit_t* c, const uint32_t* blob, size_t blob
     for (int r = 0; r < n_rounds; r++) {
       size_t rd = fdomain[r], quot = pos / rd, group = pos % rd;
       const uint32_t* col = vmerkle_verify(&fm[r], &io, group);
-      if (!col) { rc = io.underflow ? V_TRUNCATED : V_FRI_MERKLE; goto done; }
+      if (!col) { rc = io.underflow ? V_TRUNCATED : io.bad_elem ? V_BAD_ELEM : V_FRI_MERKLE; goto done; }
       fp4_t v[ORC_FRI_FOLD];
       for (int i = 0; i < ORC_FRI_FOLD; i++)
         for (int k = 0; k < 4; k++) v[i].e[k] = col[k * ORC_FRI_FOLD + i];

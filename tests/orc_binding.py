@@ -42,8 +42,12 @@ class Oracle:
         L.orc_verify_segment.restype = ctypes.c_int
         L.orc_verify_segment.argtypes = [_vp, _vp, _sz, _vp, _sz]
         L.orc_verify_strerror.restype = ctypes.c_char_p
+        L.orc_verify_segment_bound.restype = ctypes.c_int
+        L.orc_verify_segment_bound.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp]
+        L.orc_code_root.argtypes = [_vp, _u32, _u32, _vp]
         L.orc_witgen.argtypes = [_vp, _u32, _u64, _vp, _vp, _vp]
         L.orc_witgen_public.argtypes = [_vp, _u32, _u64, _vp, _vp, _vp, _vp]
+        L.orc_witgen_foreign_code.argtypes = [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp]
         L.orc_accum.argtypes = [_vp, _u32, _vp, _vp, _vp, _vp]
         L.orc_eval_check.argtypes = [_vp, _u32] + [_vp] * 7
         L.orc_poly_ext.argtypes = [_vp] * 6
@@ -208,11 +212,14 @@ class OrcCircuit:
         self.n_taps, self.n_global = L.orc_circuit_n_taps(self.h), L.orc_circuit_n_global(self.h)
         self.n_mix, self.n_combos = L.orc_circuit_n_mix(self.h), L.orc_circuit_n_combos(self.h)
 
-    def witgen(self, po2, seed, globals_in=None):
+    def witgen(self, po2, seed, globals_in=None, code_seed=None):
         n = 1 << po2
         code, data = np.zeros(self.group_size[1] * n, np.uint32), np.zeros(self.group_size[2] * n, np.uint32)
         glob = np.zeros(max(self.n_global, 1), np.uint32)
-        if globals_in is not None:
+        if code_seed is not None:  # a cheating prover's witness: CODE columns that are not the program's
+            gin = None if globals_in is None else u32(globals_in)
+            self.o.L.orc_witgen_foreign_code(self.h, po2, seed, code_seed, None if gin is None else _ptr(gin), _ptr(code), _ptr(data), _ptr(glob))
+        elif globals_in is not None:
             gin = u32(globals_in)
             assert gin.size == self.n_global
             self.o.L.orc_witgen_public(self.h, po2, seed, _ptr(gin), _ptr(code), _ptr(data), _ptr(glob))
@@ -239,10 +246,21 @@ class OrcCircuit:
         assert n, "oracle prover failed (non-zero DEEP remainder?)"
         return seal[:n].copy()
 
-    def verify(self, seal):
+    def verify(self, seal, code_root=None):
         seal = u32(seal)
-        rc = self.o.L.orc_verify_segment(self.h, _ptr(self.blob), self.blob.size, _ptr(seal), seal.size)
+        if code_root is None:
+            rc = self.o.L.orc_verify_segment(self.h, _ptr(self.blob), self.blob.size, _ptr(seal), seal.size)
+        else:
+            root = u32(code_root)
+            rc = self.o.L.orc_verify_segment_bound(self.h, _ptr(self.blob), self.blob.size, _ptr(seal), seal.size, _ptr(root))
         return rc, self.o.L.orc_verify_strerror(rc).decode()
+
+    def code_root(self, code, po2):
+        """Control root of this circuit's CODE group at 2^po2 rows (what the verifier compares the seal's CODE commitment with)."""
+        code = u32(code)
+        out = np.zeros(8, dtype=np.uint32)
+        self.o.L.orc_code_root(_ptr(code), self.group_size[1], po2, _ptr(out))
+        return out
 
 
 def load():

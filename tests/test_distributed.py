@@ -83,3 +83,30 @@ def test_run_timed_with_a_many_steps_callable():
     calls.clear()
     driver.run_timed(env, lambda i: 1 / 0, 4, 0, many_fn=lambda n: calls.append(n) or n)
     assert calls == [4]
+
+
+def _bench(*argv, timeout=240):
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, cwd=ROOT, timeout=timeout,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")})
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, lines
+
+
+def test_bench_py_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (no torchrun around it): the parent starts two fresh ranks before touching torch or the
+    GPU, they rendezvous on 127.0.0.1, run the barrier-bracketed steps, and rank 0's single JSON line comes back through the
+    parent.  The proving step needs a GPU, so the harness is rehearsed with a sleeping step (labelled as such)."""
+    out, lines = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--contexts", "2", "--rehearse-without-gpu", "30")
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and "REHEARSAL" in d["metric"]
+    assert 25.0 < d["ms_per_step"] < 200.0
+    assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 0.02  # units of all ranks / MAX time
+
+
+def test_bench_py_reports_a_failed_rank_with_a_non_zero_exit():
+    out, lines = _bench("--gpus", "3", "--steps", "2", "--warmup", "0", "--rehearse-without-gpu", "10", "--fail-rank", "2")
+    assert out.returncode != 0 and lines == [] and "rank(s) failed" in out.stderr

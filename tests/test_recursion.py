@@ -86,7 +86,12 @@ def test_two_gloo_ranks_exchange_seals_point_to_point():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_rank, args=(r, 2, 29533, out)) for r in range(2)]
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = [ctx.Process(target=_gloo_rank, args=(r, 2, port, out)) for r in range(2)]
     [p.start() for p in procs]
     got = out.get(timeout=120)
     [p.join(60) for p in procs]
@@ -142,3 +147,44 @@ def test_lift_and_join_on_the_device(hal, orc):
     with pytest.raises(r0.R0HipError, match="does not verify"):
         rec.join(lifted[0], seals[1])  # a segment seal is not a recursion seal
     rec.close()
+
+
+def _run_tree(world, leaf_of, recursor_of):
+    boxes = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+    results, errors = [None] * world, [None] * world
+
+    def run(rank):
+        send = lambda words, dst: boxes[(rank, dst)].put(np.array(words, dtype=np.uint32))
+        recv = lambda src: boxes[(src, rank)].get(timeout=10)
+        try:
+            results[rank] = recursion.join_across_ranks(recursor_of(rank), leaf_of(rank), rank, world, send, recv)
+        except Exception as exc:  # noqa: BLE001
+            errors[rank] = exc
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(30) for t in threads]
+    assert not any(t.is_alive() for t in threads), "a rank is still blocked in the tree"
+    return results, errors
+
+
+def test_ranks_without_a_segment_hand_up_an_empty_message():
+    """segments < world: ranks 3.. own nothing; the tree still completes and the root covers the three leaves that exist."""
+    world = 6
+    results, errors = _run_tree(world, lambda r: _HashRecursor.leaf(r) if r < 3 else None, lambda r: _HashRecursor())
+    assert errors == [None] * world
+    rec = _HashRecursor()
+    want = rec.join(rec.join(_HashRecursor.leaf(0), _HashRecursor.leaf(1)), _HashRecursor.leaf(2))
+    assert np.array_equal(results[0].seal, want.seal) and all(r is None for r in results[1:])
+
+
+def test_a_failed_join_reaches_the_root_and_no_rank_stays_blocked():
+    class Failing(_HashRecursor):
+        def join(self, a, b):
+            raise r0.R0HipError("join (left): the seal to be consumed does not verify")
+
+    world = 8
+    results, errors = _run_tree(world, _HashRecursor.leaf, lambda r: Failing() if r == 2 else _HashRecursor())
+    assert "does not verify" in str(errors[2])                       # where it happened
+    assert "reported a failure" in str(errors[0])                    # carried up to the root
+    assert results[0] is None and errors[1] is None and errors[3] is None  # uninvolved ranks handed up and left

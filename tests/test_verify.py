@@ -85,3 +85,56 @@ def test_a_seal_for_one_circuit_is_not_a_seal_for_another(orc):
     other = _blob("small")
     got = r0.verify_seal(other, seal)
     assert got[0] != 0 and got[:2] == orc.circuit(other).verify(seal)
+
+
+def test_a_seal_over_altered_code_columns_is_rejected_once_the_control_root_is_bound(orc):
+    """risc0-zkp verify: `check_code(po2, root)`.  A prover is free to commit any CODE columns -- here one whose first-row
+    selector is moved to row 1 and whose fixed columns are re-drawn, with DATA re-derived so that the constraints still hold
+    -- and the bare proof-system check accepts the seal; only the comparison with the control root ties it to the program."""
+    blob, po2 = _blob("tiny"), 9
+    c = orc.circuit(blob)
+    code, data, glob = c.witgen(po2, 3)
+    root = c.code_root(code, po2)
+    seal = c.prove(po2, code, data, glob)
+    assert r0.verify_seal(blob, seal, code_root=root) == (0, "ok", po2) and c.verify(seal, code_root=root) == (0, "ok")
+    assert np.array_equal(r0.seal_code_root(blob, seal), root)
+    # the honest CODE root does not depend on the segment
+    code2, data2, glob2 = c.witgen(po2, 4)
+    assert np.array_equal(c.code_root(code2, po2), root) and not np.array_equal(data2, data)
+    # another trace size has another control root
+    code10, _, _ = c.witgen(10, 3)
+    assert not np.array_equal(c.code_root(code10, 10), root)
+
+    # a *valid* proof over foreign CODE columns (fixed columns re-drawn, DATA derived from them so every constraint holds):
+    # the proof system alone accepts it -- nothing but the control root notices
+    fcode, fdata, fglob = c.witgen(po2, 3, code_seed=0xBAD)
+    assert not np.array_equal(fcode, code)
+    forged = c.prove(po2, fcode, fdata, fglob)
+    assert forged.size and r0.verify_seal(blob, forged)[0] == 0 and c.verify(forged)[0] == 0
+    assert r0.verify_seal(blob, forged, code_root=root)[:2] == c.verify(forged, code_root=root) == (10, "code root is not the expected control root")
+    wrong = root.copy()
+    wrong[0] = (int(wrong[0]) + 1) % P
+    assert r0.verify_seal(blob, seal, code_root=wrong)[:2] == c.verify(seal, code_root=wrong) == (10, "code root is not the expected control root")
+    with pytest.raises(r0.R0HipError, match="not canonical"):
+        r0.verify_seal(blob, seal, code_root=np.full(8, P, np.uint32))
+
+
+def test_non_canonical_digest_words_are_rejected_everywhere(orc):
+    """Two word sequences must not name one digest: a top-layer or sibling word raised by p is a different seal and is refused
+    (verdict 9) by both verifiers, and r0h_seal_digest refuses to name it."""
+    blob, po2 = _blob("tiny"), 9
+    c = orc.circuit(blob)
+    code, data, glob = c.witgen(po2, 1)
+    seal = c.prove(po2, code, data, glob)
+    first_top = c.n_global + 1  # globals, po2, then the CODE tree's top layer
+    hit = 0
+    for pos in (first_top, first_top + 9, seal.size - 1, seal.size - 8):
+        if int(seal[pos]) + P >= 1 << 32:
+            continue
+        bad = seal.copy()
+        bad[pos] = int(bad[pos]) + P
+        assert r0.verify_seal(blob, bad)[:2] == c.verify(bad) == (9, "non-canonical field element"), pos
+        with pytest.raises(r0.R0HipError, match="canonical"):
+            r0.seal_digest(bad)
+        hit += 1
+    assert hit >= 2

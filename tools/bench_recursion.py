@@ -5,8 +5,9 @@ line with the tree latency.  The recursion circuit is recursion-SHAPED only (hyp
 step consumes are checked by the host-side verifier beside the proof, not inside it.
 
   python tools/bench_recursion.py --segments 8                                    one GPU, whole tree in-process
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-         tools/bench_recursion.py --segments 64 [--backend gloo --share-device]    N ranks, segments sharded
+  python tools/bench_recursion.py --gpus N --segments 64 [--backend gloo --share-device]
+                                   N ranks, segments sharded: this process starts one fresh process per rank before touching the GPU
+                                   (an outer `python -m torch.distributed.run ...` that sets WORLD_SIZE works too)
 """
 import argparse
 import json
@@ -20,20 +21,29 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="ranks to start (one per GPU); 0 = take WORLD_SIZE from the environment, else 1")
     ap.add_argument("--segments", type=int, default=8, help="segment seals over all ranks")
+    ap.add_argument("--circuit", default="bench", help="segment circuit (bench at po2 20 is configs[4]; small for tests)")
     ap.add_argument("--segment-po2", type=int, default=20)
     ap.add_argument("--recursion-po2", type=int, default=18)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal on a one-GPU box; needs --backend gloo)")
     args = ap.parse_args()
 
+    import __graft_entry__ as entry
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import bench  # the same child-rank starter as bench.py: fresh processes, nothing re-exec'd after the GPU was touched
+        entry.ensure_built()
+        raise SystemExit(bench.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     import numpy as np
     import torch
 
-    import __graft_entry__ as entry
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if local == 0:
         entry.ensure_built()
+    if args.segments < world:
+        raise SystemExit("bench_recursion.py: %d segments for %d ranks: every rank needs at least one" % (args.segments, world))
     device = 0 if args.share_device else local
     torch.cuda.set_device(device)
     torch.zeros(1, device="cuda")  # torch initialises HIP before libr0hip.so is loaded
@@ -45,9 +55,10 @@ def main():
     from hyperfridge_r0_amd import driver, recursion
 
     hal = r0.Hal(device)
-    seg_blob = np.fromfile(entry.circuit_blob_path("bench"), dtype=np.uint32)
+    seg_blob = np.fromfile(entry.circuit_blob_path(args.circuit), dtype=np.uint32)
     rec_blob = np.fromfile(entry.circuit_blob_path("recursion"), dtype=np.uint32)
-    seg = hal.load_circuit(seg_blob, entry.code_object_path("bench"))
+    seg_co = entry.code_object_path(args.circuit)
+    seg = hal.load_circuit(seg_blob, seg_co if os.path.exists(seg_co) else None)
     rec = recursion.Recursor(hal, rec_blob, seg_blob, entry.code_object_path("recursion"), po2=args.recursion_po2)
     mine = driver.shard_segments(args.segments, world, rank)
 
