@@ -90,6 +90,15 @@ _SIGNATURES = {
     "r0h_receipt_new": [_c.c_int, _vp, _sz, _pp],
     "r0h_receipt_add_segment": [_vp, _vp, _sz, _u32],
     "r0h_receipt_free": [_vp],
+    "r0h_receipt_add_segment_claim": [_vp, _vp, _sz, _u32, _vp, _vp],
+    "r0h_receipt_segment_claim": [_vp, _sz, _vp, _c.POINTER(_c.c_int)],
+    "r0h_receipt_verify": [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_c.c_int), _c.POINTER(_sz), _c.POINTER(_c.c_int)],
+    "r0h_sha256": [_vp, _sz, _vp],
+    "r0h_tagged_struct": [_cp, _vp, _sz, _vp, _sz, _vp],
+    "r0h_system_state_digest": [_vp, _vp],
+    "r0h_output_digest": [_vp, _sz, _vp, _vp],
+    "r0h_claim_digest": [_vp, _vp],
+    "r0h_claim_globals": [_vp, _vp],
     "r0h_receipt_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_receipt_segment": [_vp, _sz, _pp, _c.POINTER(_sz), _c.POINTER(_u32)],
     "r0h_receipt_to_json": [_vp, _pp],
@@ -103,6 +112,7 @@ _PLAIN = {
     "r0h_receipt_kind": ([_vp], _c.c_int),
     "r0h_receipt_n_segments": ([_vp], _sz),
     "r0h_verify_reason": ([_c.c_int], _cp),
+    "r0h_receipt_verify_reason": ([_c.c_int], _cp),
     "r0h_buf_device_ptr": ([_vp], _vp),
     "r0h_buf_bytes": ([_vp], _sz),
     "r0h_circuit_group_size": ([_vp, _u32], _u32),
@@ -301,6 +311,91 @@ def seal_digest(seal):
     return out
 
 
+class SystemState(ctypes.Structure):
+    """risc0-binfmt `SystemState` (r0h_system_state)."""
+    _fields_ = [("pc", _u32), ("merkle_root", ctypes.c_uint8 * 32)]
+
+    @classmethod
+    def make(cls, pc, merkle_root):
+        st = cls()
+        st.pc = pc
+        st.merkle_root[:] = bytes(merkle_root)
+        return st
+
+    def digest(self):
+        out = (ctypes.c_uint8 * 32)()
+        _check(lib().r0h_system_state_digest(ctypes.byref(self), out))
+        return bytes(out)
+
+
+class ReceiptClaim(ctypes.Structure):
+    """risc0-zkvm `ReceiptClaim`, flattened (r0h_receipt_claim): exit code as (system, user), input/output as digests (zeros = None)."""
+    _fields_ = [("pre", SystemState), ("post", SystemState), ("exit_system", _u32), ("exit_user", _u32),
+                ("input_digest", ctypes.c_uint8 * 32), ("output_digest", ctypes.c_uint8 * 32)]
+    HALTED, PAUSED, SPLIT = 0, 1, 2
+
+    @classmethod
+    def make(cls, pre, post, exit_system, exit_user=0, output_digest=None, input_digest=None):
+        c = cls()
+        c.pre, c.post, c.exit_system, c.exit_user = pre, post, exit_system, exit_user
+        if output_digest is not None:
+            c.output_digest[:] = bytes(output_digest)
+        if input_digest is not None:
+            c.input_digest[:] = bytes(input_digest)
+        return c
+
+    def digest(self):
+        out = (ctypes.c_uint8 * 32)()
+        _check(lib().r0h_claim_digest(ctypes.byref(self), out))
+        return bytes(out)
+
+    def globals(self):
+        """The eight public-input words that name this claim in a seal (r0h_claim_globals)."""
+        return claim_globals(self.digest())
+
+
+def sha256(data):
+    data = bytes(data)
+    out = (ctypes.c_uint8 * 32)()
+    _check(lib().r0h_sha256(data, len(data), out))
+    return bytes(out)
+
+
+def tagged_struct(tag, down, data):
+    """risc0-binfmt `tagged_struct`: SHA-256(SHA-256(tag) || down digests || data as u32 LE || len(down) as u16 LE)."""
+    flat = b"".join(bytes(d) for d in down)
+    arr, parr = _u32arr(list(data) or [0])
+    out = (ctypes.c_uint8 * 32)()
+    _check(lib().r0h_tagged_struct(tag.encode(), flat, len(down), parr, len(data), out))
+    return bytes(out)
+
+
+def output_digest(journal, assumptions_digest=None):
+    journal = bytes(journal)
+    out = (ctypes.c_uint8 * 32)()
+    _check(lib().r0h_output_digest(journal, len(journal), assumptions_digest, out))
+    return bytes(out)
+
+
+def claim_globals(claim_digest):
+    out = np.zeros(8, dtype=np.uint32)
+    _check(lib().r0h_claim_globals(bytes(claim_digest), out.ctypes.data_as(_vp)))
+    return out
+
+
+def session_claims(n_segments, journal, state_seed=b"r0hip synthetic session"):
+    """The claims of an n-segment session with synthetic system states (no executor exists here: the states are SHA-256 names,
+    not memory images): segment k runs from state k to state k+1, all but the last end in SystemSplit, the last halts with the
+    journal's output.  Returns (claims, image_id) with image_id = digest of state 0."""
+    states = [SystemState.make(0, sha256(state_seed + b"/" + str(k).encode())) for k in range(n_segments + 1)]
+    claims = []
+    for k in range(n_segments):
+        last = k == n_segments - 1
+        claims.append(ReceiptClaim.make(states[k], states[k + 1], ReceiptClaim.HALTED if last else ReceiptClaim.SPLIT, 0,
+                                        output_digest(journal) if last else None))
+    return claims, states[0].digest()
+
+
 class Receipt:
     """Receipt JSON envelope (host/src/main.rs:251-252 writes it, verifier/src/main.rs:118-119 reads it)."""
 
@@ -315,15 +410,38 @@ class Receipt:
         return cls(h)
 
     @classmethod
-    def new(cls, journal, seals=None):
+    def new(cls, journal, seals=None, claims=None):
         journal = bytes(journal)
         h = _vp()
         _check(lib().r0h_receipt_new(0 if seals is None else 1, journal, len(journal), ctypes.byref(h)))
         rc = cls(h)
         for i, seal in enumerate(seals or []):
             a, pa = _u32arr(seal)
-            _check(lib().r0h_receipt_add_segment(h, pa, a.size, i))
+            if claims is None:
+                _check(lib().r0h_receipt_add_segment(h, pa, a.size, i))
+            else:
+                _check(lib().r0h_receipt_add_segment_claim(h, pa, a.size, i, ctypes.byref(claims[i]), None))
         return rc
+
+    def claims(self):
+        out = []
+        for i in range(lib().r0h_receipt_n_segments(self.handle)):
+            c, has = ReceiptClaim(), _c.c_int(0)
+            _check(lib().r0h_receipt_segment_claim(self.handle, i, ctypes.byref(c), ctypes.byref(has)))
+            out.append(c if has.value else None)
+        return out
+
+    def verify(self, blob, control_roots, image_id=None):
+        """`receipt.verify(image_id)` (r0h_receipt_verify): control_roots = {po2: root[8]}.  Returns (verdict, reason, segment, seal verdict)."""
+        b, pb = _u32arr(blob)
+        table = np.zeros(9 * max(len(control_roots), 1), dtype=np.uint32)
+        for k, (po2, root) in enumerate(sorted(control_roots.items())):
+            table[9 * k] = po2
+            table[9 * k + 1:9 * k + 9] = root
+        verdict, seg, sv = _c.c_int(-1), _sz(0), _c.c_int(0)
+        _check(lib().r0h_receipt_verify(self.handle, pb, b.size, table.ctypes.data_as(_vp), len(control_roots), None if image_id is None else bytes(image_id),
+                                        ctypes.byref(verdict), ctypes.byref(seg), ctypes.byref(sv)))
+        return verdict.value, lib().r0h_receipt_verify_reason(verdict.value).decode(), seg.value, sv.value
 
     @property
     def kind(self):

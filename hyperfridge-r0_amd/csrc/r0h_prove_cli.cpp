@@ -2,7 +2,13 @@
 // witness on the device, prove K segments, print throughput and a digest of the seal.
 // It stands where hyperfridge's `host prove-camt53` stands relative to risc0 (host/src/main.rs:420-423 obtains a prover and
 // calls prove once); everything risc0-specific above the segment prover (executor, receipts) is out of scope.
-//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json --journal text] [--receipts R]
+//   usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1]
+//                    [--receipt-out file.json | --receipt-dir dir] [--journal text] [--receipts R]
+// With --receipt-out / --receipt-dir every segment is proved for a claim (risc0-zkvm `ReceiptClaim`): the session's system states
+// are synthetic names (there is no executor here), segment k runs from state k to state k+1, all but the last end in SystemSplit,
+// the last halts with the journal's output; the claim's eight naming words are planted as the segment's public inputs.  The image
+// id (digest of state 0) and the control root of the trace size are printed for the verifier (`r0h_verify --receipt`).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -27,10 +33,10 @@ static void die(const char* what, const char* err) {
 
 int main(int argc, char** argv) {
   if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) {
-    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json --journal text] [--receipts R]\n%s\n", r0h_version());
+    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json | --receipt-dir dir] [--journal text] [--receipts R]\n%s\n", r0h_version());
     return argc < 2 ? 1 : 0;
   }
-  std::string blob_path = argv[1], co_path, seal_out, receipt_out, journal_text;
+  std::string blob_path = argv[1], co_path, seal_out, receipt_out, receipt_dir, journal_text;
   unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0, receipts = 1;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
@@ -43,6 +49,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--seal-out")) seal_out = argv[i + 1];
     else if (!strcmp(argv[i], "--verify")) verify = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--receipt-out")) receipt_out = argv[i + 1];
+    else if (!strcmp(argv[i], "--receipt-dir")) receipt_dir = argv[i + 1];
     else if (!strcmp(argv[i], "--journal")) journal_text = argv[i + 1];
     else if (!strcmp(argv[i], "--receipts")) receipts = (unsigned)atoi(argv[i + 1]);
     else { fprintf(stderr, "r0h_prove: unknown option %s\n", argv[i]); return 1; }
@@ -56,7 +63,9 @@ int main(int argc, char** argv) {
   if (fread(blob.data(), 4, blob.size(), f) != blob.size()) { fprintf(stderr, "r0h_prove: short read\n"); return 1; }
   fclose(f);
   if (contexts < 1 || contexts > 16) { fprintf(stderr, "r0h_prove: --contexts must be 1..16\n"); return 1; }
-  if (receipts < 1 || (receipts > 1 && !receipt_out.empty())) { fprintf(stderr, "r0h_prove: --receipts R > 1 is a throughput run (no --receipt-out)\n"); return 1; }
+  if (receipts < 1 || (receipts > 1 && !receipt_out.empty())) { fprintf(stderr, "r0h_prove: --receipts R > 1 writes one file per receipt: use --receipt-dir\n"); return 1; }
+  if (!receipt_out.empty() && !receipt_dir.empty()) { fprintf(stderr, "r0h_prove: --receipt-out and --receipt-dir exclude each other\n"); return 1; }
+  const bool with_claims = !receipt_out.empty() || !receipt_dir.empty();
   // BASELINE.json configs[3]: a batch of independent receipts of `segments` segments each -- receipts x segments units on one
   // work queue, every lane takes the next unit when it is free
   const unsigned units = receipts * segments;
@@ -66,7 +75,7 @@ int main(int argc, char** argv) {
   struct Lane {
     r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; r0h_buf* code = nullptr; r0h_buf* data = nullptr;
     std::vector<uint32_t> global, seal; size_t words = 0; unsigned proved = 0, loaded = 0;  // loaded: unit whose witness the buffers hold
-    std::vector<std::pair<unsigned, std::vector<uint32_t>>> kept;  // (segment index, seal) when a receipt is to be written
+    std::vector<std::pair<unsigned, std::vector<uint32_t>>> kept;  // (unit, seal) when receipts are to be written
   };
   std::vector<Lane> lanes(contexts);
   const size_t n = (size_t)1 << po2;
@@ -81,18 +90,59 @@ int main(int argc, char** argv) {
     CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + k, ln.code, ln.data, ln.global.data()));
     ln.loaded = k;
   }
+  // the claims of every unit (receipt r, segment s): unit = r * segments + s
+  std::vector<uint8_t> journal(journal_text.size() + 8);
+  size_t jn = 0;
+  CHECK(r0h_serde_encode_str((const uint8_t*)journal_text.data(), journal_text.size(), journal.data(), journal.size(), &jn));
+  journal.resize(jn);
+  std::vector<r0h_receipt_claim> claims(units);
+  std::vector<std::string> image_ids(receipts);
+  if (with_claims) {
+    if (r0h_circuit_n_global(lanes[0].circ) < 8) { fprintf(stderr, "r0h_prove: the circuit exposes fewer than 8 public inputs: a claim cannot be bound to its seals\n"); return 1; }
+    for (unsigned r = 0; r < receipts; r++) {
+      std::vector<r0h_system_state> st(segments + 1);
+      for (unsigned k = 0; k <= segments; k++) {
+        char name[96];
+        int nn = snprintf(name, sizeof name, "r0hip synthetic session %llu/%u/%u", seed, r, k);
+        st[k].pc = 0;
+        CHECK(r0h_sha256((const uint8_t*)name, (size_t)nn, st[k].merkle_root));
+      }
+      for (unsigned k = 0; k < segments; k++) {
+        r0h_receipt_claim& c = claims[r * segments + k];
+        memset(&c, 0, sizeof c);
+        c.pre = st[k];
+        c.post = st[k + 1];
+        const bool last = k + 1 == segments;
+        c.exit_system = last ? 0 : 2;  // Halted(0) | SystemSplit
+        if (last) CHECK(r0h_output_digest(journal.data(), journal.size(), nullptr, c.output_digest));
+      }
+      uint8_t id[32];
+      CHECK(r0h_system_state_digest(&st[0], id));
+      char hex[65];
+      for (int i = 0; i < 32; i++) snprintf(hex + 2 * i, 3, "%02x", id[i]);
+      image_ids[r] = hex;
+    }
+  }
   std::atomic<unsigned> next_unit{0};
   auto work = [&](unsigned k) {
     Lane& ln = lanes[k];
     for (unsigned u; (u = next_unit.fetch_add(1)) < units;) {
       const unsigned s = u % segments;  // segment index within its receipt
-      if (u != ln.loaded) {
+      if (with_claims) {  // the claim's naming words are the segment's public inputs
+        uint8_t cd[32];
+        CHECK(r0h_claim_digest(&claims[u], cd));
+        std::fill(ln.global.begin(), ln.global.end(), 0u);
+        CHECK(r0h_claim_globals(cd, ln.global.data()));
+        CHECK(r0h_witgen_public(ln.ctx, ln.circ, po2, seed + u, ln.global.data(), ln.code, ln.data));
+        ln.loaded = ~0u;
+      } else if (u != ln.loaded) {
         CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + u, ln.code, ln.data, ln.global.data()));
         ln.loaded = u;
       }
       CHECK(r0h_prove_segment(ln.ctx, ln.circ, po2, ln.code, ln.data, ln.global.data(), ln.seal.data(), ln.seal.size(), &ln.words));
       ln.proved++;
-      if (!receipt_out.empty()) ln.kept.emplace_back(s, std::vector<uint32_t>(ln.seal.begin(), ln.seal.begin() + ln.words));
+      (void)s;
+      if (with_claims) ln.kept.emplace_back(u, std::vector<uint32_t>(ln.seal.begin(), ln.seal.begin() + ln.words));
     }
   };
   auto t0 = std::chrono::steady_clock::now();
@@ -117,25 +167,33 @@ int main(int argc, char** argv) {
     }
     fprintf(stderr, "r0h_prove: seals verified\n");
   }
-  if (!receipt_out.empty()) {
+  if (with_claims) {
     // the Receipt JSON `host` writes (host/src/main.rs:251-252, 299-316): all segment seals in order + the journal, which for the
     // hyperfridge guest is the serde word stream of the committed JSON string (host/src/main.rs:258-267)
-    std::vector<uint8_t> journal(journal_text.size() + 8);
-    size_t jn = 0;
-    CHECK(r0h_serde_encode_str((const uint8_t*)journal_text.data(), journal_text.size(), journal.data(), journal.size(), &jn));
-    r0h_receipt* rc = nullptr;
-    CHECK(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, journal.data(), jn, &rc));
-    for (unsigned s = 0; s < segments; s++)
-      for (const Lane& ln : lanes)
-        for (const auto& kv : ln.kept)
-          if (kv.first == s) CHECK(r0h_receipt_add_segment(rc, kv.second.data(), kv.second.size(), s));
-    char* text = nullptr;
-    CHECK(r0h_receipt_to_json(rc, &text));
-    FILE* o = fopen(receipt_out.c_str(), "wb");
-    if (!o || fwrite(text, 1, strlen(text), o) != strlen(text)) { fprintf(stderr, "r0h_prove: cannot write %s\n", receipt_out.c_str()); return 1; }
-    fclose(o);
-    r0h_free_error(text);
-    CHECK(r0h_receipt_free(rc));
+    uint32_t root[8];
+    CHECK(r0h_code_root(lanes[0].ctx, lanes[0].code, r0h_circuit_group_size(lanes[0].circ, R0H_GROUP_CODE), po2, root));
+    printf("{\"control_root\": {\"po2\": %u, \"root\": [%u, %u, %u, %u, %u, %u, %u, %u]}, \"image_ids\": [", po2, root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7]);
+    for (unsigned r = 0; r < receipts; r++) printf("%s\"%s\"", r ? ", " : "", image_ids[r].c_str());
+    printf("]}\n");
+    for (unsigned r = 0; r < receipts; r++) {
+      r0h_receipt* rc = nullptr;
+      CHECK(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, journal.data(), journal.size(), &rc));
+      for (unsigned k = 0; k < segments; k++)
+        for (const Lane& ln : lanes)
+          for (const auto& kv : ln.kept)
+            if (kv.first == r * segments + k) CHECK(r0h_receipt_add_segment_claim(rc, kv.second.data(), kv.second.size(), k, &claims[kv.first], nullptr));
+      if (r0h_receipt_n_segments(rc) != segments) { fprintf(stderr, "r0h_prove: receipt %u is missing segments\n", r); return 3; }
+      char* text = nullptr;
+      CHECK(r0h_receipt_to_json(rc, &text));
+      char name[64];
+      snprintf(name, sizeof name, "/receipt_%04u.json", r);
+      const std::string path = receipt_out.empty() ? receipt_dir + name : receipt_out;
+      FILE* o = fopen(path.c_str(), "wb");
+      if (!o || fwrite(text, 1, strlen(text), o) != strlen(text)) { fprintf(stderr, "r0h_prove: cannot write %s\n", path.c_str()); return 1; }
+      fclose(o);
+      r0h_free_error(text);
+      CHECK(r0h_receipt_free(rc));
+    }
   }
   if (!seal_out.empty()) {
     FILE* o = fopen(seal_out.c_str(), "wb");

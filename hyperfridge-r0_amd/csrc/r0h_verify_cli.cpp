@@ -2,7 +2,11 @@
 // `verifier verify` step (verifier/src/main.rs:118-126: read the receipt, `receipt.verify(image_id)`, report).
 // Needs no GPU.  Exit status: 0 accepted, 1 rejected (reason on stdout), 2 unusable input.
 //   usage: r0h_verify <circuit.r0c> <seal.bin>
-//          r0h_verify --receipt <receipt.json> <circuit.r0c>     every segment seal of a Receipt JSON, then the commitment
+//          r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --control-root <po2>:<w0,..,w7> [--control-root ..]
+//                     `receipt.verify(image_id)` for a composite receipt (r0h_receipt_verify): seals against the control roots, claims
+//                     named by the seals, segment chain, journal digest, image id; then the commitment (verifier/src/main.rs:124-128).
+//                     Without --image-id / --control-root the seals alone are checked and the result is reported as NOT accepted
+//                     ("journal_bound": false, exit status 1): valid seals plus any journal would otherwise pass.
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -34,8 +38,8 @@ static void print_json_string(const uint8_t* p, size_t n) {
   putchar('"');
 }
 
-// verifier/src/main.rs:114-126: read the receipt JSON, verify it, print the commitment
-static int verify_receipt(const char* receipt_path, const char* blob_path) {
+// verifier/src/main.rs:114-128: read the receipt JSON, verify it against the image id, print the commitment
+static int verify_receipt(const char* receipt_path, const char* blob_path, const char* image_hex, const std::vector<uint32_t>& roots) {
   std::vector<uint32_t> blob;
   if (!read_words(blob_path, &blob)) { fprintf(stderr, "r0h_verify: cannot read %s as 32-bit words\n", blob_path); return 2; }
   FILE* f = fopen(receipt_path, "rb");
@@ -47,38 +51,71 @@ static int verify_receipt(const char* receipt_path, const char* blob_path) {
   r0h_receipt* rc = nullptr;
   const char* err = r0h_receipt_parse(text.data(), text.size(), &rc);
   if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); return 2; }
+  uint8_t image_id[32];
+  if (image_hex) {
+    bool ok = strlen(image_hex) == 64;
+    for (int i = 0; ok && i < 32; i++) {
+      unsigned v;
+      ok = sscanf(image_hex + 2 * i, "%2x", &v) == 1;
+      image_id[i] = (uint8_t)v;
+    }
+    if (!ok) { fprintf(stderr, "r0h_verify: --image-id wants 64 hex digits (verifier/src/main.rs:131-143)\n"); r0h_receipt_free(rc); return 2; }
+  }
   const size_t n_seg = r0h_receipt_n_segments(rc);
-  int verdict = R0H_VERIFY_OK;
-  const char* reason = "ok";
-  if (r0h_receipt_kind(rc) == R0H_RECEIPT_FAKE) {
-    verdict = -1;
-    reason = "Fake receipt (dev mode): nothing to verify";
-  } else if (n_seg == 0) {
-    verdict = -1;
-    reason = "composite receipt without segments";
-  }
-  for (size_t i = 0; i < n_seg && verdict == R0H_VERIFY_OK; i++) {
-    const uint32_t* seal; size_t words;
-    err = r0h_receipt_segment(rc, i, &seal, &words, nullptr);
-    if (!err) err = r0h_verify_seal(blob.data(), blob.size(), nullptr, nullptr, seal, words, &verdict, nullptr);
+  const bool bound = image_hex && !roots.empty();
+  int verdict = -1, seal_verdict = R0H_VERIFY_OK;
+  size_t at = 0;
+  const char* reason = "";
+  bool seals_valid = false;
+  if (bound) {
+    err = r0h_receipt_verify(rc, blob.data(), blob.size(), roots.data(), roots.size() / 9, image_id, &verdict, &at, &seal_verdict);
     if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
-    reason = r0h_verify_reason(verdict);
+    reason = verdict == R0H_RECEIPT_V_SEAL ? r0h_verify_reason(seal_verdict) : r0h_receipt_verify_reason(verdict);
+    seals_valid = verdict != R0H_RECEIPT_V_SEAL && verdict != R0H_RECEIPT_V_NOT_COMPOSITE && verdict != R0H_RECEIPT_V_NO_CONTROL_ROOT;
+  } else {
+    // seals only: says nothing about which program ran or which journal it committed to
+    seals_valid = r0h_receipt_kind(rc) == R0H_RECEIPT_COMPOSITE && n_seg > 0;
+    reason = seals_valid ? "seals checked without image id / control roots: neither the program nor the journal is bound" : "not a composite receipt";
+    for (size_t i = 0; i < n_seg && seals_valid; i++) {
+      const uint32_t* seal; size_t words;
+      err = r0h_receipt_segment(rc, i, &seal, &words, nullptr);
+      if (!err) err = r0h_verify_seal(blob.data(), blob.size(), nullptr, nullptr, seal, words, &seal_verdict, nullptr);
+      if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
+      if (seal_verdict != R0H_VERIFY_OK) { seals_valid = false; at = i; reason = r0h_verify_reason(seal_verdict); }
+    }
   }
+  const bool accepted = bound && verdict == R0H_RECEIPT_V_OK;
   const uint8_t* journal; size_t jn, off = 0, len = 0;
   (void)r0h_receipt_journal(rc, &journal, &jn);
   err = r0h_journal_commitment_span(journal, jn, &off, &len);
   if (err) { r0h_free_error(err); len = 0; }
-  printf("{\"accepted\": %s, \"segments\": %zu, \"reason\": \"%s\", \"commitment\": ", verdict == R0H_VERIFY_OK ? "true" : "false", n_seg, reason);
+  printf("{\"accepted\": %s, \"seals_valid\": %s, \"journal_bound\": %s, \"segments\": %zu, \"segment_at_fault\": %zu, \"reason\": \"%s\", \"commitment\": ",
+         accepted ? "true" : "false", seals_valid ? "true" : "false", accepted ? "true" : "false", n_seg, at, accepted ? "ok" : reason);
   print_json_string(journal + off, len);
   printf("}\n");
   r0h_receipt_free(rc);
-  return verdict == R0H_VERIFY_OK ? 0 : 1;
+  return accepted ? 0 : 1;
 }
 
 int main(int argc, char** argv) {
-  if (argc == 4 && !strcmp(argv[1], "--receipt")) return verify_receipt(argv[2], argv[3]);
+  if (argc >= 4 && !strcmp(argv[1], "--receipt")) {
+    const char* image_hex = nullptr;
+    std::vector<uint32_t> roots;  // records of [po2, root[8]]
+    for (int i = 4; i + 1 < argc; i += 2) {
+      if (!strcmp(argv[i], "--image-id")) image_hex = argv[i + 1];
+      else if (!strcmp(argv[i], "--control-root")) {
+        unsigned v[9];
+        if (sscanf(argv[i + 1], "%u:%u,%u,%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) != 9) {
+          fprintf(stderr, "r0h_verify: --control-root wants <po2>:<w0,..,w7>\n");
+          return 2;
+        }
+        roots.insert(roots.end(), v, v + 9);
+      } else { fprintf(stderr, "r0h_verify: unknown option %s\n", argv[i]); return 2; }
+    }
+    return verify_receipt(argv[2], argv[3], image_hex, roots);
+  }
   if (argc != 3) {
-    printf("usage: r0h_verify <circuit.r0c> <seal.bin>\n       r0h_verify --receipt <receipt.json> <circuit.r0c>\n%s\n", r0h_version());
+    printf("usage: r0h_verify <circuit.r0c> <seal.bin>\n       r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --control-root <po2>:<w0,..,w7>\n%s\n", r0h_version());
     return 2;
   }
   std::vector<uint32_t> blob, seal;

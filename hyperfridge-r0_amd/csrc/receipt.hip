@@ -7,7 +7,8 @@
 //   * the Receipt JSON envelope `serde_json::to_string(&receipt)` writes and `serde_json::from_slice` reads
 //     (host/src/main.rs:251-252, verifier/src/main.rs:118-119): {"inner": ..., "journal": {"bytes": [...]}}.
 // What the reference's fixtures pin: the envelope with "inner":"Fake" and the journal framing.  The composite layout
-// (segments with seal / index / hashfn) follows risc0-zkvm 3.x as recalled; its claim is written as null ("parity unpinned").
+// (segments with seal / index / hashfn / verifier_parameters / claim, assumption_receipts, metadata) follows risc0-zkvm 3.x as
+// recalled ("parity unpinned"); the digests inside it are computed in claim.hip.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +20,7 @@
 
 #include "../../include/r0hip.h"
 #include "internal.hpp"
+#include "receipt_types.hpp"
 
 namespace {
 
@@ -195,13 +197,6 @@ struct r0h_env {
   std::vector<uint32_t> words;
 };
 
-struct r0h_receipt {
-  int kind = R0H_RECEIPT_FAKE;
-  std::vector<uint8_t> journal;
-  struct Segment { std::vector<uint32_t> seal; uint32_t index = 0; std::string hashfn; };
-  std::vector<Segment> segments;
-};
-
 namespace {
 
 const char* u32_array(const Json* j, uint64_t limit, const char* what, std::vector<uint64_t>& out) {
@@ -221,6 +216,102 @@ const char* u32_array(const Json* j, uint64_t limit, const char* what, std::vect
   return nullptr;
 }
 
+// a risc0 `Digest` in serde_json: 64 hex digits (human-readable form); the eight-u32 array form of the binary codecs is accepted too
+const char* parse_digest(const Json* j, const char* what, uint8_t out[32]) {
+  R0H_REQUIRE(j, "receipt JSON: no %s", what);
+  if (j->kind == Json::Str) {
+    R0H_REQUIRE(j->str.size() == 64, "receipt JSON: %s is not 64 hex digits", what);
+    for (int i = 0; i < 32; i++) {
+      unsigned v = 0;
+      for (int k = 0; k < 2; k++) {
+        const char h = j->str[2 * i + k];
+        const unsigned d = h >= '0' && h <= '9' ? h - '0' : h >= 'a' && h <= 'f' ? h - 'a' + 10 : h >= 'A' && h <= 'F' ? h - 'A' + 10 : 256;
+        R0H_REQUIRE(d < 16, "receipt JSON: %s is not 64 hex digits", what);
+        v = v * 16 + d;
+      }
+      out[i] = (uint8_t)v;
+    }
+    return nullptr;
+  }
+  std::vector<uint64_t> w;
+  R0H_TRY(u32_array(j, 0xffffffffull, what, w));
+  R0H_REQUIRE(w.size() == 8, "receipt JSON: %s is not a digest (8 words)", what);
+  for (int i = 0; i < 8; i++)
+    for (int b = 0; b < 4; b++) out[4 * i + b] = (uint8_t)(w[i] >> (8 * b));
+  return nullptr;
+}
+
+// MaybePruned<T>: {"Value": T} or {"Pruned": digest}
+const Json* maybe_pruned(const Json* j, bool* pruned) {
+  if (!j || j->kind != Json::Obj || j->obj.size() != 1) return nullptr;
+  if (j->obj[0].first == "Value") { *pruned = false; return &j->obj[0].second; }
+  if (j->obj[0].first == "Pruned") { *pruned = true; return &j->obj[0].second; }
+  return nullptr;
+}
+
+const char* parse_system_state(const Json* j, const char* what, r0h_system_state& st) {
+  bool pruned = false;
+  const Json* v = maybe_pruned(j, &pruned);
+  R0H_REQUIRE(v && !pruned && v->kind == Json::Obj, "receipt JSON: claim.%s is not {\"Value\":{pc, merkle_root}} (a pruned system state cannot be chained)", what);
+  const Json* pc = v->get("pc");
+  R0H_REQUIRE(pc && pc->kind == Json::Num && pc->integral && pc->u <= 0xffffffffull, "receipt JSON: claim.%s.pc is not a u32", what);
+  st.pc = (uint32_t)pc->u;
+  return parse_digest(v->get("merkle_root"), "claim system state merkle_root", st.merkle_root);
+}
+
+const char* parse_claim(const Json& c, r0h_receipt_claim& out, const std::vector<uint8_t>&) {
+  R0H_REQUIRE(c.kind == Json::Obj, "receipt JSON: a claim is not an object");
+  memset(&out, 0, sizeof out);
+  R0H_TRY(parse_system_state(c.get("pre"), "pre", out.pre));
+  R0H_TRY(parse_system_state(c.get("post"), "post", out.post));
+  const Json* ec = c.get("exit_code");
+  R0H_REQUIRE(ec, "receipt JSON: claim without exit_code");
+  if (ec->kind == Json::Str) {
+    R0H_REQUIRE(ec->str == "SystemSplit" || ec->str == "SessionLimit", "receipt JSON: unknown exit code \"%s\"", ec->str.c_str());
+    out.exit_system = 2;
+    out.exit_user = ec->str == "SessionLimit" ? 2 : 0;
+  } else {
+    R0H_REQUIRE(ec->kind == Json::Obj && ec->obj.size() == 1 && ec->obj[0].second.kind == Json::Num && ec->obj[0].second.integral && ec->obj[0].second.u <= 0xffffffffull,
+                "receipt JSON: exit_code is neither a unit variant nor {\"Halted\"|\"Paused\": u32}");
+    R0H_REQUIRE(ec->obj[0].first == "Halted" || ec->obj[0].first == "Paused", "receipt JSON: unknown exit code \"%s\"", ec->obj[0].first.c_str());
+    out.exit_system = ec->obj[0].first == "Paused" ? 1 : 0;
+    out.exit_user = (uint32_t)ec->obj[0].second.u;
+  }
+  bool pruned = false;
+  const Json* in = maybe_pruned(c.get("input"), &pruned);
+  R0H_REQUIRE(in, "receipt JSON: claim.input is not a MaybePruned value");
+  if (pruned) R0H_TRY(parse_digest(in, "claim.input", out.input_digest));
+  else R0H_REQUIRE(in->kind == Json::Null, "receipt JSON: a claim with an unpruned input is not supported");
+  const Json* o = maybe_pruned(c.get("output"), &pruned);
+  R0H_REQUIRE(o, "receipt JSON: claim.output is not a MaybePruned value");
+  if (pruned) {
+    R0H_TRY(parse_digest(o, "claim.output", out.output_digest));
+  } else if (o->kind != Json::Null) {  // {"Value":{"journal":{..},"assumptions":{..}}}: fold it to its digest
+    R0H_REQUIRE(o->kind == Json::Obj, "receipt JSON: claim.output value is not an object");
+    uint8_t jd[32], ad[32] = {0};
+    bool jp = false, ap = false;
+    const Json* jv = maybe_pruned(o->get("journal"), &jp);
+    R0H_REQUIRE(jv, "receipt JSON: claim.output.journal is not a MaybePruned value");
+    if (jp) {
+      R0H_TRY(parse_digest(jv, "claim.output.journal", jd));
+    } else {
+      std::vector<uint64_t> bytes;
+      R0H_TRY(u32_array(jv, 255, "claim.output.journal", bytes));
+      std::vector<uint8_t> raw(bytes.begin(), bytes.end());
+      R0H_TRY(r0h_sha256(raw.data(), raw.size(), jd));
+    }
+    const Json* av = maybe_pruned(o->get("assumptions"), &ap);
+    R0H_REQUIRE(av, "receipt JSON: claim.output.assumptions is not a MaybePruned value");
+    if (ap) R0H_TRY(parse_digest(av, "claim.output.assumptions", ad));
+    else R0H_REQUIRE((av->kind == Json::Arr && av->arr.empty()) || (av->kind == Json::NumArr && av->nums.empty()), "receipt JSON: unresolved assumptions are not supported");
+    uint8_t down[2][32];
+    memcpy(down[0], jd, 32);
+    memcpy(down[1], ad, 32);
+    r0h::tagged_struct("risc0.Output", down, 2, nullptr, 0, out.output_digest);
+  }
+  return nullptr;
+}
+
 const char* parse_receipt(const Json& root, r0h_receipt& rc) {
   R0H_REQUIRE(root.kind == Json::Obj, "receipt JSON: top level is not an object");
   const Json* journal = root.get("journal");
@@ -230,7 +321,7 @@ const char* parse_receipt(const Json& root, r0h_receipt& rc) {
   rc.journal.assign(bytes.begin(), bytes.end());
   const Json* inner = root.get("inner");
   R0H_REQUIRE(inner, "receipt JSON: no \"inner\"");
-  if (inner->kind == Json::Str) {  // unit variant, risc0 0.19 style: "inner":"Fake"
+  if (inner->kind == Json::Str) {  // unit variant, risc0 0.19 style: "inner":"Fake" (what the reference's fixtures hold; no metadata)
     R0H_REQUIRE(inner->str == "Fake", "receipt JSON: unsupported inner receipt \"%s\"", inner->str.c_str());
     rc.kind = R0H_RECEIPT_FAKE;
     return nullptr;
@@ -255,9 +346,27 @@ const char* parse_receipt(const Json& root, r0h_receipt& rc) {
     const Json* hf = s.get("hashfn");
     R0H_REQUIRE(hf && hf->kind == Json::Str, "receipt JSON: segment without \"hashfn\"");
     seg.hashfn = hf->str;
+    if (const Json* vp = s.get("verifier_parameters")) R0H_TRY(parse_digest(vp, "segment.verifier_parameters", seg.verifier_parameters));
+    const Json* claim = s.get("claim");
+    if (claim && claim->kind != Json::Null) {
+      R0H_TRY(parse_claim(*claim, seg.claim, rc.journal));
+      seg.has_claim = true;
+    }
     rc.segments.push_back(std::move(seg));
   }
+  if (const Json* md = root.get("metadata")) {
+    R0H_REQUIRE(md->kind == Json::Obj, "receipt JSON: \"metadata\" is not an object");
+    R0H_TRY(parse_digest(md->get("verifier_parameters"), "metadata.verifier_parameters", rc.verifier_parameters));
+    rc.has_metadata = true;
+  }
   return nullptr;
+}
+
+void append_hex(std::string& s, const uint8_t d[32]) {
+  static const char hex[] = "0123456789abcdef";
+  s += '"';
+  for (int i = 0; i < 32; i++) { s += hex[d[i] >> 4]; s += hex[d[i] & 15]; }
+  s += '"';
 }
 
 void append_escaped(std::string& s, const std::string& v) {
@@ -382,6 +491,7 @@ const char* r0h_receipt_new(int kind, const uint8_t* journal, size_t journal_len
   r0h_receipt* rc = new r0h_receipt;
   rc->kind = kind;
   rc->journal.assign(journal, journal + journal_len);
+  rc->has_metadata = kind == R0H_RECEIPT_COMPOSITE;  // what this library writes carries risc0 3.x's metadata; Fake keeps the fixtures' form
   *out = rc;
   return nullptr;
   R0H_GUARD_END
@@ -398,6 +508,29 @@ const char* r0h_receipt_add_segment(r0h_receipt* rc, const uint32_t* seal, size_
   rc->segments.push_back(std::move(s));
   return nullptr;
   R0H_GUARD_END
+}
+
+const char* r0h_receipt_add_segment_claim(r0h_receipt* rc, const uint32_t* seal, size_t seal_words, uint32_t index, const r0h_receipt_claim* claim,
+                                          const uint8_t* verifier_parameters) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(claim, "r0h_receipt_add_segment_claim: NULL claim");
+  R0H_REQUIRE(claim->exit_system <= 2 && (claim->exit_system != 2 || claim->exit_user == 0 || claim->exit_user == 2), "r0h_receipt_add_segment_claim: exit code (%u, %u) names no ExitCode variant",
+              claim->exit_system, claim->exit_user);
+  R0H_TRY(r0h_receipt_add_segment(rc, seal, seal_words, index));
+  r0h_receipt::Segment& s = rc->segments.back();
+  s.has_claim = true;
+  s.claim = *claim;
+  if (verifier_parameters) memcpy(s.verifier_parameters, verifier_parameters, 32);
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_receipt_segment_claim(const r0h_receipt* rc, size_t i, r0h_receipt_claim* claim_out, int* has_claim_out) {
+  R0H_REQUIRE(rc && claim_out && has_claim_out, "r0h_receipt_segment_claim: NULL argument");
+  R0H_REQUIRE(i < rc->segments.size(), "r0h_receipt_segment_claim: segment %zu of %zu", i, rc->segments.size());
+  *has_claim_out = rc->segments[i].has_claim ? 1 : 0;
+  if (rc->segments[i].has_claim) *claim_out = rc->segments[i].claim;
+  return nullptr;
 }
 
 const char* r0h_receipt_free(r0h_receipt* rc) {
@@ -442,13 +575,46 @@ const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out) {
       append_u(s, g.index);
       s += ",\"hashfn\":\"";
       append_escaped(s, g.hashfn);
-      s += "\",\"verifier_parameters\":[0,0,0,0,0,0,0,0],\"claim\":null}";
+      s += "\",\"verifier_parameters\":";
+      append_hex(s, g.verifier_parameters);
+      s += ",\"claim\":";
+      if (!g.has_claim) {
+        s += "null";
+      } else {
+        const r0h_receipt_claim& c = g.claim;
+        static const uint8_t zero[32] = {0};
+        auto state = [&](const char* key, const r0h_system_state& st) {
+          s += '"'; s += key; s += "\":{\"Value\":{\"pc\":";
+          append_u(s, st.pc);
+          s += ",\"merkle_root\":";
+          append_hex(s, st.merkle_root);
+          s += "}}";
+        };
+        s += '{';
+        state("pre", c.pre);
+        s += ',';
+        state("post", c.post);
+        s += ",\"exit_code\":";
+        if (c.exit_system == 2) s += c.exit_user == 2 ? "\"SessionLimit\"" : "\"SystemSplit\"";
+        else { s += c.exit_system == 1 ? "{\"Paused\":" : "{\"Halted\":"; append_u(s, c.exit_user); s += '}'; }
+        s += ",\"input\":{\"Pruned\":";
+        append_hex(s, c.input_digest);
+        s += "},\"output\":";
+        if (memcmp(c.output_digest, zero, 32) == 0) s += "{\"Value\":null}";
+        else { s += "{\"Pruned\":"; append_hex(s, c.output_digest); s += '}'; }
+        s += '}';
+      }
+      s += '}';
     }
-    s += "],\"assumption_receipts\":[],\"verifier_parameters\":[0,0,0,0,0,0,0,0]}}";
+    s += "],\"assumption_receipts\":[],\"verifier_parameters\":";
+    append_hex(s, rc->verifier_parameters);
+    s += "}}";
   }
   s += ",\"journal\":{\"bytes\":[";
   for (size_t i = 0; i < rc->journal.size(); i++) { if (i) s += ','; append_u(s, rc->journal[i]); }
-  s += "]}}";
+  s += "]}";
+  if (rc->has_metadata) { s += ",\"metadata\":{\"verifier_parameters\":"; append_hex(s, rc->verifier_parameters); s += '}'; }
+  s += '}';
   char* out = (char*)malloc(s.size() + 1);
   R0H_REQUIRE(out, "r0h_receipt_to_json: out of memory");
   memcpy(out, s.c_str(), s.size() + 1);

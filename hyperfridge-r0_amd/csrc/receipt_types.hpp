@@ -1,0 +1,46 @@
+// Receipt / claim types shared by receipt.hip (JSON reader and writer) and claim.hip (digests, receipt verification).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/r0hip.h"
+#include "circuit.hpp"
+
+struct r0h_receipt {
+  int kind = R0H_RECEIPT_FAKE;
+  std::vector<uint8_t> journal;
+  struct Segment {
+    std::vector<uint32_t> seal;
+    uint32_t index = 0;
+    std::string hashfn;
+    bool has_claim = false;
+    r0h_receipt_claim claim;
+    uint8_t verifier_parameters[32] = {0};
+  };
+  std::vector<Segment> segments;
+  bool has_metadata = false;  // risc0 >= 1.0 `Receipt.metadata`; the reference's (older) Fake fixtures have none
+  uint8_t verifier_parameters[32] = {0};
+};
+
+namespace r0h {
+struct Sha256 {
+  uint32_t h[8];
+  uint64_t total;
+  uint8_t buf[64];
+  size_t fill;
+  Sha256() { reset(); }
+  void reset();
+  void update(const void* data, size_t n);
+  void finish(uint8_t out[32]);
+
+ private:
+  void block(const uint8_t* p);
+};
+void sha256(const void* data, size_t n, uint8_t out[32]);
+void tagged_struct(const char* tag, const uint8_t (*down)[32], size_t n_down, const uint32_t* data, size_t n_data, uint8_t out[32]);
+void system_state_digest(const r0h_system_state& st, uint8_t out[32]);
+void claim_digest(const r0h_receipt_claim& c, uint8_t out[32]);
+void claim_globals(const uint8_t digest[32], uint32_t out[8]);
+}  // namespace r0h

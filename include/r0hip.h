@@ -199,22 +199,75 @@ const char* r0h_env_words(const r0h_env* e, const uint32_t** words, size_t* n_wo
 const char* r0h_env_free(r0h_env* e);
 /* hyperfridge's reading of the commitment in a journal: first '{' .. last '}' (host/src/main.rs:258-267, verifier/src/main.rs:176-185) */
 const char* r0h_journal_commitment_span(const uint8_t* bytes, size_t n, size_t* off, size_t* len);
-/* Receipt JSON envelope as `serde_json::to_string(&receipt)` writes it (host/src/main.rs:251-252) and
- * `serde_json::from_slice` reads it (verifier/src/main.rs:118-119): {"inner": "Fake" | {"Fake": ..} | {"Composite": {"segments":
- * [{"seal": [u32..], "index": n, "hashfn": ".."}, ..]}}, "journal": {"bytes": [u8..]}}.  r0h_receipt_to_json's output is
- * serde_json's compact form (caller frees it with r0h_free_error). */
+/* Receipt JSON as `serde_json::to_string(&receipt)` writes it (host/src/main.rs:251-252) and `serde_json::from_slice` reads it
+ * (verifier/src/main.rs:118-119).  Pinned by the reference's fixtures: {"inner":"Fake","journal":{"bytes":[u8..]}}, re-serialised
+ * byte for byte.  The composite form follows risc0-zkvm 3.x as recalled (unpinned):
+ *   {"inner":{"Composite":{"segments":[{"seal":[u32..],"index":n,"hashfn":"poseidon2","verifier_parameters":"<hex>","claim":
+ *     {"pre":{"Value":{"pc":n,"merkle_root":"<hex>"}},"post":{..},"exit_code":{"Halted":0}|{"Paused":0}|"SystemSplit"|"SessionLimit",
+ *      "input":{"Pruned":"<hex>"},"output":{"Pruned":"<hex>"}|{"Value":null}}},..],"assumption_receipts":[],"verifier_parameters":"<hex>"}},
+ *    "journal":{"bytes":[..]},"metadata":{"verifier_parameters":"<hex>"}}
+ * (serde_json is human-readable, so a risc0 `Digest` is a hex string).  Segments without a claim (this library's round-1 files) are
+ * still read.  r0h_receipt_to_json's output is serde_json's compact form (caller frees it with r0h_free_error). */
 #define R0H_RECEIPT_FAKE 0
 #define R0H_RECEIPT_COMPOSITE 1
 typedef struct r0h_receipt r0h_receipt;
+/* risc0-binfmt `SystemState` and risc0-zkvm `ReceiptClaim`, flattened (field names, tags and digest layout are recalled from the
+ * public risc0 sources: unpinned, see csrc/claim.hip).  exit_system / exit_user: Halted(u) = (0, u), Paused(u) = (1, u),
+ * SystemSplit = (2, 0), SessionLimit = (2, 2).  input_digest / output_digest: Digest::ZERO stands for None. */
+typedef struct { uint32_t pc; uint8_t merkle_root[32]; } r0h_system_state;
+typedef struct {
+  r0h_system_state pre, post;
+  uint32_t exit_system, exit_user;
+  uint8_t input_digest[32];
+  uint8_t output_digest[32];
+} r0h_receipt_claim;
+/* SHA-256 (FIPS 180-4) and risc0's tagged-struct digests over it */
+const char* r0h_sha256(const uint8_t* bytes, size_t n, uint8_t digest_out[32]);
+const char* r0h_tagged_struct(const char* tag, const uint8_t* down_digests /* n_down x 32 bytes */, size_t n_down, const uint32_t* data,
+                              size_t n_data, uint8_t digest_out[32]);
+const char* r0h_system_state_digest(const r0h_system_state* st, uint8_t digest_out[32]);
+/* Output{journal, assumptions}.digest; assumptions_digest NULL = no assumptions (Digest::ZERO) */
+const char* r0h_output_digest(const uint8_t* journal, size_t n, const uint8_t* assumptions_digest, uint8_t digest_out[32]);
+const char* r0h_claim_digest(const r0h_receipt_claim* claim, uint8_t digest_out[32]);
+/* the eight public-input words (canonical Montgomery words) that name a claim in a seal: Poseidon2 sponge over the sixteen 16-bit
+ * halves of its digest.  The prover plants them as globals[0..8) (r0h_witgen_public / its own witness generator). */
+const char* r0h_claim_globals(const uint8_t claim_digest[32], uint32_t globals_out[8]);
+
 const char* r0h_receipt_parse(const char* json, size_t n, r0h_receipt** out);
 const char* r0h_receipt_new(int kind, const uint8_t* journal, size_t journal_len, r0h_receipt** out);
 const char* r0h_receipt_add_segment(r0h_receipt* rc, const uint32_t* seal, size_t seal_words, uint32_t index);
+/* the same with the segment's claim (risc0-zkvm `SegmentReceipt.claim`); verifier_parameters may be NULL (zeros) */
+const char* r0h_receipt_add_segment_claim(r0h_receipt* rc, const uint32_t* seal, size_t seal_words, uint32_t index,
+                                          const r0h_receipt_claim* claim, const uint8_t* verifier_parameters);
 const char* r0h_receipt_free(r0h_receipt* rc);
 int r0h_receipt_kind(const r0h_receipt* rc);
 size_t r0h_receipt_n_segments(const r0h_receipt* rc);
 const char* r0h_receipt_journal(const r0h_receipt* rc, const uint8_t** bytes, size_t* n);
 const char* r0h_receipt_segment(const r0h_receipt* rc, size_t i, const uint32_t** seal, size_t* seal_words, uint32_t* index);
+/* *has_claim_out = 0 when the segment was read from a receipt without claims (claim_out untouched) */
+const char* r0h_receipt_segment_claim(const r0h_receipt* rc, size_t i, r0h_receipt_claim* claim_out, int* has_claim_out);
 const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out);
+/* `receipt.verify(image_id)` (verifier/src/main.rs:124-126, host/src/main.rs:622-624) for a composite receipt, as risc0-zkvm
+ * receipt/composite.rs does it: every seal verifies against the control root of its trace size (control_roots: n_roots records of
+ * 9 words [po2, root[8]], from r0h_code_root), its public inputs name the segment's claim, the segments chain (index, SystemSplit,
+ * post-state == next pre-state), the last claim's output commits to SHA-256(journal.bytes) and exits Halted(0)/Paused(0), and the
+ * first pre-state's digest is image_id (32 bytes; NULL skips that last comparison).  Pure host code.  Returns NULL when the check
+ * ran: *verdict_out is R0H_RECEIPT_V_*; *segment_out (optional) the segment at fault; *seal_verdict_out (optional) the R0H_VERIFY_*
+ * code when the verdict is R0H_RECEIPT_V_SEAL. */
+#define R0H_RECEIPT_V_OK 0
+#define R0H_RECEIPT_V_NOT_COMPOSITE 1
+#define R0H_RECEIPT_V_SEAL 2
+#define R0H_RECEIPT_V_NO_CONTROL_ROOT 3
+#define R0H_RECEIPT_V_NO_CLAIM 4
+#define R0H_RECEIPT_V_CLAIM_MISMATCH 5
+#define R0H_RECEIPT_V_CHAIN 6
+#define R0H_RECEIPT_V_JOURNAL 7
+#define R0H_RECEIPT_V_IMAGE_ID 8
+#define R0H_RECEIPT_V_EXIT_CODE 9
+#define R0H_RECEIPT_V_NO_BINDING 10
+const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots,
+                               size_t n_roots, const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out);
+const char* r0h_receipt_verify_reason(int verdict); /* static string, do not free */
 
 /* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
  * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */

@@ -68,12 +68,22 @@ def test_prove_to_receipt_json_then_verify_like_the_reference_verifier(tmp_path)
     out = subprocess.run([CLI, circuit_path("small"), "--po2", "10", "--segments", "3", "--contexts", "2", "--receipt-out", receipt, "--journal", commitment],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+    ids = [json.loads(ln) for ln in out.stdout.splitlines() if "control_root" in ln][0]
     doc = json.load(open(receipt))
-    assert [s["index"] for s in doc["inner"]["Composite"]["segments"]] == [0, 1, 2]
-    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("small")], capture_output=True, text=True)
+    segs = doc["inner"]["Composite"]["segments"]
+    assert [s["index"] for s in segs] == [0, 1, 2] and segs[2]["claim"]["exit_code"] == {"Halted": 0} and segs[0]["claim"]["exit_code"] == "SystemSplit"
+    bind = ["--image-id", ids["image_ids"][0], "--control-root", "%d:%s" % (ids["control_root"]["po2"], ",".join(map(str, ids["control_root"]["root"])))]
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("small")] + bind, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     report = json.loads(out.stdout)
-    assert report["accepted"] is True and report["segments"] == 3 and report["commitment"] == commitment
+    assert report["accepted"] is True and report["journal_bound"] is True and report["segments"] == 3 and report["commitment"] == commitment
+    # the same seals with another journal, or checked against another image id, are refused
+    doc["journal"]["bytes"][-6] ^= 1
+    json.dump(doc, open(receipt, "w"), separators=(",", ":"))
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("small")] + bind, capture_output=True, text=True)
+    assert out.returncode == 1 and "journal" in json.loads(out.stdout)["reason"]
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("small")], capture_output=True, text=True)
+    assert out.returncode == 1 and json.loads(out.stdout)["seals_valid"] is True and json.loads(out.stdout)["journal_bound"] is False
 
 
 @pytest.mark.gpu
@@ -86,4 +96,4 @@ def test_batch_of_receipts_on_a_work_queue(tmp_path):
     info = json.loads(out.stdout.strip().splitlines()[-1])
     assert info["receipts"] == 4 and info["segments"] == 3 and info["receipts_per_s"] > 0 and abs(info["segments_per_s"] / info["receipts_per_s"] - 3) < 1e-3
     bad = subprocess.run([CLI, circuit_path("small"), "--receipts", "2", "--receipt-out", str(tmp_path / "r.json")], capture_output=True, text=True)
-    assert bad.returncode == 1 and "throughput run" in bad.stderr
+    assert bad.returncode == 1 and "--receipt-dir" in bad.stderr

@@ -1,0 +1,97 @@
+"""BASELINE.json configs[2], [3] and [4] at their stated sizes, on the one GPU a test box has (the 8-GPU side of each is the
+driver's to run; the code path per rank is the one exercised here):
+  configs[2]  the same trace as ~64 segments at po2 = 20, sharded segment-parallel          -> bench.py --segments 64
+  configs[3]  a batch of 32 independent receipts, throughput mode                            -> r0h_prove --receipts 32 --segments 2
+  configs[4]  lift + join of segment receipts up a binary tree, ranks exchanging seals       -> tools/bench_recursion.py --gpus 2 (gloo, one GPU)
+Every seal that leaves these runs is checked by the CPU oracle's verifier (bound to the control root), not by the product's."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+import hyperfridge_r0_amd as r0
+from conftest import ROOT, circuit_path
+
+pytestmark = pytest.mark.gpu
+PO2 = 20
+_ENV = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+@pytest.fixture(scope="module")
+def bench_circuit(hal, orc):
+    blob = np.fromfile(circuit_path("bench"), dtype=np.uint32)
+    gc = hal.load_circuit(blob, entry.code_object_path("bench"))
+    root = hal.code_root(gc, PO2)
+    # the oracle computes the same control root from its own CODE columns (bit-exact device vs CPU at full size)
+    oc = orc.circuit(blob)
+    ocode, _, _ = oc.witgen(PO2, 0)
+    assert np.array_equal(oc.code_root(ocode, PO2), root)
+    yield dict(blob=blob, oc=oc, root=root)
+    gc.free()
+
+
+def test_config2_fixed_batch_of_64_segments(tmp_path, bench_circuit):
+    seal_dir = str(tmp_path / "seals")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--segments", "64", "--cpu-po2", "0", "--seal-dir", seal_dir, "--keep-every", "8"],
+                         capture_output=True, text=True, cwd=ROOT, env=_ENV, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(d) == 1
+    d = d[0]
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["fixed_batch_segments"] == 64 and d["config"]["po2"] == PO2
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 64) < 0.5  # 64 units in the timed region
+    assert d["config"]["workload"].startswith("configs[2]")
+    kept = sorted(glob.glob(os.path.join(seal_dir, "seal_*.npy")))
+    assert [os.path.basename(p) for p in kept] == ["seal_%04d.npy" % k for k in range(0, 64, 8)]
+    firsts = set()
+    for p in kept:
+        seal = np.load(p)
+        assert bench_circuit["oc"].verify(seal, code_root=bench_circuit["root"]) == (0, "ok"), p
+        firsts.add(tuple(seal[:8].tolist()))
+    assert len(firsts) == len(kept)  # distinct segments, not one witness proved 64 times
+
+
+def test_config3_batch_of_32_receipts_at_full_size(tmp_path, bench_circuit):
+    rdir = tmp_path / "receipts"
+    rdir.mkdir()
+    commitment = json.dumps({"hostinfo": "host:main", "iban": "CH4308307000289537312", "stmts": [{"elctrnc_seq_nb": "247"}]}, separators=(",", ":"))
+    cli = os.path.join(ROOT, "hyperfridge-r0_amd", "r0h_prove")
+    out = subprocess.run([cli, circuit_path("bench"), "--code-object", entry.code_object_path("bench"), "--po2", str(PO2), "--receipts", "32", "--segments", "2",
+                          "--contexts", "8", "--receipt-dir", str(rdir), "--journal", commitment], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    info = [ln for ln in lines if "segments_per_s" in ln][0]
+    ids = [ln for ln in lines if "control_root" in ln][0]
+    assert info["receipts"] == 32 and info["segments"] == 2 and info["po2"] == PO2 and info["receipts_per_s"] > 0
+    assert ids["control_root"]["po2"] == PO2 and ids["control_root"]["root"] == bench_circuit["root"].tolist() and len(set(ids["image_ids"])) == 32
+    files = sorted(glob.glob(str(rdir / "receipt_*.json")))
+    assert len(files) == 32
+    roots = {PO2: bench_circuit["root"]}
+    for r, path in enumerate(files):
+        text = open(path).read()
+        doc = json.loads(text)  # plain JSON any reader can take
+        segs = doc["inner"]["Composite"]["segments"]
+        assert [s["index"] for s in segs] == [0, 1] and r0.journal_commitment(bytes(doc["journal"]["bytes"])).decode() == commitment
+        for s in segs:  # every seal through the oracle's verifier, bound to the program
+            assert bench_circuit["oc"].verify(np.array(s["seal"], dtype=np.uint32), code_root=bench_circuit["root"]) == (0, "ok"), (path, s["index"])
+        rc = r0.Receipt.parse(text)
+        assert rc.to_json() == text
+        assert rc.verify(bench_circuit["blob"], roots, bytes.fromhex(ids["image_ids"][r]))[:2] == (0, "ok"), path
+        assert rc.verify(bench_circuit["blob"], roots, bytes.fromhex(ids["image_ids"][(r + 1) % 32]))[0] == 8  # another receipt's image id
+
+
+def test_config4_lift_join_tree_of_8_leaves_over_two_ranks(tmp_path, orc):
+    root_file = str(tmp_path / "root.npy")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_recursion.py"), "--gpus", "2", "--segments", "8", "--backend", "gloo", "--share-device",
+                          "--root-out", root_file], capture_output=True, text=True, cwd=ROOT, env=_ENV, timeout=1100)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    assert d["n_gpus"] == 2 and d["segments"] == 8 and d["segment_po2"] == 20 and d["recursion_po2"] == 18
+    assert d["cross_rank_join_steps"] == 1 and d["root_verifies"] is True and d["backend"] == "gloo"
+    rec_blob = np.fromfile(circuit_path("recursion"), dtype=np.uint32)
+    assert orc.circuit(rec_blob).verify(np.load(root_file)) == (0, "ok")

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--segment-po2", type=int, default=20)
     ap.add_argument("--recursion-po2", type=int, default=18)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--root-out", default="", help="rank 0 writes the root seal there (.npy) for checking")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal on a one-GPU box; needs --backend gloo)")
     args = ap.parse_args()
 
@@ -92,6 +93,8 @@ def main():
     t3 = time.perf_counter()
     if rank == 0:
         verdict = r0.verify_seal(rec_blob, node.seal)
+        if args.root_out:
+            np.save(args.root_out, node.seal)
         steps = len(recursion.tree_schedule(world))
         print(json.dumps({
             "metric": "lift+join tree over segment seals (configs[4] in shape; recursion-shaped circuit, see hyperfridge-r0_amd/recursion.py)",

@@ -247,7 +247,8 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
 
 SHAPES = {
     "tiny": dict(n_code=4, n_data=12, n_acc=2, n_free=4, n_pad=6, n_global=2, seed=1, comp=6),
-    "small": dict(n_code=8, n_data=40, n_acc=4, n_free=8, n_pad=60, n_global=4, seed=2, comp=10),
+    # 8 public inputs: enough to name a receipt claim (r0h_claim_globals), as `bench` can
+    "small": dict(n_code=8, n_data=40, n_acc=4, n_free=8, n_pad=60, n_global=8, seed=2, comp=10),
     "bench": dict(n_code=16, n_data=192, n_acc=12, n_free=24, n_pad=2600, n_global=8, seed=3, comp=16),
     # recursion-SHAPED: a smaller trace (proved at po2 = 18) whose 16 public inputs carry the two 8-word digests a lift/join step
     # stands for (hyperfridge-r0_amd/recursion.py).  It does not verify seals in-circuit: risc0's recursion circuit is not reproducible here.
