@@ -17,6 +17,58 @@ __device__ __forceinline__ uint32_t sbox7(uint32_t x) {
   return reduce1(mul_lazy(x3, x4));
 }
 
+// One modular add inside a larger asm statement: r = a + b mod p (x: scratch).  r may be a or b.
+#define R0H_ASM_ADD(r, a, b, x) "v_add_u32 " r ", " a ", " b "\n\tv_subrev_co_u32 " x ", vcc, 0x78000001, " r "\n\tv_cndmask_b32 " r ", " x ", " r ", vcc\n\t"
+// External linear layer: circ(2 M4, M4, .., M4) with M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] -- 128 modular adds.
+// Written as seven asm statements (one per block of four cells incl. its share of the column sums, one for the final 24 adds):
+// hipcc puts an `s_nop 0` between an asm statement and the next instruction touching a register that statement wrote (it assumes
+// a dst-forwarding hazard on gfx950 for anything inside asm), so the one-statement-per-add form carried a nop with every add:
+// the kernel is VALU-throughput bound, so the nops themselves cost next to nothing, but the statement form needs 98 instead of 139
+// VGPRs (four waves per SIMD instead of three) and measures 0.45 % faster on hash_rows in an A/B on one box
+// (profiles/r02/poseidon2_variants.md).  Same canonical words: every add is reduced, only the statement boundaries moved.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(R0H_MEXT_PLAIN)
+template <bool FIRST>
+__device__ __forceinline__ void m4_block(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3) {
+  uint32_t o0, o1, o2, o3, t0, t1, t2, t3, u, x;
+  // %0-3 o, %4-7 s (in/out), %8-13 t0 t1 t2 t3 u x, %14-17 a b d e
+  asm(R0H_ASM_ADD("%8", "%14", "%15", "%13")   // t0 = a + b
+      R0H_ASM_ADD("%9", "%16", "%17", "%13")   // t1 = d + e
+      R0H_ASM_ADD("%12", "%15", "%15", "%13")  // u = 2b
+      R0H_ASM_ADD("%10", "%12", "%9", "%13")   // t2 = 2b + t1
+      R0H_ASM_ADD("%12", "%17", "%17", "%13")  // u = 2e
+      R0H_ASM_ADD("%11", "%12", "%8", "%13")   // t3 = 2e + t0
+      R0H_ASM_ADD("%9", "%9", "%9", "%13")     // 2 t1
+      R0H_ASM_ADD("%9", "%9", "%9", "%13")     // 4 t1
+      R0H_ASM_ADD("%3", "%9", "%11", "%13")    // o3 = t4 = 4 t1 + t3
+      R0H_ASM_ADD("%8", "%8", "%8", "%13")     // 2 t0
+      R0H_ASM_ADD("%8", "%8", "%8", "%13")     // 4 t0
+      R0H_ASM_ADD("%1", "%8", "%10", "%13")    // o1 = t5 = 4 t0 + t2
+      R0H_ASM_ADD("%0", "%11", "%1", "%13")    // o0 = t3 + t5
+      R0H_ASM_ADD("%2", "%10", "%3", "%13")    // o2 = t2 + t4
+      R0H_ASM_ADD("%4", "%4", "%0", "%13") R0H_ASM_ADD("%5", "%5", "%1", "%13") R0H_ASM_ADD("%6", "%6", "%2", "%13") R0H_ASM_ADD("%7", "%7", "%3", "%13")
+      : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(u), "=&v"(x)
+      : "v"(c0), "v"(c1), "v"(c2), "v"(c3)
+      : "vcc");
+  c0 = o0; c1 = o1; c2 = o2; c3 = o3;
+}
+__device__ __forceinline__ void m_ext(uint32_t (&c)[P2_CELLS]) {
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, x;
+#pragma unroll
+  for (int k = 0; k < P2_CELLS; k += 4) m4_block<false>(c[k], c[k + 1], c[k + 2], c[k + 3], s0, s1, s2, s3);
+  // %0-23 cells (in/out), %24 scratch, %25-28 column sums
+  asm(R0H_ASM_ADD("%0", "%0", "%25", "%24") R0H_ASM_ADD("%1", "%1", "%26", "%24") R0H_ASM_ADD("%2", "%2", "%27", "%24") R0H_ASM_ADD("%3", "%3", "%28", "%24")
+      R0H_ASM_ADD("%4", "%4", "%25", "%24") R0H_ASM_ADD("%5", "%5", "%26", "%24") R0H_ASM_ADD("%6", "%6", "%27", "%24") R0H_ASM_ADD("%7", "%7", "%28", "%24")
+      R0H_ASM_ADD("%8", "%8", "%25", "%24") R0H_ASM_ADD("%9", "%9", "%26", "%24") R0H_ASM_ADD("%10", "%10", "%27", "%24") R0H_ASM_ADD("%11", "%11", "%28", "%24")
+      R0H_ASM_ADD("%12", "%12", "%25", "%24") R0H_ASM_ADD("%13", "%13", "%26", "%24") R0H_ASM_ADD("%14", "%14", "%27", "%24") R0H_ASM_ADD("%15", "%15", "%28", "%24")
+      R0H_ASM_ADD("%16", "%16", "%25", "%24") R0H_ASM_ADD("%17", "%17", "%26", "%24") R0H_ASM_ADD("%18", "%18", "%27", "%24") R0H_ASM_ADD("%19", "%19", "%28", "%24")
+      R0H_ASM_ADD("%20", "%20", "%25", "%24") R0H_ASM_ADD("%21", "%21", "%26", "%24") R0H_ASM_ADD("%22", "%22", "%27", "%24") R0H_ASM_ADD("%23", "%23", "%28", "%24")
+      : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]),
+        "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]), "+v"(c[16]), "+v"(c[17]), "+v"(c[18]), "+v"(c[19]), "+v"(c[20]), "+v"(c[21]), "+v"(c[22]), "+v"(c[23]),
+        "=&v"(x)
+      : "v"(s0), "v"(s1), "v"(s2), "v"(s3)
+      : "vcc");
+}
+#else
 __device__ __forceinline__ void m_ext(uint32_t (&c)[P2_CELLS]) {
   uint32_t s0, s1, s2, s3;
 #pragma unroll
@@ -35,6 +87,7 @@ __device__ __forceinline__ void m_ext(uint32_t (&c)[P2_CELLS]) {
     c[k] = add(c[k], s0); c[k + 1] = add(c[k + 1], s1); c[k + 2] = add(c[k + 2], s2); c[k + 3] = add(c[k + 3], s3);
   }
 }
+#endif
 
 // c[1] + ... + c[23] mod p for reduced words, as a balanced tree
 __device__ __forceinline__ uint32_t sum_lanes_1_to_23(const uint32_t (&c)[P2_CELLS]) {

@@ -61,7 +61,7 @@ int main() {
   (void)hipMalloc(&d, 4096);
   (void)hipMalloc(&dk, sizeof hk);
   (void)hipMemcpy(dk, &hk, sizeof hk, hipMemcpyHostToDevice);
-  for (int w = 1; w <= 3; w++) {
+  for (int w = 1; w <= 5; w++) {
     run<0>("full round", d, dk, 4000, w);
     run<1>("21 partial", d, dk, 400, w);
     run<3>("m_ext", d, dk, 8000, w);
