@@ -28,64 +28,88 @@ static const char* launch_ok(const char* what) {
 // sum_i c[i] x^i = sum_hi B[hi] * (sum_lo c[hi*RL + lo] * A[lo]),  A[lo] = x^lo, B[hi] = x^(hi*RL).
 // A wave owns a row of RL coefficients: each lane keeps its 16 A-values in registers, multiplies base-field
 // coefficients into them (4 products per coefficient), the wave reduces, lane 0 folds in B[hi].
-constexpr uint32_t EVAL_RL_LOG = 10;
 constexpr uint32_t EVAL_BLOCKS = 64;  // partial sums per evaluation
 
 // A[lo] and B[hi] with A[lo] * B[hi] = x^e(hi*rl + lo): e = identity for natural-order coefficients, e = brev_n for
 // bit-reversed ones (brev_n(hi*rl + lo) = brev(lo) * rows + brev(hi))
-__global__ void eval_tables_kernel(uint32_t* __restrict__ tab, Fp4 x, uint32_t rl_log, uint32_t rows_log, uint32_t bitrev_coeffs) {
+__global__ void eval_tables_kernel(uint32_t* __restrict__ tabs, const uint32_t* __restrict__ points, uint32_t rl_log, uint32_t rows_log, uint32_t bitrev_coeffs) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, rl = 1u << rl_log, rows = 1u << rows_log;
+  uint32_t* tab = tabs + 4 * (size_t)blockIdx.y * (rl + rows);  // one table pair per point
+  const Fp4 x = ld4(points + 4 * (size_t)blockIdx.y);
   if (i < rl) st4(tab + 4 * (size_t)i, fp4_pow(x, bitrev_coeffs ? (uint64_t)bitrev(i, rl_log) << rows_log : (uint64_t)i));
   else if (i < rl + rows) st4(tab + 4 * (size_t)i, fp4_pow(x, bitrev_coeffs ? (uint64_t)bitrev(i - rl, rows_log) : (uint64_t)(i - rl) << rl_log));
 }
 
+// A column is read ONCE and evaluated at all NP points asked of it (a register's taps sit at 1-3 points z w^-back): the lanes keep
+// NP sets of 2^rl_log / 64 powers, the loaded coefficients are shared by the NP sums.  (Round 1 ran one pass per point: 2.0 GB
+// read per segment for 1.09 GB of distinct columns.)
+template <int NP>
 __global__ __launch_bounds__(256) void eval_rows_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
-                                                         const uint32_t* __restrict__ which, const uint32_t* __restrict__ tab,
+                                                         const uint32_t* __restrict__ which, const uint32_t* __restrict__ tabs,
                                                          uint32_t po2, uint32_t rl_log) {
+  constexpr int KP = 8;  // powers per lane and point: rows of up to 512 coefficients
   const uint32_t rl = 1u << rl_log, rows = 1u << (po2 - rl_log);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t* poly = coeffs + ((size_t)which[blockIdx.y] << po2);
-  Fp4 a[16];
+  const size_t tab_stride = 4 * (size_t)(rl + rows);
+  Fp4 a[NP][KP];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    uint32_t lo = lane + 64 * k;
-    a[k] = lo < rl ? ld4(tab + 4 * (size_t)lo) : fp4_zero();
-  }
-  Fp4 tot = fp4_zero();
+  for (int p = 0; p < NP; p++)
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+      uint32_t lo = lane + 64 * k;
+      a[p][k] = lo < rl ? ld4(tabs + p * tab_stride + 4 * (size_t)lo) : fp4_zero();
+    }
+  Fp4 tot[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) tot[p] = fp4_zero();
+#pragma unroll 1
   for (uint32_t hi = blockIdx.x * 4 + wave; hi < rows; hi += gridDim.x * 4) {
     const uint32_t* row = poly + ((size_t)hi << rl_log);
-    Fp4 s = fp4_zero();
+    uint32_t cf[KP];
 #pragma unroll
-    for (int g = 0; g < 4; g++) {  // four coefficient * power products per 64-bit sum, one reduction per component
-      uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (int k = 0; k < KP; k++) {
+      uint32_t lo = lane + 64 * k;
+      cf[k] = lo < rl ? row[lo] : 0u;
+    }
 #pragma unroll
-      for (int k = 4 * g; k < 4 * g + 4; k++) {
-        uint32_t lo = lane + 64 * k;
-        uint32_t cf = lo < rl ? row[lo] : 0u;
-        t0 += (uint64_t)a[k].e[0] * cf; t1 += (uint64_t)a[k].e[1] * cf;
-        t2 += (uint64_t)a[k].e[2] * cf; t3 += (uint64_t)a[k].e[3] * cf;
+    for (int p = 0; p < NP; p++) {
+      Fp4 s = fp4_zero();
+#pragma unroll
+      for (int g = 0; g < KP / 4; g++) {  // four coefficient * power products per 64-bit sum, one reduction per component
+        uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+        for (int k = 4 * g; k < 4 * g + 4; k++) {
+          t0 += (uint64_t)a[p][k].e[0] * cf[k]; t1 += (uint64_t)a[p][k].e[1] * cf[k];
+          t2 += (uint64_t)a[p][k].e[2] * cf[k]; t3 += (uint64_t)a[p][k].e[3] * cf[k];
+        }
+        s = s + Fp4{{reduce64(t0), reduce64(t1), reduce64(t2), reduce64(t3)}};
+        __builtin_amdgcn_sched_barrier(0);  // keep the 64-bit sums of one group from being interleaved with the next (register pressure)
       }
-      s = s + Fp4{{reduce64(t0), reduce64(t1), reduce64(t2), reduce64(t3)}};
-    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      Fp4 o;
+      for (int off = 32; off >= 1; off >>= 1) {
+        Fp4 o;
 #pragma unroll
-      for (int q = 0; q < 4; q++) o.e[q] = __shfl_xor(s.e[q], off);
-      s = s + o;
+        for (int q = 0; q < 4; q++) o.e[q] = __shfl_xor(s.e[q], off);
+        s = s + o;
+      }
+      if (lane == 0) tot[p] = tot[p] + s * ld4(tabs + p * tab_stride + 4 * (size_t)(rl + hi));
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (lane == 0) tot = tot + s * ld4(tab + 4 * (size_t)(rl + hi));
   }
-  __shared__ uint32_t red[4][4];
+  __shared__ uint32_t red[4][NP][4];
   if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) red[wave][q] = tot.e[q];
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) red[wave][p][q] = tot[p].e[q];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < NP) {
+    const uint32_t p = threadIdx.x;
     Fp4 r = fp4_zero();
-    for (int w = 0; w < 4; w++) r = r + Fp4{{red[w][0], red[w][1], red[w][2], red[w][3]}};
-    st4(partial + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x), r);
+    for (int w = 0; w < 4; w++) r = r + Fp4{{red[w][p][0], red[w][p][1], red[w][p][2], red[w][p][3]}};
+    st4(partial + 4 * (((size_t)blockIdx.y * NP + p) * gridDim.x + blockIdx.x), r);
   }
 }
 
@@ -245,10 +269,21 @@ __global__ void prefix_apply_kernel(uint32_t* __restrict__ io, const uint32_t* _
 struct DivPowers {
   Fp4 z, zE, zChunk;  // z, z^E, z^chunk
 };
-__global__ void divide_chunk_sum_kernel(uint32_t* __restrict__ chunk_val, const uint32_t* __restrict__ poly, DivPowers pw, uint32_t E) {
+// One division job = (polynomial index within a buffer of n-coefficient polynomials, point, slot of its chunk values).  The
+// kernels take a batch of jobs on blockIdx.y -- the DEEP step divides ~10 combos by one to three points each: one launch set
+// per "k-th point of every combo" instead of one per (combo, point), and the remainders are read back once at the end.
+struct DivJob {
+  DivPowers pw;
+  uint32_t poly, slot, pad0, pad1;
+};
+__global__ void divide_chunk_sum_kernel(uint32_t* __restrict__ chunk_vals, const uint32_t* __restrict__ polys, const DivJob* __restrict__ jobs, uint32_t E,
+                                        uint32_t n, uint32_t n_chunks) {
   extern __shared__ uint32_t sh[];
   const uint32_t t = threadIdx.x, nt = blockDim.x;
-  const uint32_t* p = poly + 4 * ((size_t)blockIdx.x * nt * E + (size_t)t * E);
+  const DivJob job = jobs[blockIdx.y];
+  const DivPowers pw = job.pw;
+  uint32_t* chunk_val = chunk_vals + 4 * (size_t)job.slot * (n_chunks + 1);
+  const uint32_t* p = polys + 4 * ((size_t)job.poly * n + (size_t)blockIdx.x * nt * E + (size_t)t * E);
   Fp4 v = fp4_zero();
   for (uint32_t k = E; k-- > 0;) v = v * pw.z + ld4(p + 4 * k);  // sum_k p[k] z^k
   st4(sh + 4 * t, v);
@@ -264,8 +299,11 @@ __global__ void divide_chunk_sum_kernel(uint32_t* __restrict__ chunk_val, const 
 }
 // carry[b] = sum_{b' > b} S_b' z^((b'-b-1)*chunk); remainder = sum_b S_b z^(b*chunk) -> chunk_val[n_chunks].
 // One block: each thread owns `per` consecutive chunks, a suffix scan with growing powers links the threads.
-__global__ __launch_bounds__(256) void divide_chunk_carry_kernel(uint32_t* chunk_val, DivPowers pw, uint32_t n_chunks) {
+__global__ __launch_bounds__(256) void divide_chunk_carry_kernel(uint32_t* chunk_vals, const DivJob* __restrict__ jobs, uint32_t n_chunks) {
   __shared__ uint32_t sh[256 * 4];
+  const DivJob job = jobs[blockIdx.x];
+  const DivPowers pw = job.pw;
+  uint32_t* chunk_val = chunk_vals + 4 * (size_t)job.slot * (n_chunks + 1);
   const uint32_t t = threadIdx.x, per = (n_chunks + 255) / 256, b0 = t * per;
   Fp4 v = fp4_zero();  // sum_k S[b0+k] zc^k
   for (uint32_t k = per; k-- > 0;)
@@ -291,10 +329,14 @@ __global__ __launch_bounds__(256) void divide_chunk_carry_kernel(uint32_t* chunk
     cur = cur * pw.zChunk + sv;
   }
 }
-__global__ void divide_apply_kernel(uint32_t* __restrict__ poly, const uint32_t* __restrict__ chunk_carry, DivPowers pw, uint32_t E) {
+__global__ void divide_apply_kernel(uint32_t* __restrict__ polys, const uint32_t* __restrict__ chunk_vals, const DivJob* __restrict__ jobs, uint32_t E, uint32_t n,
+                                    uint32_t n_chunks) {
   extern __shared__ uint32_t sh[];
   const uint32_t t = threadIdx.x, nt = blockDim.x;
-  uint32_t* p = poly + 4 * ((size_t)blockIdx.x * nt * E + (size_t)t * E);
+  const DivJob job = jobs[blockIdx.y];
+  const DivPowers pw = job.pw;
+  const uint32_t* chunk_carry = chunk_vals + 4 * (size_t)job.slot * (n_chunks + 1);
+  uint32_t* p = polys + 4 * ((size_t)job.poly * n + (size_t)blockIdx.x * nt * E + (size_t)t * E);
   Fp4 v = fp4_zero();
   for (uint32_t k = E; k-- > 0;) v = v * pw.z + ld4(p + 4 * k);
   st4(sh + 4 * t, v);
@@ -317,6 +359,12 @@ __global__ void divide_apply_kernel(uint32_t* __restrict__ poly, const uint32_t*
     st4(p + 4 * k, cur);
     cur = next;
   }
+}
+
+// remainders of a batch, packed: out[job] = chunk_vals[slot(job)][n_chunks]
+__global__ void divide_remainders_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ chunk_vals, uint32_t n_jobs, uint32_t n_chunks) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_jobs) st4(out + 4 * (size_t)j, ld4(chunk_vals + 4 * ((size_t)j * (n_chunks + 1) + n_chunks)));
 }
 
 static Fp4 host_fp4(const uint32_t v[4]) { return Fp4{{v[0], v[1], v[2], v[3]}}; }
@@ -344,36 +392,61 @@ const char* evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, cons
   R0H_REQUIRE((size_t)n_eval * 16 <= out->bytes, "r0h_batch_evaluate_any: %u results exceed the output buffer", n_eval);
   if (!n_eval) return nullptr;
   const size_t n_polys = coeffs->bytes >> (po2 + 2);
-  // group evaluations by their point: the power tables are shared by every polynomial evaluated at the same x
-  std::map<std::array<uint32_t, 4>, std::vector<uint32_t>> groups;
+  // evaluations of one column share a single read of it: group the requests by column, then the columns by the list of points
+  // asked of them (in the prover: one list per tap combo), at most MAX_NP points per pass
+  constexpr uint32_t MAX_NP = 2;  // three or four points at once need 246+ VGPRs: a third point takes a second pass over its column
+  struct ColJob { uint32_t col; std::vector<uint32_t> dest; };
+  std::map<uint32_t, std::vector<uint32_t>> by_col;  // column -> request indices
   for (uint32_t k = 0; k < n_eval; k++) {
     R0H_REQUIRE(which[k] < n_polys, "r0h_batch_evaluate_any: which[%u] = %u but the buffer holds %zu polynomials", k, which[k], n_polys);
     for (int q = 0; q < 4; q++) R0H_REQUIRE(xs[4 * k + q] < P, "r0h_batch_evaluate_any: xs[%u] not canonical", k);
-    groups[{xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]}].push_back(k);
+    by_col[which[k]].push_back(k);
   }
-  const uint32_t rl_log = po2 < EVAL_RL_LOG ? po2 : EVAL_RL_LOG, rl = 1u << rl_log, rows = 1u << (po2 - rl_log);
+  std::map<std::vector<uint32_t>, std::vector<ColJob>> groups;  // point list (4 words per point) -> columns
+  for (auto& c : by_col)
+    for (size_t at = 0; at < c.second.size(); at += MAX_NP) {
+      std::vector<uint32_t> key;
+      ColJob job{c.first, {}};
+      for (size_t i = at; i < c.second.size() && i < at + MAX_NP; i++) {
+        key.insert(key.end(), xs + 4 * (size_t)c.second[i], xs + 4 * (size_t)c.second[i] + 4);
+        job.dest.push_back(c.second[i]);
+      }
+      groups[key].push_back(std::move(job));
+    }
+  const uint32_t rl_log = po2 < 9 ? po2 : 9, rl = 1u << rl_log, rows = 1u << (po2 - rl_log);
   uint32_t blocks = (rows + 3) / 4;
   if (blocks > EVAL_BLOCKS) blocks = EVAL_BLOCKS;
-  const size_t tab_words = 4 * (size_t)(rl + rows), idx_words = 2 * (size_t)n_eval, part_words = 4 * (size_t)n_eval * blocks;
-  R0H_TRY(ensure_scratch(ctx, (tab_words + idx_words + part_words) * 4));
+  size_t max_cols = 0;
+  for (auto& g : groups) max_cols = std::max(max_cols, g.second.size());
+  const size_t tab_words = 4 * (size_t)MAX_NP * (rl + rows), pt_words = 4 * MAX_NP, idx_words = (size_t)(1 + MAX_NP) * max_cols,
+               part_words = 4 * (size_t)MAX_NP * max_cols * blocks;
+  R0H_TRY(ensure_scratch(ctx, (tab_words + pt_words + idx_words + part_words) * 4));
   uint32_t* tab = (uint32_t*)ctx->scratch;
-  uint32_t* idx = tab + tab_words;
+  uint32_t* pts = tab + tab_words;
+  uint32_t* idx = pts + pt_words;
   uint32_t* part = idx + idx_words;
   for (auto& g : groups) {
-    const uint32_t ng = (uint32_t)g.second.size();
-    std::vector<uint32_t> host(2 * ng);
-    for (uint32_t k = 0; k < ng; k++) { host[k] = which[g.second[k]]; host[ng + k] = g.second[k]; }
+    const uint32_t np = (uint32_t)(g.first.size() / 4), ng = (uint32_t)g.second.size();
+    std::vector<uint32_t> host((size_t)(1 + np) * ng);  // [column per job][destination per (job, point)]
+    for (uint32_t j = 0; j < ng; j++) {
+      host[j] = g.second[j].col;
+      for (uint32_t p = 0; p < np; p++) host[ng + (size_t)j * np + p] = g.second[j].dest[p];
+    }
     R0H_TRY(stage_h2d(ctx, idx, host.data(), host.size() * 4));
-    Fp4 x = Fp4{{g.first[0], g.first[1], g.first[2], g.first[3]}};
-    KScope ks(ctx, "batch_evaluate_any", 4.0 * ng * (double)(1u << po2));
-    // blocks per polynomial: enough workgroups overall (~2048) to fill the chip, but no more -- every block re-loads the
-    // 16 KB power table, and 192 polynomials run 20 % faster with 16 blocks each than with 64
+    R0H_TRY(stage_h2d(ctx, pts, g.first.data(), g.first.size() * 4));
+    KScope ks(ctx, "batch_evaluate_any", 4.0 * ng * (double)(1u << po2));  // algorithmic bytes: every column once
+    // blocks per polynomial: enough workgroups overall (~2048) to fill the chip, but no more -- every block re-loads the power tables
     uint32_t gb = 2048 / ng;
     gb = gb < 4 ? 4 : gb;
     gb = gb > blocks ? blocks : gb;
-    hipLaunchKernelGGL(eval_tables_kernel, dim3((rl + rows + 255) / 256), dim3(256), 0, ctx->stream, tab, x, rl_log, po2 - rl_log, bitrev_coeffs ? 1u : 0u);
-    hipLaunchKernelGGL(eval_rows_kernel, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log);
-    hipLaunchKernelGGL(eval_reduce_kernel, dim3((ng + 63) / 64), dim3(64), 0, ctx->stream, u32(out), part, idx + ng, gb, ng);
+    hipLaunchKernelGGL(eval_tables_kernel, dim3((rl + rows + 255) / 256, np), dim3(256), 0, ctx->stream, tab, pts, rl_log, po2 - rl_log, bitrev_coeffs ? 1u : 0u);
+    switch (np) {
+      case 1: hipLaunchKernelGGL(eval_rows_kernel<1>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log); break;
+      case 2: hipLaunchKernelGGL(eval_rows_kernel<2>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log); break;
+      case 3: hipLaunchKernelGGL(eval_rows_kernel<3>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log); break;
+      default: hipLaunchKernelGGL(eval_rows_kernel<4>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log); break;
+    }
+    hipLaunchKernelGGL(eval_reduce_kernel, dim3((ng * np + 63) / 64), dim3(64), 0, ctx->stream, u32(out), part, idx + ng, gb, ng * np);
     R0H_TRY(launch_ok("batch_evaluate_any kernels"));  // scratch reuse by the next group is ordered by the stream
   }
   return nullptr;
@@ -502,23 +575,65 @@ const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint3
   R0H_REQUIRE(canonical4(z), "r0h_poly_divide: z words must be canonical (< p)");
   R0H_REQUIRE(n && (n & (n - 1)) == 0, "r0h_poly_divide: n %u is not a power of two", n);
   R0H_REQUIRE((size_t)n * 16 <= poly->bytes, "r0h_poly_divide: n %u exceeds the buffer", n);
-  const ScanGeom g = scan_geom(n);
-  DivPowers pw;
-  pw.z = host_fp4(z);
-  pw.zE = fp4_pow(pw.z, g.E);
-  pw.zChunk = fp4_pow(pw.z, g.chunk);
-  R0H_TRY(ensure_scratch(ctx, (size_t)(g.n_chunks + 1) * 16));
-  uint32_t* cv = (uint32_t*)ctx->scratch;
-  KScope ks(ctx, "poly_divide", 48.0 * n);
-  hipLaunchKernelGGL(divide_chunk_sum_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, cv, u32(poly), pw, g.E);
-  hipLaunchKernelGGL(divide_chunk_carry_kernel, dim3(1), dim3(256), 0, ctx->stream, cv, pw, g.n_chunks);
-  hipLaunchKernelGGL(divide_apply_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, u32(poly), cv, pw, g.E);
-  R0H_TRY(launch_ok("poly_divide kernels"));
-  if (remainder) {
-    R0H_TRY_HIP(hipMemcpyAsync(remainder, cv + 4 * (size_t)g.n_chunks, 16, hipMemcpyDeviceToHost, ctx->stream));
-    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
-  }
-  return nullptr;
+  const uint32_t idx = 0;
+  return r0h::poly_divide_batch(ctx, poly, n, &idx, z, 1, remainder);
 }
 
 }  // extern "C"
+
+namespace r0h {
+// polys: a buffer of n-coefficient extension polynomials (AoS, natural order); job j divides polynomial poly_idx[j] in place by
+// (x - points[4j..4j+4)).  Jobs on the same polynomial are applied in the order given.  remainders_host (4 words per job, may be
+// NULL) is filled by ONE blocking copy after everything has been enqueued.
+const char* poly_divide_batch(r0h_ctx* ctx, r0h_buf* polys, uint32_t n, const uint32_t* poly_idx, const uint32_t* points, uint32_t n_jobs, uint32_t* remainders_host) {
+  R0H_GUARD_BEGIN
+  if (!n_jobs) return nullptr;
+  const ScanGeom g = scan_geom(n);
+  const size_t n_polys = polys->bytes / ((size_t)n * 16);
+  // pass k holds the k-th job of every polynomial: within a pass the jobs touch different polynomials and run side by side
+  std::vector<std::vector<uint32_t>> passes;
+  {
+    std::map<uint32_t, uint32_t> seen;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+      R0H_REQUIRE(poly_idx[j] < n_polys, "poly_divide: polynomial %u outside a buffer of %zu", poly_idx[j], n_polys);
+      const uint32_t k = seen[poly_idx[j]]++;
+      if (passes.size() <= k) passes.emplace_back();
+      passes[k].push_back(j);
+    }
+  }
+  std::vector<DivJob> jobs;  // in launch order; slot = the job's index as given (remainders come back in the caller's order)
+  for (const auto& pass : passes)
+    for (uint32_t j : pass) {
+      DivJob d;
+      d.pw.z = host_fp4(points + 4 * (size_t)j);
+      d.pw.zE = fp4_pow(d.pw.z, g.E);
+      d.pw.zChunk = fp4_pow(d.pw.z, g.chunk);
+      d.poly = poly_idx[j]; d.slot = j; d.pad0 = d.pad1 = 0;
+      jobs.push_back(d);
+    }
+  const size_t cv_bytes = (size_t)n_jobs * (g.n_chunks + 1) * 16, job_bytes = jobs.size() * sizeof(DivJob), rem_bytes = (size_t)n_jobs * 16;
+  R0H_TRY(ensure_scratch(ctx, cv_bytes + job_bytes + rem_bytes));
+  uint32_t* cv = (uint32_t*)ctx->scratch;
+  DivJob* d_jobs = (DivJob*)((char*)ctx->scratch + cv_bytes);
+  uint32_t* d_rem = (uint32_t*)((char*)ctx->scratch + cv_bytes + job_bytes);
+  R0H_TRY(stage_h2d(ctx, d_jobs, jobs.data(), job_bytes));
+  KScope ks(ctx, "poly_divide", 48.0 * n * n_jobs);
+  size_t first = 0;
+  for (const auto& pass : passes) {
+    const uint32_t nj = (uint32_t)pass.size();
+    hipLaunchKernelGGL(divide_chunk_sum_kernel, dim3(g.n_chunks, nj), dim3(g.threads), g.threads * 16, ctx->stream, cv, u32(polys), d_jobs + first, g.E, n, g.n_chunks);
+    hipLaunchKernelGGL(divide_chunk_carry_kernel, dim3(nj), dim3(256), 0, ctx->stream, cv, d_jobs + first, g.n_chunks);
+    hipLaunchKernelGGL(divide_apply_kernel, dim3(g.n_chunks, nj), dim3(g.threads), g.threads * 16, ctx->stream, u32(polys), cv, d_jobs + first, g.E, n, g.n_chunks);
+    first += nj;
+  }
+  R0H_TRY(launch_ok("poly_divide kernels"));
+  if (remainders_host) {
+    hipLaunchKernelGGL(divide_remainders_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, ctx->stream, d_rem, cv, n_jobs, g.n_chunks);
+    R0H_TRY(launch_ok("divide_remainders_kernel"));
+    R0H_TRY_HIP(hipMemcpyAsync(remainders_host, d_rem, rem_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return nullptr;
+  R0H_GUARD_END
+}
+}  // namespace r0h

@@ -152,6 +152,8 @@ const char* evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, cons
 const char* bit_reverse_ext(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
 // per-device kernel attributes of the NTT family (LDS limits); called by r0h_ctx_create with the device current
 const char* ntt_init_device();
+// batched synthetic division (DEEP step): job j divides polynomial poly_idx[j] of `polys` by (x - points[4j..]); one read-back
+const char* poly_divide_batch(r0h_ctx* ctx, r0h_buf* polys, uint32_t n, const uint32_t* poly_idx, const uint32_t* points, uint32_t n_jobs, uint32_t* remainders_host);
 void ctx_retain(r0h_ctx* ctx);
 void ctx_release(r0h_ctx* ctx);
 // host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table

@@ -398,21 +398,27 @@ static const char* proof_finish(r0h_proof& st, const r0h_buf* accum, std::vector
     sc.release(d_fix);
   }
   phase(ctx, "deep_divide");
-  for (uint32_t k = 0; k <= n_combos; k++) {
-    r0h_buf view = *combos;
-    view.ptr = (char*)combos->ptr + ((size_t)k << po2) * 16;
-    view.bytes = n * 16;
-    if (k < n_combos) {
-      for (uint32_t b = cv.combo_begin[k]; b < cv.combo_begin[k + 1]; b++) {
-        Fp4 pt = scale(z, fpow(back_one, cv.combo_backs[b])), rem;
-        R0H_TRY(r0h_poly_divide(ctx, &view, (uint32_t)n, pt.e, rem.e));
-        R0H_REQUIRE(rem == fp4_zero(), "prove_segment: DEEP quotient of combo %u has a non-zero remainder (witness violates the taps?)", k);
+  {
+    // every (combo, point) division of the DEEP step as one batch: a launch set per "k-th point of every combo", one read-back
+    // of all remainders (upstream divides on the host; round 1 here ran one scan and one host sync per division)
+    std::vector<uint32_t> job_poly, job_pt;
+    for (uint32_t k = 0; k <= n_combos; k++) {
+      if (k < n_combos) {
+        for (uint32_t b = cv.combo_begin[k]; b < cv.combo_begin[k + 1]; b++) {
+          const Fp4 pt = scale(z, fpow(back_one, cv.combo_backs[b]));
+          job_poly.push_back(k);
+          job_pt.insert(job_pt.end(), pt.e, pt.e + 4);
+        }
+      } else {
+        job_poly.push_back(k);
+        job_pt.insert(job_pt.end(), z4.e, z4.e + 4);
       }
-    } else {
-      Fp4 rem;
-      R0H_TRY(r0h_poly_divide(ctx, &view, (uint32_t)n, z4.e, rem.e));
-      R0H_REQUIRE(rem == fp4_zero(), "prove_segment: check quotient has a non-zero remainder");
     }
+    std::vector<uint32_t> rem(4 * job_poly.size());
+    R0H_TRY(poly_divide_batch(ctx, combos, (uint32_t)n, job_poly.data(), job_pt.data(), (uint32_t)job_poly.size(), rem.data()));
+    for (size_t j = 0; j < job_poly.size(); j++)
+      R0H_REQUIRE(!(rem[4 * j] | rem[4 * j + 1] | rem[4 * j + 2] | rem[4 * j + 3]),
+                  "prove_segment: DEEP quotient of combo %u has a non-zero remainder (witness violates the taps?)", job_poly[j]);
   }
   r0h_buf* fri_coeffs = nullptr;
   R0H_TRY(sc.alloc(ctx, n * 16, &fri_coeffs));
