@@ -30,17 +30,40 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary, or None."""
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
-        try:
-            k = json.load(open(path))["kernels"].get(kernel)
-        except Exception:
-            k = None
-        if k:
-            best = k["hbm_bytes_per_launch"]
-    return best
+def device_code_fingerprint(circuit="bench"):
+    """SHA-256 over everything that decides which kernels run and what they move: the HIP sources and headers of the library and
+    the circuit blob (the eval_check kernels are generated from it).  Stored with a PMC summary when it is collected
+    (tools/summarize_pmc.py) and compared here, so that `roofline.traffic` is never quoted from another state of the code."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "hyperfridge-r0_amd", "csrc")
+    files = sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".hpp")))
+    files += [os.path.join(ROOT, "include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))]
+    files.append(os.path.join(ROOT, "circuits", circuit + ".r0c"))
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel, launches_per_segment=None, circuit="bench"):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary -- or None when that summary was collected on other
+    device code than what is running now, or with another launch count per segment for this kernel (a stale figure is worse
+    than none: VERDICT r01)."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
+    if not paths:
+        return None
+    try:
+        doc = json.load(open(paths[-1]))
+        k = doc["kernels"].get(kernel)
+        if not k or doc.get("device_code_sha256") != device_code_fingerprint(circuit):
+            return None
+        per_segment = doc.get("segments_profiled")
+        if launches_per_segment is not None and per_segment and abs(k["launches"] / per_segment - launches_per_segment) > 1e-9:
+            return None
+        return k["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def spawn_ranks(script, argv, n, extra_env=None):
@@ -256,16 +279,18 @@ def main():
             launches = max(st["launches"], 1)
             achieved = st["alg_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name),
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name, launches / steps, args.circuit),
                         "launches_per_step": launches / steps, "avg_launch_ms": round(st["total_ms"] / launches, 4),
                         "alg_bytes_per_launch": round(st["alg_bytes"] / launches),
                         "share_of_device_time": round(st["total_ms"] / max(sum(v["total_ms"] for v in kstats.values()), 1e-9), 4),
                         "note": "this kernel is VALU-integer bound (Poseidon2: ~1.36k Montgomery products per permutation, "
                                 "the static VALU issue floor of the permutation is in valu_view); its HBM fraction is reported because the metric asks for it: DESIGN.md 6"}
         if roofline and roofline["kernel"] == "hash_rows_kernel":
-            # secondary view: the bound this kernel actually sits on -- the VALU issue rate.  SIMD cycles one wave spends per
-            # permutation (1024 SIMDs, in-kernel clock 2.37 GHz: profiles/r01/fpmul_microbench.txt) against the static issue floor of
-            # the compiled permutation (instruction counts x measured issue costs: tools/p2_issue_floor.py).
+            # secondary view: the bound this kernel actually sits on -- VALU throughput.  SIMD cycles one wave spends per permutation
+            # (1024 SIMDs; the cycles the measured time can hold at the 2.4 GHz maximum clock, so an upper bound of the real count)
+            # against the static floor of the compiled permutation: instruction counts x guaranteed minimum issue cycles
+            # (tools/p2_issue_floor.py).  frac <= 1 by construction; the rate-table estimate beside it prices the same
+            # stream at the rates isolated streams of each instruction sustain.
             rows = 4 << po2
             perms = rows * sum(-(-g // 16) for g in circuit.group_size) + rows  # three groups + CHECK (16 columns)
             d = 1 << po2
@@ -273,14 +298,16 @@ def main():
                 perms += (4 * d // 16) * 4
                 d //= 16
             st = kstats["hash_rows_kernel"]
-            cyc = st["total_ms"] * 1e-3 * 2.37e9 * 1024 / (perms * steps / 64.0)
+            cyc = st["total_ms"] * 1e-3 * 2.4e9 * 1024 / (perms * steps / 64.0)
             view = {"permutations_per_segment": perms, "G_permutations_per_s": round(perms * steps / (st["total_ms"] * 1e-3) / 1e9, 3),
-                    "simd_cycles_per_wave_permutation": round(cyc, 1), "issue_floor_simd_cycles": None, "frac": None}
-            floor_path = os.path.join(ROOT, "profiles", "r01", "p2_issue_floor.json")
-            if os.path.exists(floor_path):
-                fl = json.load(open(floor_path))
+                    "simd_cycles_per_wave_permutation_at_2.4GHz": round(cyc, 1), "issue_floor_simd_cycles": None, "frac": None}
+            floors = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "p2_issue_floor.json")))
+            if floors:
+                fl = json.load(open(floors[-1]))
                 view["issue_floor_simd_cycles"] = fl["issue_floor_simd_cycles_per_wave_permutation"]
+                view["rate_table_estimate_simd_cycles"] = fl.get("rate_table_estimate_simd_cycles_per_wave_permutation")
                 view["valu_instructions_per_permutation"] = fl["valu_instructions_per_permutation"]
+                view["multiply_instructions_per_permutation"] = sum(v for k, v in fl["by_class"].items() if k != "full_rate")
                 view["frac"] = round(view["issue_floor_simd_cycles"] / cyc, 4)
             roofline["valu_view"] = view
         cols = sum(circuit.group_size)

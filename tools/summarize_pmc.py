@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs into profiles/<round>/pmc_traffic.json.
-usage: summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<how it was collected>" """
+usage: summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<how it was collected>" [segments profiled] """
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # device_code_fingerprint(): the traffic is only quoted for exactly the code it was measured on
 
 
 def load(path, counter):
@@ -31,6 +35,9 @@ def main():
         corr = raw if "strided16" in k else 2 * raw
         out["kernels"][k] = {"launches": n, "fetch_raw_bytes": round(raw), "fetch_corrected_bytes": round(corr), "write_bytes": round(wr),
                              "hbm_bytes_per_launch": round(corr + wr)}
+    if len(sys.argv) > 5:
+        out["segments_profiled"] = int(sys.argv[5])  # launches / this = launches per segment (bench.py compares it with its own count)
+    out["kernel_names"] = sorted(out["kernels"])
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
 
