@@ -61,6 +61,10 @@ _SIGNATURES = {
     "r0h_gather_sample": [_vp, _vp, _vp, _u32, _u32, _u32],
     "r0h_scatter": [_vp, _vp, _vp, _vp, _vp, _u32],
     "r0h_fri_fold": [_vp, _vp, _vp, _vp, _u32],
+    "r0h_batch_evaluate_any_buf": [_vp, _vp, _u32, _vp, _vp, _u32, _vp],
+    "r0h_mix_poly_coeffs_buf": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32],
+    "r0h_scatter_slices": [_vp, _vp, _vp, _u32, _vp, _vp, _u32],
+    "r0h_hash_fold_io": [_vp, _vp, _u32, _u32],
     "r0h_prefix_products": [_vp, _vp, _u32],
     "r0h_poly_divide": [_vp, _vp, _u32, _vp, _vp],
     "r0h_circuit_emit_hip": [_vp, _sz, _c.POINTER(_c.c_char_p)],
@@ -574,6 +578,25 @@ class Hal:
 
     def scatter(self, into, index, offsets, values, n_index):
         _check(lib().r0h_scatter(self.ctx, into.handle, index.handle, offsets.handle, values.handle, n_index))
+
+    # ---- the Hal trait's operand placement: device buffers for which / xs / combos, host slices for scatter
+    def batch_evaluate_any_buf(self, coeffs, po2, which_buf, xs_buf, n_eval, out):
+        _check(lib().r0h_batch_evaluate_any_buf(self.ctx, coeffs.handle, po2, which_buf.handle, xs_buf.handle, n_eval, out.handle))
+
+    def mix_poly_coeffs_buf(self, combos, mix_start, mix, inp, combo_buf, input_count, po2):
+        ms, pms = _u32arr(mix_start)
+        m, pm = _u32arr(mix)
+        _check(lib().r0h_mix_poly_coeffs_buf(self.ctx, combos.handle, pms, pm, inp.handle, combo_buf.handle, input_count, po2))
+
+    def scatter_slices(self, into, index, offsets, values):
+        i, pi = _u32arr(index)
+        o, po = _u32arr(offsets)
+        v, pv = _u32arr(values)
+        assert o.size == v.size
+        _check(lib().r0h_scatter_slices(self.ctx, into.handle, pi, i.size, po, pv, o.size))
+
+    def hash_fold_io(self, io, input_size, output_size):
+        _check(lib().r0h_hash_fold_io(self.ctx, io.handle, input_size, output_size))
 
     def fri_fold(self, out, inp, mix, n_out):
         m, pm = _u32arr(mix)

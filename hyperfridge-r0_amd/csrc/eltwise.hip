@@ -548,6 +548,56 @@ const char* r0h_scatter(r0h_ctx* ctx, r0h_buf* into, const r0h_buf* index, const
   R0H_GUARD_END
 }
 
+// ---- the same operations with the operand placement of the risc0-zkp `Hal` trait (as recalled): `which`, `xs` and
+// `combos` are device Buffers there, `scatter` takes host slices.  The grouping these kernels rely on is made on the host, so the
+// Buffer forms read the small index buffers back (one copy of a few KB) -- a Rust `HipHal` calls these and never copies itself.
+const char* r0h_batch_evaluate_any_buf(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, const r0h_buf* which, const r0h_buf* xs, uint32_t n_eval, r0h_buf* out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && coeffs && out && which && xs, "r0h_batch_evaluate_any_buf: NULL argument");
+  R0H_REQUIRE((size_t)n_eval * 4 <= which->bytes && (size_t)n_eval * 16 <= xs->bytes, "r0h_batch_evaluate_any_buf: %u evaluations exceed the which / xs buffers", n_eval);
+  std::vector<uint32_t> w(n_eval), x(4 * (size_t)n_eval);
+  if (n_eval) {
+    R0H_TRY(r0h_buf_d2h(ctx, which, 0, w.data(), w.size() * 4));
+    R0H_TRY(r0h_buf_d2h(ctx, xs, 0, x.data(), x.size() * 4));
+  }
+  return r0h::evaluate_any(ctx, coeffs, po2, w.data(), x.data(), n_eval, out, false);
+  R0H_GUARD_END
+}
+
+const char* r0h_mix_poly_coeffs_buf(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mix_start[4], const uint32_t mix[4], const r0h_buf* input, const r0h_buf* combo_of,
+                                    uint32_t input_count, uint32_t po2) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && combo_of, "r0h_mix_poly_coeffs_buf: NULL argument");
+  R0H_REQUIRE((size_t)input_count * 4 <= combo_of->bytes, "r0h_mix_poly_coeffs_buf: %u columns exceed the combo buffer", input_count);
+  std::vector<uint32_t> c(input_count);
+  if (input_count) R0H_TRY(r0h_buf_d2h(ctx, combo_of, 0, c.data(), c.size() * 4));
+  return r0h_mix_poly_coeffs(ctx, combos, mix_start, mix, input, c.data(), input_count, po2);
+  R0H_GUARD_END
+}
+
+// Hal::scatter(into, index: &[u32], offsets: &[u32], values: &[Elem]): values[k] goes to into[offsets[k]] for index[0] <= k < index[n_index - 1]
+const char* r0h_scatter_slices(r0h_ctx* ctx, r0h_buf* into, const uint32_t* index, uint32_t n_index, const uint32_t* offsets, const uint32_t* values, uint32_t n_values) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && into && (index || !n_index) && ((offsets && values) || !n_values), "r0h_scatter_slices: NULL argument");
+  if (n_index < 2) return nullptr;
+  const uint32_t begin = index[0], end = index[n_index - 1];
+  R0H_REQUIRE(begin <= end && end <= n_values, "r0h_scatter_slices: index range [%u, %u) outside %u offsets/values", begin, end, n_values);
+  if (end == begin) return nullptr;
+  for (uint32_t k = begin; k < end; k++) {
+    R0H_REQUIRE((size_t)offsets[k] * 4 < into->bytes, "r0h_scatter_slices: offset %u outside the destination", offsets[k]);
+    R0H_REQUIRE(values[k] < P, "r0h_scatter_slices: value %u is not a canonical field word", k);
+  }
+  const size_t bytes = (size_t)(end - begin) * 4;
+  R0H_TRY(ensure_scratch(ctx, 2 * bytes));
+  uint32_t* d_off = (uint32_t*)ctx->scratch;
+  uint32_t* d_val = d_off + (end - begin);
+  R0H_TRY(stage_h2d(ctx, d_off, offsets + begin, bytes));
+  R0H_TRY(stage_h2d(ctx, d_val, values + begin, bytes));
+  hipLaunchKernelGGL(scatter_kernel, dim3((end - begin + 255) / 256), dim3(256), 0, ctx->stream, u32(into), d_off, d_val, 0u, end - begin);
+  return launch_ok("scatter_kernel");
+  R0H_GUARD_END
+}
+
 const char* r0h_fri_fold(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, const uint32_t mix[4], uint32_t n_out) {
   R0H_REQUIRE(ctx && out && in && mix, "r0h_fri_fold: NULL argument");
   R0H_REQUIRE(canonical4(mix), "r0h_fri_fold: mix words must be canonical (< p)");

@@ -36,7 +36,8 @@ extern "C" {
 #define R0H_GROUP_ACCUM 0
 #define R0H_GROUP_CODE 1
 #define R0H_GROUP_DATA 2
-#define R0H_MAX_PO2 20 /* trace rows; the evaluation domain is 4x that */
+#define R0H_MAX_PO2 20 /* trace rows of a segment (risc0's default segment size); the evaluation domain is 4x that, and the NTT
+                        * entry points take up to 2^22 points (the twiddle tables of a context cover exactly that) */
 
 typedef struct r0h_ctx r0h_ctx;
 typedef struct r0h_buf r0h_buf;
@@ -99,6 +100,18 @@ const char* r0h_gather_sample(r0h_ctx* ctx, r0h_buf* dst, const r0h_buf* src, ui
 const char* r0h_scatter(r0h_ctx* ctx, r0h_buf* into, const r0h_buf* index, const r0h_buf* offsets,
                         const r0h_buf* values, uint32_t n_index);
 const char* r0h_fri_fold(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, const uint32_t mix[4], uint32_t n_out);
+/* The same operations with the operand placement of the risc0-zkp `Hal` trait (as recalled): `which` (u32), `xs` (extension
+ * elements) and `combos` (u32) are device Buffers there, `scatter` takes host slices, `hash_fold` names both level sizes.  A Rust
+ * `HipHal` calls these directly; the grouping the kernels rely on is made on the host, so the Buffer forms read the small index
+ * buffers back themselves (one copy of a few KB). */
+const char* r0h_batch_evaluate_any_buf(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, const r0h_buf* which, const r0h_buf* xs,
+                                       uint32_t n_eval, r0h_buf* out);
+const char* r0h_mix_poly_coeffs_buf(r0h_ctx* ctx, r0h_buf* combos, const uint32_t mix_start[4], const uint32_t mix[4],
+                                    const r0h_buf* input, const r0h_buf* combo_of, uint32_t input_count, uint32_t po2);
+/* values[k] goes to into[offsets[k]] for index[0] <= k < index[n_index - 1] (offsets / values hold n_values host words) */
+const char* r0h_scatter_slices(r0h_ctx* ctx, r0h_buf* into, const uint32_t* index, uint32_t n_index, const uint32_t* offsets,
+                               const uint32_t* values, uint32_t n_values);
+const char* r0h_hash_fold_io(r0h_ctx* ctx, r0h_buf* io, uint32_t input_size, uint32_t output_size);
 const char* r0h_prefix_products(r0h_ctx* ctx, r0h_buf* io, uint32_t n);
 /* in-place synthetic division of an extension-coefficient polynomial (AoS, natural order) by (x - z) */
 const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint32_t z[4], uint32_t remainder[4]);

@@ -138,3 +138,31 @@ int main(int argc, char** argv) {
                            "-L", libdir, "-lr0hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe, blob_path, seal_path], capture_output=True, text=True)
     assert out.returncode == 0 and "verdict=0 (ok) po2=9" in out.stdout, out.stdout + out.stderr
+
+
+def test_rust_bindings_are_generated_from_the_header_and_name_the_same_symbols():
+    """bindings/r0hip_sys.rs (the `extern "C"` block a Rust `HipHal` links against) is generated from include/r0hip.h by
+    tools/gen_rust_bindings.py; it must be fresh, declare exactly the header's functions -- which the library exports -- and every
+    parameter must have come through with a Rust type (no rustc exists here to compile it, so the shape is checked textually)."""
+    import subprocess
+    import sys
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_bindings.py"), "--check"]).returncode == 0, "stale bindings"
+    rs = open(os.path.join(ROOT, "bindings", "r0hip_sys.rs")).read()
+    fns = re.findall(r"pub fn (r0h_\w+)\(([^)]*)\)( -> [^;]+)?;", rs)
+    assert sorted(f[0] for f in fns) == declared_symbols()
+    import hyperfridge_r0_amd as r0
+    lib = r0.lib()
+    for name, args, ret in fns:
+        assert hasattr(lib, name)
+        for a in filter(None, (x.strip() for x in args.split(","))):
+            nm, ty = a.split(": ")
+            assert re.fullmatch(r"(\*(const|mut) )*(u8|u32|u64|usize|f32|c_int|c_char|c_void|r0h_\w+)", ty), (name, a)
+        if ret:
+            assert re.fullmatch(r" -> (\*(const|mut) )*(u32|usize|c_int|c_char|c_void)", ret), (name, ret)
+    # spot checks of the translation rules
+    assert "pub fn r0h_ctx_create(device: c_int, out: *mut *mut r0h_ctx) -> *const c_char;" in rs
+    assert "pub fn r0h_buf_device_ptr(buf: *const r0h_buf) -> *mut c_void;" in rs
+    assert "pub fn r0h_free_error(msg: *const c_char);" in rs
+    assert "pub fn r0h_claim_digest(claim: *const r0h_receipt_claim, digest_out: *mut u8) -> *const c_char;" in rs
+    # INTEGRATION.md points at the generated file instead of carrying its own (partial) copy
+    assert "bindings/r0hip_sys.rs" in open(os.path.join(ROOT, "INTEGRATION.md")).read()

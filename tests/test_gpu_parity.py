@@ -405,3 +405,38 @@ def test_extreme_field_values_through_every_arithmetic_kernel(hal, orc):
     glob, mixw, pm = _extreme(rng, oc.n_global), _extreme(rng, oc.n_mix), np.array([P - 1, P - 1, P - 1, P - 1], np.uint32)
     check = hal.eval_check(gc, po2, hal.copy_from(ea), hal.copy_from(ec), hal.copy_from(ed), glob, mixw, pm)
     assert np.array_equal(check.to_host(), oc.eval_check(po2, ea, ec, ed, glob, mixw, pm))
+
+
+def test_hal_trait_operand_placement_forms_match_the_host_array_forms(hal, orc):
+    """`which` / `xs` / `combos` as device buffers, `scatter` from host slices, `hash_fold(io, input_size, output_size)`: the
+    operand placement of the risc0-zkp Hal trait (include/r0hip.h); results identical to the oracle's, as for the other forms."""
+    import hyperfridge_r0_amd as r0
+    rng = np.random.default_rng(5)
+    po2, cols = 11, 7
+    n = 1 << po2
+    coeffs = rnd(rng, cols * n)
+    which = np.array([0, 3, 3, 6, 1], np.uint32)
+    xs = rnd(rng, 4 * which.size)
+    out = hal.alloc(4 * which.size)
+    hal.batch_evaluate_any_buf(hal.copy_from(coeffs), po2, hal.copy_from(which), hal.copy_from(xs), which.size, out)
+    assert np.array_equal(out.to_host(), orc.batch_evaluate_any(coeffs, po2, which, xs))
+    combo_of = np.array([0, 1, 1, 0, 2, 2, 1], np.uint32)
+    ms, m = rnd(rng, 4), rnd(rng, 4)
+    want = orc.mix_poly_coeffs(np.zeros(3 * n * 4, np.uint32), ms, m, coeffs, combo_of, po2)
+    combos = hal.copy_from(np.zeros(3 * n * 4, np.uint32))
+    hal.mix_poly_coeffs_buf(combos, ms, m, hal.copy_from(coeffs), hal.copy_from(combo_of), cols, po2)
+    assert np.array_equal(combos.to_host(), want)
+    into = hal.copy_from(np.zeros(50, np.uint32))
+    offsets, vals = np.array([4, 9, 2, 30, 31], np.uint32), rnd(rng, 5)
+    hal.scatter_slices(into, [1, 3, 5], offsets, vals)  # entries 1..4
+    want = np.zeros(50, np.uint32)
+    want[offsets[1:]] = vals[1:]
+    assert np.array_equal(into.to_host(), want)
+    with pytest.raises(r0.R0HipError, match="outside the destination"):
+        hal.scatter_slices(into, [0, 5], np.array([4, 9, 2, 30, 50], np.uint32), vals)
+    lvl = rnd(rng, 2 * 64 * 8)
+    nb = hal.copy_from(lvl)
+    hal.hash_fold_io(nb, 64, 32)
+    assert np.array_equal(nb.to_host(), orc.hash_fold(lvl, 32))
+    with pytest.raises(r0.R0HipError, match="2 \\* output_size"):
+        hal.hash_fold_io(nb, 60, 32)
