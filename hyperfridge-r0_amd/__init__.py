@@ -106,6 +106,19 @@ _SIGNATURES = {
     "r0h_receipt_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_receipt_segment": [_vp, _sz, _pp, _c.POINTER(_sz), _c.POINTER(_u32)],
     "r0h_receipt_to_json": [_vp, _pp],
+    "r0h_ebics_parse": [_vp, _sz, _pp],
+    "r0h_ebics_free": [_vp],
+    "r0h_ebics_part": [_vp, _c.c_int, _pp, _c.POINTER(_sz)],
+    "r0h_ebics_check_digest": [_vp, _c.POINTER(_c.c_int)],
+    "r0h_ebics_verify_bank_signature": [_vp, _vp, _sz, _c.POINTER(_c.c_int)],
+    "r0h_ebics_check_transaction_key": [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_c.c_int)],
+    "r0h_ebics_verify_witness": [_vp, _vp, _sz, _vp, _sz, _c.POINTER(_c.c_int)],
+    "r0h_ebics_decrypt_order_data": [_vp, _vp],
+    "r0h_ebics_document": [_vp, _sz, _pp, _pp, _c.POINTER(_sz)],
+    "r0h_rsa_public_key_decimal": [_vp, _sz, _pp, _pp],
+    "r0h_ebics_env_inputs": [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _cp, _cp, _vp, _sz, _vp, _sz, _cp, _pp],
+    "r0h_aes128_block": [_vp, _vp, _c.c_int, _vp],
+    "r0h_zlib_inflate": [_vp, _sz, _pp, _c.POINTER(_sz)],
     "r0h_kernel_timing": [_vp, _c.c_int],
     "r0h_kernel_stats": [_vp, _vp, _sz],
     "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],
@@ -115,6 +128,7 @@ _PLAIN = {
     "r0h_version": ([], _cp),
     "r0h_receipt_kind": ([_vp], _c.c_int),
     "r0h_receipt_n_segments": ([_vp], _sz),
+    "r0h_ebics_n_documents": ([_vp], _sz),
     "r0h_verify_reason": ([_c.c_int], _cp),
     "r0h_receipt_verify_reason": ([_c.c_int], _cp),
     "r0h_buf_device_ptr": ([_vp], _vp),
@@ -312,6 +326,106 @@ def seal_digest(seal):
     a, pa = _u32arr(seal)
     out = np.zeros(8, dtype=np.uint32)
     _check(lib().r0h_seal_digest(pa, a.size, out.ctypes.data_as(_vp)))
+    return out
+
+
+class Ebics:
+    """An EBICS response pre-processed as data/checkResponse.sh does it (r0h_ebics_*; host only, no GPU)."""
+    AUTHENTICATED, SIGNED_INFO, SIGNATURE_VALUE, ORDER_DATA, DIGEST_VALUE, SIGNATURE_BIN, TRANSACTION_KEY_BIN, ORDER_DATA_BIN, PAYLOAD_ZIP = range(9)
+
+    def __init__(self, xml):
+        raw = xml.encode("utf-8") if isinstance(xml, str) else bytes(xml)
+        self.handle = _vp()
+        _check(lib().r0h_ebics_parse(raw, len(raw), ctypes.byref(self.handle)))
+
+    def part(self, which):
+        p, n = _vp(), _sz(0)
+        _check(lib().r0h_ebics_part(self.handle, which, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p, n.value) if n.value else b""
+
+    def _flag(self, fn, *args):
+        ok = _c.c_int(-1)
+        _check(fn(self.handle, *args, ctypes.byref(ok)))
+        return bool(ok.value)
+
+    def check_digest(self):
+        return self._flag(lib().r0h_ebics_check_digest)
+
+    def verify_bank_signature(self, pub_bank_pem):
+        pem = pub_bank_pem.encode() if isinstance(pub_bank_pem, str) else bytes(pub_bank_pem)
+        return self._flag(lib().r0h_ebics_verify_bank_signature, pem, len(pem))
+
+    def check_transaction_key(self, pub_client_pem, raw_block):
+        """(ok, 16-byte AES key) for the raw RSA-decrypted block 00 02 PS 00 key."""
+        pem = pub_client_pem.encode() if isinstance(pub_client_pem, str) else bytes(pub_client_pem)
+        raw, key = bytes(raw_block), (ctypes.c_uint8 * 16)()
+        ok = self._flag(lib().r0h_ebics_check_transaction_key, pem, len(pem), raw, len(raw), key)
+        return ok, bytes(key)
+
+    def verify_witness(self, pub_witness_pem, witness_hex):
+        pem = pub_witness_pem.encode() if isinstance(pub_witness_pem, str) else bytes(pub_witness_pem)
+        hx = witness_hex.encode() if isinstance(witness_hex, str) else bytes(witness_hex)
+        return self._flag(lib().r0h_ebics_verify_witness, pem, len(pem), hx, len(hx))
+
+    def decrypt_order_data(self, key):
+        """AES-128-CBC (zero IV) -> inflate -> ZIP: returns [(member name, bytes)]."""
+        _check(lib().r0h_ebics_decrypt_order_data(self.handle, bytes(key)))
+        docs = []
+        for i in range(lib().r0h_ebics_n_documents(self.handle)):
+            name, data, n = _vp(), _vp(), _sz(0)
+            _check(lib().r0h_ebics_document(self.handle, i, ctypes.byref(name), ctypes.byref(data), ctypes.byref(n)))
+            docs.append((ctypes.cast(name, _cp).value.decode("utf-8", "replace"), ctypes.string_at(data, n.value)))
+        return docs
+
+    def env_inputs(self, pub_bank_pem, client_private_pem, decrypted_tx_key, iban, host_info, witness_hex, pub_witness_pem, verbose):
+        """The u32 words of the thirteen ExecutorEnv inputs (host/src/main.rs:389-417)."""
+        b = lambda x: x.encode("utf-8") if isinstance(x, str) else bytes(x)
+        bank, client, wit, pubw, tx = b(pub_bank_pem), b(client_private_pem), b(witness_hex), b(pub_witness_pem), bytes(decrypted_tx_key)
+        env = _vp()
+        _check(lib().r0h_ebics_env_inputs(self.handle, bank, len(bank), client, len(client), tx, len(tx), b(iban), b(host_info), wit, len(wit), pubw, len(pubw),
+                                          b(verbose), ctypes.byref(env)))
+        try:
+            p, n = _vp(), _sz(0)
+            _check(lib().r0h_env_words(env, ctypes.byref(p), ctypes.byref(n)))
+            return np.frombuffer(ctypes.string_at(p, n.value * 4), dtype=np.uint32).copy()
+        finally:
+            lib().r0h_env_free(env)
+
+    def close(self):
+        if self.handle:
+            lib().r0h_ebics_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rsa_public_key_decimal(pem):
+    """(modulus, exponent) of a PEM "PUBLIC KEY" as decimal strings, as host/src/main.rs:383-387 hands the bank key to the guest."""
+    raw = pem.encode() if isinstance(pem, str) else bytes(pem)
+    m, e = _vp(), _vp()
+    _check(lib().r0h_rsa_public_key_decimal(raw, len(raw), ctypes.byref(m), ctypes.byref(e)))
+    out = ctypes.cast(m, _cp).value.decode(), ctypes.cast(e, _cp).value.decode()
+    lib().r0h_free_error(m)
+    lib().r0h_free_error(e)
+    return out
+
+
+def aes128_block(key, block, decrypt=False):
+    out = (ctypes.c_uint8 * 16)()
+    _check(lib().r0h_aes128_block(bytes(key), bytes(block), 1 if decrypt else 0, out))
+    return bytes(out)
+
+
+def zlib_inflate(data):
+    data = bytes(data)
+    p, n = _vp(), _sz(0)
+    _check(lib().r0h_zlib_inflate(data, len(data), ctypes.byref(p), ctypes.byref(n)))
+    out = ctypes.string_at(p, n.value)
+    lib().r0h_free_error(p)
     return out
 
 

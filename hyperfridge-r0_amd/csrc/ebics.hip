@@ -1,0 +1,962 @@
+// Native pre-processor for EBICS camt.053 responses (host-only, no device work) -- SURVEY.md 8(f) rank 4, the one row of the scope
+// table whose results the reference's own files pin.  It does what data/checkResponse.sh does with xmllint / openssl / perl /
+// zlib-flate / unzip before `host` is started (data/checkResponse.sh:112-298, called from host/src/main.rs:143-151):
+//   * cuts the four guest inputs out of the response and canonicalises them (:151-155, :192, :200, :221): "<xml>-authenticated",
+//     "<xml>-SignedInfo", "<xml>-SignatureValue", "<xml>-OrderData";
+//   * DigestValue == base64(SHA-256(authenticated))                                                         (:117-175);
+//   * RSA-2048 PKCS#1 v1.5 / SHA-256 verification of SignatureValue over SignedInfo with the bank's key       (:192-212);
+//   * the transaction key: the raw RSA-decrypted block (`-TransactionKeyDecrypt.bin`, 00 02 PS 00 key) re-encrypted with the
+//     client's public key must be <TransactionKey> -- the cheap direction the guest uses too (methods/guest/src/main.rs:663-718);
+//   * the witness signature over SHA-256(decoded order data)                                                (:261-286);
+//   * AES-128-CBC, zero IV, no padding removal, then RFC 1950 inflate, then the ZIP container                (:243-298);
+//   * the 13 `ExecutorEnv` input frames in the order host/src/main.rs:389-417 writes them.
+// Pinned by the reference's fixtures (tests/golden/camt53/, copied unchanged from data/test/ and data/): the four canonicalised
+// files byte for byte, the digest / signature / key identities, the decrypted statement (tests/test_ebics.py).
+// The canonicalisation is the subset of Exclusive XML C14N these documents need (no DTD, no processing instructions): attributes
+// sorted, empty elements expanded, text and attribute values re-escaped, then the namespace declarations the script injects.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/r0hip.h"
+#include "internal.hpp"
+#include "receipt_types.hpp"
+
+namespace {
+
+using Bytes = std::vector<uint8_t>;
+
+// ---------------------------------------------------------------- base64 / hex
+bool b64_decode(const char* s, size_t n, Bytes& out) {
+  uint32_t acc = 0;
+  int bits = 0, pad = 0;
+  for (size_t i = 0; i < n; i++) {
+    const unsigned char c = (unsigned char)s[i];
+    int v;
+    if (c >= 'A' && c <= 'Z') v = c - 'A';
+    else if (c >= 'a' && c <= 'z') v = c - 'a' + 26;
+    else if (c >= '0' && c <= '9') v = c - '0' + 52;
+    else if (c == '+') v = 62;
+    else if (c == '/') v = 63;
+    else if (c == '=') { pad++; continue; }
+    else if (c == ' ' || c == '\n' || c == '\r' || c == '\t') continue;
+    else return false;
+    if (pad) return false;  // data after padding
+    acc = (acc << 6) | (uint32_t)v;
+    bits += 6;
+    if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+  }
+  return pad <= 2;
+}
+std::string b64_encode(const uint8_t* p, size_t n) {
+  static const char tab[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+  std::string s;
+  for (size_t i = 0; i < n; i += 3) {
+    uint32_t v = (uint32_t)p[i] << 16 | (i + 1 < n ? (uint32_t)p[i + 1] << 8 : 0) | (i + 2 < n ? p[i + 2] : 0);
+    s += tab[v >> 18]; s += tab[(v >> 12) & 63];
+    s += i + 1 < n ? tab[(v >> 6) & 63] : '=';
+    s += i + 2 < n ? tab[v & 63] : '=';
+  }
+  return s;
+}
+bool hex_decode(const char* s, size_t n, Bytes& out) {
+  int hi = -1;
+  for (size_t i = 0; i < n; i++) {
+    const char c = s[i];
+    int v;
+    if (c >= '0' && c <= '9') v = c - '0';
+    else if (c >= 'a' && c <= 'f') v = c - 'a' + 10;
+    else if (c >= 'A' && c <= 'F') v = c - 'A' + 10;
+    else if (c == ' ' || c == '\n' || c == '\r' || c == '\t') continue;
+    else return false;
+    if (hi < 0) hi = v; else { out.push_back((uint8_t)(hi << 4 | v)); hi = -1; }
+  }
+  return hi < 0;
+}
+
+// ---------------------------------------------------------------- big unsigned integers (RSA public operations)
+struct Big {
+  std::vector<uint32_t> w;  // little-endian limbs, no leading zeros
+  void trim() { while (!w.empty() && w.back() == 0) w.pop_back(); }
+  static Big from_bytes(const uint8_t* p, size_t n) {  // big-endian
+    Big b;
+    b.w.assign((n + 3) / 4, 0);
+    for (size_t i = 0; i < n; i++) b.w[(n - 1 - i) / 4] |= (uint32_t)p[i] << (8 * ((n - 1 - i) % 4));
+    b.trim();
+    return b;
+  }
+  Bytes to_bytes(size_t n) const {  // big-endian, left-padded to n
+    Bytes out(n, 0);
+    for (size_t i = 0; i < n && i / 4 < w.size(); i++) out[n - 1 - i] = (uint8_t)(w[i / 4] >> (8 * (i % 4)));
+    return out;
+  }
+  size_t bits() const {
+    if (w.empty()) return 0;
+    size_t b = 32 * (w.size() - 1);
+    for (uint32_t t = w.back(); t; t >>= 1) b++;
+    return b;
+  }
+  bool bit(size_t i) const { return i / 32 < w.size() && ((w[i / 32] >> (i % 32)) & 1u); }
+  std::string decimal() const {
+    if (w.empty()) return "0";
+    std::vector<uint32_t> t = w;
+    std::string s;
+    while (!t.empty()) {
+      uint64_t rem = 0;
+      for (size_t i = t.size(); i-- > 0;) {
+        uint64_t cur = (rem << 32) | t[i];
+        t[i] = (uint32_t)(cur / 1000000000u);
+        rem = cur % 1000000000u;
+      }
+      while (!t.empty() && t.back() == 0) t.pop_back();
+      char tmp[16];
+      snprintf(tmp, sizeof tmp, t.empty() ? "%u" : "%09u", (unsigned)rem);
+      s.insert(0, tmp);
+    }
+    return s;
+  }
+};
+int cmp(const Big& a, const Big& b) {
+  if (a.w.size() != b.w.size()) return a.w.size() < b.w.size() ? -1 : 1;
+  for (size_t i = a.w.size(); i-- > 0;)
+    if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1;
+  return 0;
+}
+// Montgomery arithmetic modulo an odd n of k limbs (CIOS): what the guest's BigUint::modpow does, 2048 bits at a time
+struct Mont {
+  std::vector<uint32_t> n;
+  uint32_t n0inv;             // -n^-1 mod 2^32
+  std::vector<uint32_t> r2;   // R^2 mod n, R = 2^(32k)
+  explicit Mont(const Big& mod) : n(mod.w) {
+    uint32_t inv = 1;
+    for (int i = 0; i < 5; i++) inv *= 2 - n[0] * inv;  // Newton: n^-1 mod 2^32
+    n0inv = 0u - inv;
+    const size_t k = n.size();
+    // R^2 mod n by 64k doublings of 1 (mod n)
+    std::vector<uint32_t> x(k, 0);
+    x[0] = 1;
+    for (size_t i = 0; i < 64 * k; i++) {
+      uint32_t carry = 0;
+      for (size_t j = 0; j < k; j++) { uint32_t nc = x[j] >> 31; x[j] = (x[j] << 1) | carry; carry = nc; }
+      if (carry || geq(x)) sub(x);
+    }
+    r2 = x;
+  }
+  bool geq(const std::vector<uint32_t>& x) const {
+    for (size_t i = n.size(); i-- > 0;)
+      if (x[i] != n[i]) return x[i] > n[i];
+    return true;
+  }
+  void sub(std::vector<uint32_t>& x) const {
+    uint64_t borrow = 0;
+    for (size_t i = 0; i < n.size(); i++) { uint64_t d = (uint64_t)x[i] - n[i] - borrow; x[i] = (uint32_t)d; borrow = (d >> 63) & 1; }
+  }
+  std::vector<uint32_t> mul(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) const {
+    const size_t k = n.size();
+    std::vector<uint32_t> t(k + 2, 0);
+    for (size_t i = 0; i < k; i++) {
+      uint64_t c = 0;
+      for (size_t j = 0; j < k; j++) { uint64_t v = (uint64_t)a[i] * b[j] + t[j] + c; t[j] = (uint32_t)v; c = v >> 32; }
+      uint64_t v = (uint64_t)t[k] + c;
+      t[k] = (uint32_t)v;
+      t[k + 1] = (uint32_t)(v >> 32);
+      const uint32_t m = t[0] * n0inv;
+      c = ((uint64_t)m * n[0] + t[0]) >> 32;
+      for (size_t j = 1; j < k; j++) { uint64_t u = (uint64_t)m * n[j] + t[j] + c; t[j - 1] = (uint32_t)u; c = u >> 32; }
+      v = (uint64_t)t[k] + c;
+      t[k - 1] = (uint32_t)v;
+      t[k] = t[k + 1] + (uint32_t)(v >> 32);
+    }
+    std::vector<uint32_t> r(t.begin(), t.begin() + k);
+    if (t[k] || geq(r)) sub(r);
+    return r;
+  }
+  Big pow(const Big& base, const Big& e) const {
+    const size_t k = n.size();
+    std::vector<uint32_t> b(k, 0), one(k, 0);
+    std::copy(base.w.begin(), base.w.end(), b.begin());
+    one[0] = 1;
+    std::vector<uint32_t> bm = mul(b, r2), acc = mul(one, r2);
+    for (size_t i = e.bits(); i-- > 0;) {
+      acc = mul(acc, acc);
+      if (e.bit(i)) acc = mul(acc, bm);
+    }
+    Big out;
+    out.w = mul(acc, one);
+    out.trim();
+    return out;
+  }
+};
+
+// ---------------------------------------------------------------- DER: SubjectPublicKeyInfo of an RSA key
+struct Der {
+  const uint8_t* p; size_t n, pos = 0;
+  bool tlv(uint8_t tag, const uint8_t** body, size_t* len) {
+    if (pos + 2 > n || p[pos] != tag) return false;
+    size_t l = p[pos + 1];
+    pos += 2;
+    if (l & 0x80) {
+      const size_t nb = l & 0x7f;
+      if (nb == 0 || nb > 4 || pos + nb > n) return false;
+      l = 0;
+      for (size_t i = 0; i < nb; i++) l = (l << 8) | p[pos + i];
+      pos += nb;
+    }
+    if (pos + l > n) return false;
+    *body = p + pos; *len = l;
+    pos += l;
+    return true;
+  }
+};
+struct RsaPub { Big n, e; size_t bytes = 0; };
+const char* parse_rsa_pub_pem(const char* pem, size_t len, RsaPub& key) {
+  std::string text(pem, len);
+  const size_t a = text.find("-----BEGIN PUBLIC KEY-----"), b = text.find("-----END PUBLIC KEY-----");
+  R0H_REQUIRE(a != std::string::npos && b != std::string::npos && b > a, "RSA public key: no PEM \"PUBLIC KEY\" block (SubjectPublicKeyInfo)");
+  Bytes der;
+  R0H_REQUIRE(b64_decode(text.data() + a + 26, b - a - 26, der), "RSA public key: bad base64 in the PEM body");
+  Der d{der.data(), der.size()};
+  const uint8_t* body; size_t l;
+  R0H_REQUIRE(d.tlv(0x30, &body, &l), "RSA public key: DER does not start with a SEQUENCE");
+  Der spki{body, l};
+  const uint8_t* alg; size_t al;
+  R0H_REQUIRE(spki.tlv(0x30, &alg, &al), "RSA public key: no AlgorithmIdentifier");
+  static const uint8_t rsa_oid[] = {0x06, 0x09, 0x2a, 0x86, 0x48, 0x86, 0xf7, 0x0d, 0x01, 0x01, 0x01};
+  R0H_REQUIRE(al >= sizeof rsa_oid && memcmp(alg, rsa_oid, sizeof rsa_oid) == 0, "RSA public key: algorithm is not rsaEncryption");
+  const uint8_t* bits; size_t bl;
+  R0H_REQUIRE(spki.tlv(0x03, &bits, &bl) && bl > 1 && bits[0] == 0, "RSA public key: no BIT STRING");
+  Der inner{bits + 1, bl - 1};
+  const uint8_t* seq; size_t sl;
+  R0H_REQUIRE(inner.tlv(0x30, &seq, &sl), "RSA public key: no RSAPublicKey SEQUENCE");
+  Der rk{seq, sl};
+  const uint8_t *np, *ep; size_t nl, el;
+  R0H_REQUIRE(rk.tlv(0x02, &np, &nl) && rk.tlv(0x02, &ep, &el), "RSA public key: modulus / exponent missing");
+  key.n = Big::from_bytes(np, nl);
+  key.e = Big::from_bytes(ep, el);
+  key.bytes = (key.n.bits() + 7) / 8;
+  R0H_REQUIRE(key.n.bits() >= 512 && (key.n.w[0] & 1) && !key.e.w.empty(), "RSA public key: implausible modulus / exponent");
+  return nullptr;
+}
+// RSASSA-PKCS1-v1_5 with SHA-256: sig^e mod n == 00 01 FF.. 00 DigestInfo || digest
+bool pkcs1_sha256_verify(const RsaPub& key, const Bytes& sig, const uint8_t digest[32]) {
+  if (sig.size() != key.bytes) return false;
+  const Big s = Big::from_bytes(sig.data(), sig.size());
+  if (cmp(s, key.n) >= 0) return false;
+  const Bytes em = Mont(key.n).pow(s, key.e).to_bytes(key.bytes);
+  static const uint8_t info[] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, 0x01, 0x05, 0x00, 0x04, 0x20};
+  const size_t tlen = sizeof info + 32;
+  if (em.size() < tlen + 11 || em[0] != 0 || em[1] != 1) return false;
+  const size_t ps_end = em.size() - tlen - 1;
+  for (size_t i = 2; i < ps_end; i++)
+    if (em[i] != 0xff) return false;
+  return em[ps_end] == 0 && memcmp(&em[ps_end + 1], info, sizeof info) == 0 && memcmp(&em[ps_end + 1 + sizeof info], digest, 32) == 0;
+}
+
+// ---------------------------------------------------------------- AES-128 (FIPS 197), decryption direction, CBC
+struct Aes128 {
+  uint8_t sbox[256], inv[256], rk[176];
+  static uint8_t xt(uint8_t x) { return (uint8_t)((x << 1) ^ ((x >> 7) * 0x1b)); }
+  static uint8_t gmul(uint8_t a, uint8_t b) {
+    uint8_t r = 0;
+    for (int i = 0; i < 8; i++) { if (b & 1) r ^= a; a = xt(a); b >>= 1; }
+    return r;
+  }
+  explicit Aes128(const uint8_t key[16]) {
+    // S-box from the field inverse and the affine map, not from a pasted table
+    uint8_t p = 1, q = 1;
+    do {
+      p = (uint8_t)(p ^ (p << 1) ^ ((p & 0x80) ? 0x1b : 0));
+      q ^= (uint8_t)(q << 1); q ^= (uint8_t)(q << 2); q ^= (uint8_t)(q << 4);
+      if (q & 0x80) q ^= 0x09;
+      const uint8_t x = (uint8_t)(q ^ (uint8_t)((q << 1) | (q >> 7)) ^ (uint8_t)((q << 2) | (q >> 6)) ^ (uint8_t)((q << 3) | (q >> 5)) ^ (uint8_t)((q << 4) | (q >> 4)));
+      sbox[p] = (uint8_t)(x ^ 0x63);
+    } while (p != 1);
+    sbox[0] = 0x63;
+    for (int i = 0; i < 256; i++) inv[sbox[i]] = (uint8_t)i;
+    memcpy(rk, key, 16);
+    uint8_t rcon = 1;
+    for (int i = 16; i < 176; i += 4) {
+      uint8_t t[4] = {rk[i - 4], rk[i - 3], rk[i - 2], rk[i - 1]};
+      if (i % 16 == 0) {
+        const uint8_t t0 = t[0];
+        t[0] = (uint8_t)(sbox[t[1]] ^ rcon); t[1] = sbox[t[2]]; t[2] = sbox[t[3]]; t[3] = sbox[t0];
+        rcon = xt(rcon);
+      }
+      for (int j = 0; j < 4; j++) rk[i + j] = (uint8_t)(rk[i - 16 + j] ^ t[j]);
+    }
+  }
+  void decrypt_block(const uint8_t in[16], uint8_t out[16]) const {
+    uint8_t s[16];
+    for (int i = 0; i < 16; i++) s[i] = (uint8_t)(in[i] ^ rk[160 + i]);
+    for (int round = 9; round >= 0; round--) {
+      uint8_t t[16];
+      for (int c = 0; c < 4; c++)  // InvShiftRows + InvSubBytes
+        for (int r = 0; r < 4; r++) t[4 * ((c + r) % 4) + r] = inv[s[4 * c + r]];
+      for (int i = 0; i < 16; i++) t[i] ^= rk[16 * round + i];
+      if (round == 0) { memcpy(s, t, 16); break; }
+      for (int c = 0; c < 4; c++) {  // InvMixColumns
+        const uint8_t a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+        s[4 * c] = (uint8_t)(gmul(a0, 14) ^ gmul(a1, 11) ^ gmul(a2, 13) ^ gmul(a3, 9));
+        s[4 * c + 1] = (uint8_t)(gmul(a0, 9) ^ gmul(a1, 14) ^ gmul(a2, 11) ^ gmul(a3, 13));
+        s[4 * c + 2] = (uint8_t)(gmul(a0, 13) ^ gmul(a1, 9) ^ gmul(a2, 14) ^ gmul(a3, 11));
+        s[4 * c + 3] = (uint8_t)(gmul(a0, 11) ^ gmul(a1, 13) ^ gmul(a2, 9) ^ gmul(a3, 14));
+      }
+    }
+    memcpy(out, s, 16);
+  }
+  void encrypt_block(const uint8_t in[16], uint8_t out[16]) const {  // for the FIPS-197 known-answer test
+    uint8_t s[16];
+    for (int i = 0; i < 16; i++) s[i] = (uint8_t)(in[i] ^ rk[i]);
+    for (int round = 1; round <= 10; round++) {
+      uint8_t t[16];
+      for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) t[4 * c + r] = sbox[s[4 * ((c + r) % 4) + r]];
+      if (round < 10) {
+        for (int c = 0; c < 4; c++) {
+          const uint8_t a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+          s[4 * c] = (uint8_t)(xt(a0) ^ (xt(a1) ^ a1) ^ a2 ^ a3);
+          s[4 * c + 1] = (uint8_t)(a0 ^ xt(a1) ^ (xt(a2) ^ a2) ^ a3);
+          s[4 * c + 2] = (uint8_t)(a0 ^ a1 ^ xt(a2) ^ (xt(a3) ^ a3));
+          s[4 * c + 3] = (uint8_t)((xt(a0) ^ a0) ^ a1 ^ a2 ^ xt(a3));
+        }
+      } else {
+        memcpy(s, t, 16);
+      }
+      for (int i = 0; i < 16; i++) s[i] ^= rk[16 * round + i];
+    }
+    memcpy(out, s, 16);
+  }
+};
+
+// ---------------------------------------------------------------- inflate (RFC 1951) under zlib framing (RFC 1950)
+struct Inflate {
+  const uint8_t* in; size_t n, pos = 0;
+  uint32_t bitbuf = 0; int bitcnt = 0;
+  Bytes& out;
+  const char* err = nullptr;
+  Inflate(const uint8_t* p, size_t len, Bytes& o) : in(p), n(len), out(o) {}
+  int bits(int need) {
+    uint32_t v = bitbuf;
+    while (bitcnt < need) {
+      if (pos >= n) { err = "inflate: input ends inside a block"; return 0; }
+      v |= (uint32_t)in[pos++] << bitcnt;
+      bitcnt += 8;
+    }
+    bitbuf = need < 32 ? v >> need : 0;
+    bitcnt -= need;
+    return (int)(v & ((1u << need) - 1));
+  }
+  struct Huff { uint16_t count[16]; uint16_t symbol[288]; };
+  static bool build(Huff& h, const uint8_t* len, int n_sym) {
+    memset(h.count, 0, sizeof h.count);
+    for (int s = 0; s < n_sym; s++) h.count[len[s]]++;
+    int left = 1;
+    for (int l = 1; l < 16; l++) { left = (left << 1) - h.count[l]; if (left < 0) return false; }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + h.count[l]);
+    for (int s = 0; s < n_sym; s++)
+      if (len[s]) h.symbol[offs[len[s]]++] = (uint16_t)s;
+    return true;
+  }
+  int decode(const Huff& h) {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l < 16; l++) {
+      code |= bits(1);
+      if (err) return -1;
+      const int count = h.count[l];
+      if (code - count < first) return h.symbol[index + (code - first)];
+      index += count; first += count; first <<= 1; code <<= 1;
+    }
+    err = "inflate: invalid Huffman code";
+    return -1;
+  }
+  bool codes(const Huff& lit, const Huff& dist) {
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (;;) {
+      int sym = decode(lit);
+      if (err) return false;
+      if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+      if (sym == 256) return true;
+      sym -= 257;
+      if (sym >= 29) { err = "inflate: invalid length symbol"; return false; }
+      const int len = lbase[sym] + bits(lext[sym]);
+      const int ds = decode(dist);
+      if (err) return false;
+      if (ds >= 30) { err = "inflate: invalid distance symbol"; return false; }
+      const size_t d = dbase[ds] + (size_t)bits(dext[ds]);
+      if (err) return false;
+      if (d > out.size()) { err = "inflate: distance reaches before the start of the output"; return false; }
+      if (out.size() + (size_t)len > ((size_t)1 << 30)) { err = "inflate: output exceeds 1 GiB"; return false; }
+      for (int i = 0; i < len; i++) out.push_back(out[out.size() - d]);
+    }
+  }
+  bool run() {  // raw deflate stream
+    int last;
+    do {
+      last = bits(1);
+      const int type = bits(2);
+      if (err) return false;
+      if (type == 0) {
+        bitbuf = 0; bitcnt = 0;
+        if (pos + 4 > n) { err = "inflate: stored block header truncated"; return false; }
+        const unsigned len = in[pos] | in[pos + 1] << 8, nlen = in[pos + 2] | in[pos + 3] << 8;
+        pos += 4;
+        if ((len ^ 0xffff) != nlen || pos + len > n) { err = "inflate: bad stored block"; return false; }
+        out.insert(out.end(), in + pos, in + pos + len);
+        pos += len;
+      } else if (type == 1) {
+        uint8_t l[288];
+        for (int i = 0; i < 144; i++) l[i] = 8;
+        for (int i = 144; i < 256; i++) l[i] = 9;
+        for (int i = 256; i < 280; i++) l[i] = 7;
+        for (int i = 280; i < 288; i++) l[i] = 8;
+        Huff lit, dist;
+        build(lit, l, 288);
+        uint8_t dl[30];
+        memset(dl, 5, sizeof dl);
+        build(dist, dl, 30);
+        if (!codes(lit, dist)) return false;
+      } else if (type == 2) {
+        const int nlen = bits(5) + 257, ndist = bits(5) + 1, ncode = bits(4) + 4;
+        if (err || nlen > 286 || ndist > 30) { if (!err) err = "inflate: bad code counts"; return false; }
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        uint8_t lengths[320];
+        memset(lengths, 0, sizeof lengths);
+        for (int i = 0; i < ncode; i++) lengths[order[i]] = (uint8_t)bits(3);
+        if (err) return false;
+        Huff cl;
+        if (!build(cl, lengths, 19)) { err = "inflate: over-subscribed code-length code"; return false; }
+        uint8_t ll[320];
+        memset(ll, 0, sizeof ll);
+        for (int i = 0; i < nlen + ndist;) {
+          int sym = decode(cl);
+          if (err) return false;
+          if (sym < 16) { ll[i++] = (uint8_t)sym; continue; }
+          int prev = 0, rep;
+          if (sym == 16) { if (i == 0) { err = "inflate: repeat with no previous length"; return false; } prev = ll[i - 1]; rep = 3 + bits(2); }
+          else if (sym == 17) rep = 3 + bits(3);
+          else rep = 11 + bits(7);
+          if (err || i + rep > nlen + ndist) { if (!err) err = "inflate: too many code lengths"; return false; }
+          while (rep--) ll[i++] = (uint8_t)prev;
+        }
+        if (ll[256] == 0) { err = "inflate: no end-of-block code"; return false; }
+        Huff lit, dist;
+        if (!build(lit, ll, nlen) || !build(dist, ll + nlen, ndist)) { err = "inflate: over-subscribed code"; return false; }
+        if (!codes(lit, dist)) return false;
+      } else {
+        err = "inflate: reserved block type";
+        return false;
+      }
+    } while (!last);
+    return true;
+  }
+};
+uint32_t adler32(const Bytes& d) {
+  uint32_t a = 1, b = 0;
+  for (uint8_t c : d) { a = (a + c) % 65521; b = (b + a) % 65521; }
+  return (b << 16) | a;
+}
+uint32_t crc32(const uint8_t* p, size_t n) {
+  uint32_t c = 0xffffffffu;
+  for (size_t i = 0; i < n; i++) {
+    c ^= p[i];
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1)));
+  }
+  return ~c;
+}
+// zlib stream; bytes after the end of the stream (the AES padding) are ignored, as zlib-flate does
+const char* zlib_inflate(const uint8_t* p, size_t n, Bytes& out) {
+  R0H_REQUIRE(n >= 6 && (p[0] & 0x0f) == 8 && ((p[0] << 8 | p[1]) % 31) == 0 && !(p[1] & 0x20), "zlib: not a deflate stream header (wrong transaction key?)");
+  Inflate inf(p + 2, n - 2, out);
+  R0H_REQUIRE(inf.run(), "%s", inf.err ? inf.err : "inflate failed");
+  size_t at = 2 + inf.pos;
+  R0H_REQUIRE(at + 4 <= n, "zlib: checksum missing");
+  const uint32_t want = (uint32_t)p[at] << 24 | (uint32_t)p[at + 1] << 16 | (uint32_t)p[at + 2] << 8 | p[at + 3];
+  R0H_REQUIRE(adler32(out) == want, "zlib: Adler-32 mismatch");
+  return nullptr;
+}
+
+// ---------------------------------------------------------------- a small XML reader for the canonicalisation
+struct XmlNode {
+  bool is_text = false;
+  std::string name, text;  // text already un-escaped
+  std::vector<std::pair<std::string, std::string>> attrs;
+  std::vector<XmlNode> kids;
+};
+struct XmlParser {
+  const char* p; const char* end; const char* err = nullptr;
+  static void append_utf8(std::string& s, uint32_t v) {
+    if (v < 0x80) s += (char)v;
+    else if (v < 0x800) { s += (char)(0xC0 | v >> 6); s += (char)(0x80 | (v & 63)); }
+    else if (v < 0x10000) { s += (char)(0xE0 | v >> 12); s += (char)(0x80 | ((v >> 6) & 63)); s += (char)(0x80 | (v & 63)); }
+    else { s += (char)(0xF0 | v >> 18); s += (char)(0x80 | ((v >> 12) & 63)); s += (char)(0x80 | ((v >> 6) & 63)); s += (char)(0x80 | (v & 63)); }
+  }
+  bool unescape(const char* a, const char* b, std::string& out) {
+    while (a < b) {
+      if (*a == '\r') {  // line ends of the literal text: CRLF and CR read as LF (a carriage return written as &#13; stays one)
+        out += '\n';
+        a += (a + 1 < b && a[1] == '\n') ? 2 : 1;
+        continue;
+      }
+      if (*a != '&') { out += *a++; continue; }
+      const char* semi = (const char*)memchr(a, ';', (size_t)(b - a));
+      if (!semi) { err = "XML: '&' without ';'"; return false; }
+      const std::string ent(a + 1, semi);
+      if (ent == "amp") out += '&';
+      else if (ent == "lt") out += '<';
+      else if (ent == "gt") out += '>';
+      else if (ent == "quot") out += '"';
+      else if (ent == "apos") out += '\'';
+      else if (ent.size() > 1 && ent[0] == '#') {
+        const uint32_t v = (uint32_t)strtoul(ent.c_str() + (ent[1] == 'x' ? 2 : 1), nullptr, ent[1] == 'x' ? 16 : 10);
+        if (!v || v > 0x10ffff) { err = "XML: bad character reference"; return false; }
+        append_utf8(out, v);
+      } else { err = "XML: unknown entity"; return false; }
+      a = semi + 1;
+    }
+    return true;
+  }
+  static bool name_char(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == ':' || c == '_' || c == '-' || c == '.' || (unsigned char)c >= 0x80; }
+  void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+  bool element(XmlNode& node, int depth) {
+    if (depth > 64) { err = "XML: nesting too deep"; return false; }
+    if (p >= end || *p != '<') { err = "XML: expected '<'"; return false; }
+    p++;
+    const char* s = p;
+    while (p < end && name_char(*p)) p++;
+    if (p == s) { err = "XML: missing element name"; return false; }
+    node.name.assign(s, p);
+    for (;;) {
+      ws();
+      if (p >= end) { err = "XML: unterminated start tag"; return false; }
+      if (*p == '>') { p++; break; }
+      if (*p == '/') {
+        if (p + 1 >= end || p[1] != '>') { err = "XML: stray '/'"; return false; }
+        p += 2;
+        return true;  // empty element
+      }
+      const char* a = p;
+      while (p < end && name_char(*p)) p++;
+      if (p == a) { err = "XML: bad attribute"; return false; }
+      std::string an(a, p);
+      ws();
+      if (p >= end || *p != '=') { err = "XML: attribute without '='"; return false; }
+      p++;
+      ws();
+      if (p >= end || (*p != '"' && *p != '\'')) { err = "XML: attribute value not quoted"; return false; }
+      const char q = *p++;
+      const char* v = p;
+      while (p < end && *p != q) p++;
+      if (p >= end) { err = "XML: unterminated attribute value"; return false; }
+      std::string val;
+      if (!unescape(v, p, val)) return false;
+      for (char& c : val)
+        if (c == '\t' || c == '\n' || c == '\r') c = ' ';  // attribute-value normalisation (non-reference whitespace)
+      p++;
+      node.attrs.emplace_back(an, val);
+    }
+    for (;;) {  // content
+      if (p >= end) { err = "XML: unterminated element"; return false; }
+      if (*p != '<') {
+        const char* t = p;
+        while (p < end && *p != '<') p++;
+        XmlNode tx;
+        tx.is_text = true;
+        if (!unescape(t, p, tx.text)) return false;
+        node.kids.push_back(std::move(tx));
+        continue;
+      }
+      if (end - p >= 4 && !memcmp(p, "<!--", 4)) {  // comments are dropped by canonicalisation without comments
+        static const char close_comment[] = "-->";
+        const char* e = std::search(p + 4, end, close_comment, close_comment + 3);
+        if (e == end) { err = "XML: unterminated comment"; return false; }
+        p = e + 3;
+        continue;
+      }
+      if (end - p >= 9 && !memcmp(p, "<![CDATA[", 9)) {
+        static const char close_cdata[] = "]]>";
+        const char* e = std::search(p + 9, end, close_cdata, close_cdata + 3);
+        if (e == end) { err = "XML: unterminated CDATA"; return false; }
+        XmlNode tx;
+        tx.is_text = true;
+        tx.text.assign(p + 9, e);
+        node.kids.push_back(std::move(tx));
+        p = e + 3;
+        continue;
+      }
+      if (end - p >= 2 && p[1] == '/') {
+        p += 2;
+        const char* c = p;
+        while (p < end && name_char(*p)) p++;
+        if (std::string(c, p) != node.name) { err = "XML: mismatched end tag"; return false; }
+        ws();
+        if (p >= end || *p != '>') { err = "XML: bad end tag"; return false; }
+        p++;
+        return true;
+      }
+      if (end - p >= 2 && (p[1] == '?' || p[1] == '!')) { err = "XML: processing instructions / DTD inside the signed parts are not supported"; return false; }
+      XmlNode kid;
+      if (!element(kid, depth + 1)) return false;
+      node.kids.push_back(std::move(kid));
+    }
+  }
+};
+void c14n_text(std::string& out, const std::string& t) {
+  for (char c : t) {
+    if (c == '&') out += "&amp;";
+    else if (c == '<') out += "&lt;";
+    else if (c == '>') out += "&gt;";
+    else if (c == '\r') out += "&#xD;";
+    else out += c;
+  }
+}
+void c14n_attr(std::string& out, const std::string& t) {
+  for (char c : t) {
+    if (c == '&') out += "&amp;";
+    else if (c == '<') out += "&lt;";
+    else if (c == '"') out += "&quot;";
+    else if (c == '\t') out += "&#x9;";
+    else if (c == '\n') out += "&#xA;";
+    else if (c == '\r') out += "&#xD;";
+    else out += c;
+  }
+}
+// `top_ns`: namespace declarations written on the top element only (already in canonical order: default first, then by prefix)
+void c14n(std::string& out, const XmlNode& n, const std::string& top_ns) {
+  if (n.is_text) { c14n_text(out, n.text); return; }
+  out += '<';
+  out += n.name;
+  out += top_ns;
+  std::vector<std::pair<std::string, std::string>> ns, at;
+  for (const auto& a : n.attrs) (a.first == "xmlns" || a.first.compare(0, 6, "xmlns:") == 0 ? ns : at).push_back(a);
+  std::sort(ns.begin(), ns.end());
+  // attributes sort by (namespace URI, local name); the documents here carry unprefixed attributes only, where that is the name
+  std::sort(at.begin(), at.end());
+  for (const auto& a : ns) { out += ' '; out += a.first; out += "=\""; c14n_attr(out, a.second); out += '"'; }
+  for (const auto& a : at) { out += ' '; out += a.first; out += "=\""; c14n_attr(out, a.second); out += '"'; }
+  out += '>';
+  for (const XmlNode& k : n.kids) c14n(out, k, std::string());
+  out += "</";
+  out += n.name;
+  out += '>';
+}
+
+// perl -ne 'print $1 if /(<TAG.*<\/TAG>)/': first "<TAG" to the LAST "</TAG>" of the line; the responses are one line
+bool cut_greedy(const std::string& xml, const std::string& open, const std::string& close, std::string& out) {
+  const size_t a = xml.find(open), b = xml.rfind(close);
+  if (a == std::string::npos || b == std::string::npos || b < a) return false;
+  out = xml.substr(a, b + close.size() - a);
+  return true;
+}
+bool element_text(const std::string& xml, const std::string& tag, std::string& out) {
+  const std::string open = "<" + tag + ">", close = "</" + tag + ">";
+  const size_t a = xml.find(open);
+  if (a == std::string::npos) return false;
+  const size_t b = xml.find(close, a);
+  if (b == std::string::npos) return false;
+  out = xml.substr(a + open.size(), b - a - open.size());
+  return true;
+}
+std::string strip(const std::string& s, const char* what) {
+  std::string r;
+  const size_t wl = strlen(what);
+  for (size_t i = 0; i < s.size();) {
+    if (wl && s.compare(i, wl, what) == 0) { i += wl; continue; }
+    if (s[i] == '\n') { i++; continue; }
+    r += s[i++];
+  }
+  return r;
+}
+
+}  // namespace
+
+struct r0h_ebics {
+  std::string authenticated, signed_info, signature_value, order_data, digest_value, ns;
+  Bytes signature, transaction_key, order_data_bin, payload;
+  struct Doc { std::string name; Bytes data; };
+  std::vector<Doc> docs;
+};
+
+namespace {
+const char* canonical_part(const std::string& xml, const char* tag, const char* open, const std::string& inject, bool optional, std::string& out) {
+  std::string snippet;
+  if (!cut_greedy(xml, open, std::string("</") + tag + ">", snippet)) {
+    R0H_REQUIRE(optional, "EBICS response: no <%s> element", tag);
+    return nullptr;
+  }
+  XmlParser ps{snippet.data(), snippet.data() + snippet.size()};
+  XmlNode node;
+  R0H_REQUIRE(ps.element(node, 0), "EBICS response: <%s>: %s", tag, ps.err ? ps.err : "parse error");
+  c14n(out, node, inject);
+  return nullptr;
+}
+}  // namespace
+
+using namespace r0h;
+
+extern "C" {
+
+const char* r0h_ebics_parse(const char* xml_p, size_t n, r0h_ebics** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(xml_p && out, "r0h_ebics_parse: NULL argument");
+  const std::string xml(xml_p, n);
+  std::unique_ptr<r0h_ebics> e(new r0h_ebics);
+  // data/checkResponse.sh:133-149: the namespace of the response, H003 or H004 in either spelling
+  for (const char* cand : {"http://www.ebics.org/H003", "http://www.ebics.org/H004", "urn:org:ebics:H003", "urn:org:ebics:H004"})
+    if (xml.find(std::string("xmlns=\"") + cand + "\"") != std::string::npos) { e->ns = cand; break; }
+  R0H_REQUIRE(!e->ns.empty(), "EBICS response: no xmlns=\"…ebics…H003|H004\" declaration (checkResponse.sh exits 34)");
+  const bool h004 = e->ns.find("H004") != std::string::npos;
+  std::string inject = " xmlns=\"" + e->ns + "\"";
+  if (h004) inject += " xmlns:ds=\"http://www.w3.org/2000/09/xmldsig#\"";
+  // :151-155 the authenticated parts in document order, each canonicalised on its own with the inherited namespaces put back
+  R0H_TRY(canonical_part(xml, "header", "<header", inject, false, e->authenticated));
+  R0H_TRY(canonical_part(xml, "DataEncryptionInfo", "<DataEncryptionInfo", inject, false, e->authenticated));
+  R0H_TRY(canonical_part(xml, "ReturnCode", "<ReturnCode auth", inject, false, e->authenticated));
+  R0H_TRY(canonical_part(xml, "TimestampBankParameter", "<TimestampBankParameter", inject, true, e->authenticated));
+  // :192 SignedInfo: default namespace of the response first, then the ds prefix it uses
+  R0H_TRY(canonical_part(xml, "ds:SignedInfo", "<ds:SignedInfo", " xmlns=\"" + e->ns + "\" xmlns:ds=\"http://www.w3.org/2000/09/xmldsig#\"", false, e->signed_info));
+  // :200 SignatureValue element with its tags, "&#13;" and newlines removed; :221 OrderData element as it stands
+  {
+    const size_t a = xml.find("<ds:SignatureValue>");
+    const size_t b = a == std::string::npos ? a : xml.find("</ds:SignatureValue>", a);
+    R0H_REQUIRE(b != std::string::npos, "EBICS response: no <ds:SignatureValue>");
+    e->signature_value = strip(xml.substr(a, b + 20 - a), "&#13;");
+    R0H_REQUIRE(e->signature_value.size() > 39, "EBICS response: empty SignatureValue (checkResponse.sh exits 19)");
+    const std::string body = e->signature_value.substr(19, e->signature_value.size() - 39);
+    R0H_REQUIRE(b64_decode(body.data(), body.size(), e->signature), "EBICS response: SignatureValue is not base64");
+  }
+  R0H_REQUIRE(cut_greedy(xml, "<OrderData", "</OrderData>", e->order_data), "EBICS response: no <OrderData>");
+  std::string t;
+  R0H_REQUIRE(element_text(xml, "ds:DigestValue", t), "EBICS response: no <ds:DigestValue>");
+  e->digest_value = strip(t, "");
+  R0H_REQUIRE(element_text(xml, "TransactionKey", t) && b64_decode(t.data(), t.size(), e->transaction_key), "EBICS response: no base64 <TransactionKey>");
+  R0H_REQUIRE(element_text(xml, "OrderData", t) && b64_decode(t.data(), t.size(), e->order_data_bin), "EBICS response: <OrderData> is not base64");
+  *out = e.release();
+  return nullptr;
+  R0H_GUARD_END
+}
+
+const char* r0h_ebics_free(r0h_ebics* e) {
+  delete e;
+  return nullptr;
+}
+
+const char* r0h_ebics_part(const r0h_ebics* e, int which, const uint8_t** p, size_t* n) {
+  R0H_REQUIRE(e && p && n, "r0h_ebics_part: NULL argument");
+  auto str = [&](const std::string& s) { *p = (const uint8_t*)s.data(); *n = s.size(); };
+  auto bin = [&](const Bytes& b) { *p = b.data(); *n = b.size(); };
+  switch (which) {
+    case R0H_EBICS_AUTHENTICATED: str(e->authenticated); break;
+    case R0H_EBICS_SIGNED_INFO: str(e->signed_info); break;
+    case R0H_EBICS_SIGNATURE_VALUE: str(e->signature_value); break;
+    case R0H_EBICS_ORDER_DATA: str(e->order_data); break;
+    case R0H_EBICS_DIGEST_VALUE: str(e->digest_value); break;
+    case R0H_EBICS_SIGNATURE_BIN: bin(e->signature); break;
+    case R0H_EBICS_TRANSACTION_KEY_BIN: bin(e->transaction_key); break;
+    case R0H_EBICS_ORDER_DATA_BIN: bin(e->order_data_bin); break;
+    case R0H_EBICS_PAYLOAD_ZIP: bin(e->payload); break;
+    default: return make_error("r0h_ebics_part: unknown part %d", which);
+  }
+  return nullptr;
+}
+
+// data/checkResponse.sh:117-175 (the guest repeats it: methods/guest/src/main.rs:558-564)
+const char* r0h_ebics_check_digest(const r0h_ebics* e, int* ok) {
+  R0H_REQUIRE(e && ok, "r0h_ebics_check_digest: NULL argument");
+  uint8_t d[32];
+  sha256(e->authenticated.data(), e->authenticated.size(), d);
+  *ok = b64_encode(d, 32) == e->digest_value;
+  return nullptr;
+}
+
+// data/checkResponse.sh:192-212 (guest: methods/guest/src/main.rs:450-485)
+const char* r0h_ebics_verify_bank_signature(const r0h_ebics* e, const char* pub_bank_pem, size_t pem_len, int* ok) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && pub_bank_pem && ok, "r0h_ebics_verify_bank_signature: NULL argument");
+  RsaPub key;
+  R0H_TRY(parse_rsa_pub_pem(pub_bank_pem, pem_len, key));
+  uint8_t d[32];
+  sha256(e->signed_info.data(), e->signed_info.size(), d);
+  *ok = pkcs1_sha256_verify(key, e->signature, d);
+  return nullptr;
+  R0H_GUARD_END
+}
+
+// The decrypted transaction key arrives as the raw RSA block (checkResponse.sh:231-236 `rsa_padding_mode:none`): 00 02 PS 00 key16.
+// Re-encrypting it with the client's PUBLIC key must give <TransactionKey> (methods/guest/src/main.rs:663-718).
+const char* r0h_ebics_check_transaction_key(const r0h_ebics* e, const char* pub_client_pem, size_t pem_len, const uint8_t* raw_block, size_t raw_len, uint8_t key_out[16],
+                                            int* ok) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && pub_client_pem && raw_block && key_out && ok, "r0h_ebics_check_transaction_key: NULL argument");
+  RsaPub key;
+  R0H_TRY(parse_rsa_pub_pem(pub_client_pem, pem_len, key));
+  *ok = 0;
+  if (raw_len != key.bytes || e->transaction_key.size() != key.bytes) return nullptr;
+  size_t sep = 2;
+  while (sep < raw_len && raw_block[sep] != 0) sep++;
+  if (raw_block[0] != 0 || raw_block[1] != 2 || sep < 10 || raw_len - sep - 1 != 16) return nullptr;  // EME-PKCS1-v1_5: at least 8 padding bytes
+  const Big m = Big::from_bytes(raw_block, raw_len);
+  if (cmp(m, key.n) >= 0) return nullptr;
+  const Bytes c = Mont(key.n).pow(m, key.e).to_bytes(key.bytes);
+  if (c != e->transaction_key) return nullptr;
+  memcpy(key_out, raw_block + sep + 1, 16);
+  *ok = 1;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+// data/checkResponse.sh:261-286 (guest: methods/guest/src/main.rs:757-781): the witness signs SHA-256 of the decoded order data
+const char* r0h_ebics_verify_witness(const r0h_ebics* e, const char* pub_witness_pem, size_t pem_len, const char* witness_hex, size_t hex_len, int* ok) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && pub_witness_pem && witness_hex && ok, "r0h_ebics_verify_witness: NULL argument");
+  RsaPub key;
+  R0H_TRY(parse_rsa_pub_pem(pub_witness_pem, pem_len, key));
+  Bytes sig;
+  R0H_REQUIRE(hex_decode(witness_hex, hex_len, sig), "witness signature: not hexadecimal");
+  uint8_t d[32];
+  sha256(e->order_data_bin.data(), e->order_data_bin.size(), d);
+  *ok = pkcs1_sha256_verify(key, sig, d);
+  return nullptr;
+  R0H_GUARD_END
+}
+
+// data/checkResponse.sh:243-298 (guest: methods/guest/src/main.rs:792-833): AES-128-CBC with a zero IV and the padding left in,
+// RFC 1950 inflate (trailing padding ignored), then the ZIP container with the camt.053 documents
+const char* r0h_ebics_decrypt_order_data(r0h_ebics* e, const uint8_t key[16]) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && key, "r0h_ebics_decrypt_order_data: NULL argument");
+  const Bytes& ct = e->order_data_bin;
+  R0H_REQUIRE(!ct.empty() && ct.size() % 16 == 0, "order data: %zu bytes is not a whole number of AES blocks", ct.size());
+  const Aes128 aes(key);
+  Bytes pt(ct.size());
+  uint8_t prev[16] = {0};
+  for (size_t off = 0; off < ct.size(); off += 16) {
+    aes.decrypt_block(&ct[off], &pt[off]);
+    for (int i = 0; i < 16; i++) pt[off + i] ^= prev[i];
+    memcpy(prev, &ct[off], 16);
+  }
+  e->payload.clear();
+  e->docs.clear();
+  R0H_TRY(zlib_inflate(pt.data(), pt.size(), e->payload));
+  // ZIP: walk the local file headers (PK\3\4); stored or deflated members, CRC-32 checked
+  const Bytes& z = e->payload;
+  size_t at = 0;
+  while (at + 30 <= z.size() && z[at] == 'P' && z[at + 1] == 'K' && z[at + 2] == 3 && z[at + 3] == 4) {
+    auto u16 = [&](size_t o) { return (uint32_t)z[at + o] | (uint32_t)z[at + o + 1] << 8; };
+    auto u32 = [&](size_t o) { return u16(o) | u16(o + 2) << 16; };
+    const uint32_t flags = u16(6), method = u16(8), crc = u32(14), csize = u32(18), usize = u32(22), nlen = u16(26), xlen = u16(28);
+    R0H_REQUIRE(!(flags & 1), "zip: encrypted member");
+    R0H_REQUIRE(!(flags & 8), "zip: members with a trailing data descriptor are not supported");
+    const size_t data = at + 30 + nlen + xlen;
+    R0H_REQUIRE(data + csize <= z.size(), "zip: member runs past the end of the archive");
+    r0h_ebics::Doc doc;
+    doc.name.assign((const char*)&z[at + 30], nlen);
+    if (method == 0) {
+      doc.data.assign(z.begin() + data, z.begin() + data + csize);
+    } else {
+      R0H_REQUIRE(method == 8, "zip: compression method %u is not stored / deflate", method);
+      Inflate inf(&z[data], csize, doc.data);
+      R0H_REQUIRE(inf.run(), "zip member %s: %s", doc.name.c_str(), inf.err ? inf.err : "inflate failed");
+    }
+    R0H_REQUIRE(doc.data.size() == usize && crc32(doc.data.data(), doc.data.size()) == crc, "zip member %s: size / CRC-32 mismatch", doc.name.c_str());
+    e->docs.push_back(std::move(doc));
+    at = data + csize;
+  }
+  R0H_REQUIRE(!e->docs.empty(), "order data: the inflated payload is not a ZIP archive");
+  return nullptr;
+  R0H_GUARD_END
+}
+
+size_t r0h_ebics_n_documents(const r0h_ebics* e) { return e ? e->docs.size() : 0; }
+
+const char* r0h_ebics_document(const r0h_ebics* e, size_t i, const char** name, const uint8_t** data, size_t* n) {
+  R0H_REQUIRE(e && name && data && n, "r0h_ebics_document: NULL argument");
+  R0H_REQUIRE(i < e->docs.size(), "r0h_ebics_document: document %zu of %zu", i, e->docs.size());
+  *name = e->docs[i].name.c_str();
+  *data = e->docs[i].data.data();
+  *n = e->docs[i].data.size();
+  return nullptr;
+}
+
+// host/src/main.rs:383-387: the bank key goes to the guest as decimal strings of its modulus and exponent
+const char* r0h_rsa_public_key_decimal(const char* pem, size_t pem_len, char** modulus_out, char** exponent_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(pem && modulus_out && exponent_out, "r0h_rsa_public_key_decimal: NULL argument");
+  RsaPub key;
+  R0H_TRY(parse_rsa_pub_pem(pem, pem_len, key));
+  const std::string m = key.n.decimal(), x = key.e.decimal();
+  *modulus_out = (char*)malloc(m.size() + 1);
+  *exponent_out = (char*)malloc(x.size() + 1);
+  R0H_REQUIRE(*modulus_out && *exponent_out, "r0h_rsa_public_key_decimal: out of memory");
+  memcpy(*modulus_out, m.c_str(), m.size() + 1);
+  memcpy(*exponent_out, x.c_str(), x.size() + 1);
+  return nullptr;
+  R0H_GUARD_END
+}
+
+// host/src/main.rs:389-417: the thirteen inputs in the order the guest reads them (methods/guest/src/main.rs:159-171)
+const char* r0h_ebics_env_inputs(const r0h_ebics* e, const char* pub_bank_pem, size_t bank_len, const char* client_private_pem, size_t client_len,
+                                 const uint8_t* decrypted_tx_key, size_t tx_len, const char* iban, const char* host_info, const char* witness_hex,
+                                 size_t witness_len, const char* pub_witness_pem, size_t pub_witness_len, const char* verbose, r0h_env** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && pub_bank_pem && client_private_pem && decrypted_tx_key && iban && host_info && witness_hex && pub_witness_pem && verbose && out,
+              "r0h_ebics_env_inputs: NULL argument");
+  char *mod = nullptr, *exp = nullptr;
+  R0H_TRY(r0h_rsa_public_key_decimal(pub_bank_pem, bank_len, &mod, &exp));
+  r0h_env* env = nullptr;
+  const char* err = r0h_env_new(&env);
+  auto str = [&](const void* p, size_t n) { if (!err) err = r0h_env_write_str(env, (const uint8_t*)p, n); };
+  str(e->signed_info.data(), e->signed_info.size());
+  str(e->authenticated.data(), e->authenticated.size());
+  str(e->signature_value.data(), e->signature_value.size());
+  str(e->order_data.data(), e->order_data.size());
+  str(mod, strlen(mod));
+  str(exp, strlen(exp));
+  str(client_private_pem, client_len);
+  if (!err) err = r0h_env_write_u8_seq(env, decrypted_tx_key, tx_len);
+  str(iban, strlen(iban));
+  str(host_info, strlen(host_info));
+  str(witness_hex, witness_len);
+  str(pub_witness_pem, pub_witness_len);
+  str(verbose, strlen(verbose));
+  free(mod);
+  free(exp);
+  if (err) { r0h_env_free(env); return err; }
+  *out = env;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+// FIPS-197 known-answer hook for the tests: one AES-128 block, either direction
+const char* r0h_aes128_block(const uint8_t key[16], const uint8_t in[16], int decrypt, uint8_t out[16]) {
+  R0H_REQUIRE(key && in && out, "r0h_aes128_block: NULL argument");
+  const Aes128 aes(key);
+  if (decrypt) aes.decrypt_block(in, out); else aes.encrypt_block(in, out);
+  return nullptr;
+}
+
+// RFC 1950 stream -> bytes (caller frees with r0h_free_error); test hook for the inflater against Python's zlib
+const char* r0h_zlib_inflate(const uint8_t* in, size_t n, uint8_t** out, size_t* out_len) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(in && out && out_len, "r0h_zlib_inflate: NULL argument");
+  Bytes o;
+  R0H_TRY(zlib_inflate(in, n, o));
+  *out = (uint8_t*)malloc(o.size() ? o.size() : 1);
+  R0H_REQUIRE(*out, "r0h_zlib_inflate: out of memory");
+  if (!o.empty()) memcpy(*out, o.data(), o.size());
+  *out_len = o.size();
+  return nullptr;
+  R0H_GUARD_END
+}
+
+}  // extern "C"

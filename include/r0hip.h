@@ -282,6 +282,46 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
                                size_t n_roots, const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out);
 const char* r0h_receipt_verify_reason(int verdict); /* static string, do not free */
 
+/* ---- EBICS pre-processing: what data/checkResponse.sh does with xmllint / openssl / zlib-flate / unzip
+ * before `host` starts (host/src/main.rs:143-151), as pure host code.  r0h_ebics_parse cuts the guest's four XML inputs out of a
+ * response and canonicalises them exactly as the script does (checkResponse.sh:151-155, 192, 200, 221); the checks below are the
+ * script's (and the guest's) checks; r0h_ebics_env_inputs frames the thirteen `ExecutorEnv` inputs (host/src/main.rs:389-417).
+ * Pinned by the reference's fixtures data/test/test.xml-* (tests/test_ebics.py). ---- */
+typedef struct r0h_ebics r0h_ebics;
+#define R0H_EBICS_AUTHENTICATED 0       /* "<xml>-authenticated": header, DataEncryptionInfo, ReturnCode, [TimestampBankParameter] */
+#define R0H_EBICS_SIGNED_INFO 1         /* "<xml>-SignedInfo" */
+#define R0H_EBICS_SIGNATURE_VALUE 2     /* "<xml>-SignatureValue" (element with its tags) */
+#define R0H_EBICS_ORDER_DATA 3          /* "<xml>-OrderData" (element with its tags) */
+#define R0H_EBICS_DIGEST_VALUE 4        /* text of <ds:DigestValue> */
+#define R0H_EBICS_SIGNATURE_BIN 5       /* base64-decoded signature */
+#define R0H_EBICS_TRANSACTION_KEY_BIN 6 /* base64-decoded <TransactionKey> (the RSA ciphertext) */
+#define R0H_EBICS_ORDER_DATA_BIN 7      /* base64-decoded order data (AES ciphertext) */
+#define R0H_EBICS_PAYLOAD_ZIP 8         /* decrypted and inflated payload (after r0h_ebics_decrypt_order_data) */
+const char* r0h_ebics_parse(const char* xml, size_t n, r0h_ebics** out);
+const char* r0h_ebics_free(r0h_ebics* e);
+const char* r0h_ebics_part(const r0h_ebics* e, int which, const uint8_t** bytes, size_t* n);
+/* each check returns NULL when it ran; *ok_out = 1 passed / 0 failed */
+const char* r0h_ebics_check_digest(const r0h_ebics* e, int* ok_out);
+const char* r0h_ebics_verify_bank_signature(const r0h_ebics* e, const char* pub_bank_pem, size_t pem_len, int* ok_out);
+/* raw_block: the RSA-decrypted transaction key with its padding ("<xml>-TransactionKeyDecrypt.bin"); key_out: the AES key in it */
+const char* r0h_ebics_check_transaction_key(const r0h_ebics* e, const char* pub_client_pem, size_t pem_len, const uint8_t* raw_block,
+                                            size_t raw_len, uint8_t key_out[16], int* ok_out);
+const char* r0h_ebics_verify_witness(const r0h_ebics* e, const char* pub_witness_pem, size_t pem_len, const char* witness_hex,
+                                     size_t hex_len, int* ok_out);
+/* AES-128-CBC (zero IV) -> RFC 1950 inflate -> ZIP members; an error means the key or the data is wrong */
+const char* r0h_ebics_decrypt_order_data(r0h_ebics* e, const uint8_t key[16]);
+size_t r0h_ebics_n_documents(const r0h_ebics* e);
+const char* r0h_ebics_document(const r0h_ebics* e, size_t i, const char** name, const uint8_t** data, size_t* n);
+/* modulus and exponent of a PEM "PUBLIC KEY" as decimal strings (host/src/main.rs:383-387); free both with r0h_free_error */
+const char* r0h_rsa_public_key_decimal(const char* pem, size_t pem_len, char** modulus_out, char** exponent_out);
+const char* r0h_ebics_env_inputs(const r0h_ebics* e, const char* pub_bank_pem, size_t bank_len, const char* client_private_pem,
+                                 size_t client_len, const uint8_t* decrypted_tx_key, size_t tx_len, const char* iban,
+                                 const char* host_info, const char* witness_hex, size_t witness_len, const char* pub_witness_pem,
+                                 size_t pub_witness_len, const char* verbose, r0h_env** out);
+/* known-answer hooks: one AES-128 block (FIPS 197), one RFC 1950 stream (caller frees *out with r0h_free_error) */
+const char* r0h_aes128_block(const uint8_t key[16], const uint8_t in[16], int decrypt, uint8_t out[16]);
+const char* r0h_zlib_inflate(const uint8_t* in, size_t n, uint8_t** out, size_t* out_len);
+
 /* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
  * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */
 const char* r0h_kernel_timing(r0h_ctx* ctx, int enable);
