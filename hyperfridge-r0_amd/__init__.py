@@ -119,6 +119,19 @@ _SIGNATURES = {
     "r0h_ebics_env_inputs": [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _cp, _cp, _vp, _sz, _vp, _sz, _cp, _pp],
     "r0h_aes128_block": [_vp, _vp, _c.c_int, _vp],
     "r0h_zlib_inflate": [_vp, _sz, _pp, _c.POINTER(_sz)],
+    "r0h_vm_new": [_pp],
+    "r0h_vm_free": [_vp],
+    "r0h_vm_load": [_vp, _u32, _vp, _sz],
+    "r0h_vm_load_elf": [_vp, _vp, _sz],
+    "r0h_vm_set_input": [_vp, _vp, _sz],
+    "r0h_vm_set_pc": [_vp, _u32],
+    "r0h_vm_set_reg": [_vp, _u32, _u32],
+    "r0h_vm_read": [_vp, _u32, _vp, _sz],
+    "r0h_vm_run": [_vp, _vp, _c.POINTER(_c.c_int), _c.POINTER(_u32)],
+    "r0h_vm_segment_info": [_vp, _sz, _vp],
+    "r0h_vm_preflight": [_vp, _sz, _pp, _c.POINTER(_sz)],
+    "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
+    "r0h_vm_segment_claim": [_vp, _sz, _vp],
     "r0h_kernel_timing": [_vp, _c.c_int],
     "r0h_kernel_stats": [_vp, _vp, _sz],
     "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],
@@ -129,6 +142,10 @@ _PLAIN = {
     "r0h_receipt_kind": ([_vp], _c.c_int),
     "r0h_receipt_n_segments": ([_vp], _sz),
     "r0h_ebics_n_documents": ([_vp], _sz),
+    "r0h_vm_n_segments": ([_vp], _sz),
+    "r0h_vm_cycles": ([_vp], _u64),
+    "r0h_vm_reg": ([_vp, _u32], _u32),
+    "r0h_vm_pc": ([_vp], _u32),
     "r0h_verify_reason": ([_c.c_int], _cp),
     "r0h_receipt_verify_reason": ([_c.c_int], _cp),
     "r0h_buf_device_ptr": ([_vp], _vp),
@@ -470,6 +487,109 @@ class ReceiptClaim(ctypes.Structure):
     def globals(self):
         """The eight public-input words that name this claim in a seal (r0h_claim_globals)."""
         return claim_globals(self.digest())
+
+
+class VmLimits(ctypes.Structure):
+    _fields_ = [("segment_po2", _u32), ("page_in_cycles", _u32), ("page_out_cycles", _u32), ("keep_trace", _u32), ("max_cycles", _u64)]
+
+
+class VmSegment(ctypes.Structure):
+    _fields_ = [("index", _u32), ("exit_system", _u32), ("exit_user", _u32), ("pages_in", _u32), ("pages_out", _u32), ("reserved", _u32),
+                ("user_cycles", _u64), ("paging_cycles", _u64), ("pre", SystemState), ("post", SystemState)]
+
+
+class PreflightRow(ctypes.Structure):
+    _fields_ = [("cycle", _u64), ("pc", _u32), ("insn", _u32), ("next_pc", _u32), ("rs1_value", _u32), ("rs2_value", _u32), ("rd", _u32), ("rd_after", _u32),
+                ("mem_kind", _u32), ("mem_addr", _u32), ("mem_before", _u32), ("mem_after", _u32)]
+
+
+class Vm:
+    """RV32IM executor + segmenter + preflight trace (r0h_vm_*; host only): the step of `prover.prove(env, elf)` before prove_segment."""
+    HALTED, PAUSED, LIMIT = 0, 1, 2
+
+    def __init__(self):
+        self.handle = _vp()
+        _check(lib().r0h_vm_new(ctypes.byref(self.handle)))
+
+    def load(self, addr, words):
+        a, pa = _u32arr(words)
+        _check(lib().r0h_vm_load(self.handle, addr, pa, a.size))
+
+    def load_elf(self, data):
+        data = bytes(data)
+        _check(lib().r0h_vm_load_elf(self.handle, data, len(data)))
+
+    def set_input(self, words):
+        a, pa = _u32arr(words)
+        _check(lib().r0h_vm_set_input(self.handle, pa, a.size))
+
+    def set_pc(self, pc):
+        _check(lib().r0h_vm_set_pc(self.handle, pc))
+
+    def set_reg(self, i, v):
+        _check(lib().r0h_vm_set_reg(self.handle, i, v & 0xFFFFFFFF))
+
+    def reg(self, i):
+        return lib().r0h_vm_reg(self.handle, i)
+
+    @property
+    def pc(self):
+        return lib().r0h_vm_pc(self.handle)
+
+    @property
+    def cycles(self):
+        return lib().r0h_vm_cycles(self.handle)
+
+    def read(self, addr, n):
+        out = np.zeros(n, dtype=np.uint32)
+        _check(lib().r0h_vm_read(self.handle, addr, out.ctypes.data_as(_vp), n))
+        return out
+
+    def run(self, segment_po2=20, page_in_cycles=0, page_out_cycles=0, keep_trace=False, max_cycles=0):
+        """Returns (exit kind, exit code); raises R0HipError on a guest trap."""
+        lim = VmLimits(segment_po2, page_in_cycles, page_out_cycles, 1 if keep_trace else 0, max_cycles)
+        kind, code = _c.c_int(-1), _u32(0)
+        _check(lib().r0h_vm_run(self.handle, ctypes.byref(lim), ctypes.byref(kind), ctypes.byref(code)))
+        return kind.value, code.value
+
+    def segments(self):
+        out = []
+        for i in range(lib().r0h_vm_n_segments(self.handle)):
+            s = VmSegment()
+            _check(lib().r0h_vm_segment_info(self.handle, i, ctypes.byref(s)))
+            out.append(s)
+        return out
+
+    def preflight(self, i):
+        p, n = _vp(), _sz(0)
+        _check(lib().r0h_vm_preflight(self.handle, i, ctypes.byref(p), ctypes.byref(n)))
+        rows = ctypes.cast(p, ctypes.POINTER(PreflightRow))
+        return [rows[k] for k in range(n.value)]
+
+    @property
+    def journal(self):
+        p, n = _vp(), _sz(0)
+        _check(lib().r0h_vm_journal(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p, n.value) if n.value else b""
+
+    def claims(self):
+        out = []
+        for i in range(lib().r0h_vm_n_segments(self.handle)):
+            c = ReceiptClaim()
+            _check(lib().r0h_vm_segment_claim(self.handle, i, ctypes.byref(c)))
+            out.append(c)
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().r0h_vm_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def sha256(data):

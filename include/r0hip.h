@@ -322,6 +322,58 @@ const char* r0h_ebics_env_inputs(const r0h_ebics* e, const char* pub_bank_pem, s
 const char* r0h_aes128_block(const uint8_t key[16], const uint8_t in[16], int decrypt, uint8_t out[16]);
 const char* r0h_zlib_inflate(const uint8_t* in, size_t n, uint8_t** out, size_t* out_len);
 
+/* ---- RV32IM executor, segmenter and preflight trace (csrc/rv32im.hip): the part of `prover.prove(env, elf)`
+ * that runs before prove_segment.  Pure host code.  Instruction semantics are the RISC-V specification's; the ecall ABI, the cycle
+ * model and the page Merkle root are this library's own documented choices (risc0's are recalled in outline only: see the source).
+ * ecall (a7): 0 HALT(a0) | 1 READ_WORDS(a0 = dst, a1 = n) | 2 COMMIT(a0 = src, a1 = n bytes) | 3 CYCLES -> a0 | 4 PAUSE(a0). ---- */
+typedef struct r0h_vm r0h_vm;
+typedef struct {
+  uint32_t segment_po2;     /* a segment holds at most 2^segment_po2 cycles (instructions + paging) */
+  uint32_t page_in_cycles;  /* charged once per 1 KiB page first touched in a segment */
+  uint32_t page_out_cycles; /* charged once per page written in a segment */
+  uint32_t keep_trace;      /* record one r0h_preflight_row per instruction */
+  uint64_t max_cycles;      /* stop (R0H_VM_LIMIT, ExitCode::SessionLimit) after this many instructions; 0 = no limit */
+} r0h_vm_limits;
+typedef struct {
+  uint32_t index, exit_system, exit_user, pages_in, pages_out, reserved;
+  uint64_t user_cycles, paging_cycles;
+  r0h_system_state pre, post; /* pc + Merkle root of memory before the first and after the last instruction of the segment */
+} r0h_vm_segment;
+#define R0H_MEM_NONE 0
+#define R0H_MEM_READ 1
+#define R0H_MEM_WRITE 2
+/* what witness generation replays, one row per cycle: the instruction, its operands and result, and its memory transaction */
+typedef struct {
+  uint64_t cycle;  /* within the segment */
+  uint32_t pc, insn, next_pc;
+  uint32_t rs1_value, rs2_value;
+  uint32_t rd, rd_after;                           /* rd = 0: no register written */
+  uint32_t mem_kind, mem_addr, mem_before, mem_after; /* word-aligned address, the word before and after */
+} r0h_preflight_row;
+#define R0H_VM_HALTED 0
+#define R0H_VM_PAUSED 1
+#define R0H_VM_LIMIT 2
+const char* r0h_vm_new(r0h_vm** out);
+const char* r0h_vm_free(r0h_vm* vm);
+const char* r0h_vm_load(r0h_vm* vm, uint32_t addr, const uint32_t* words, size_t n);
+const char* r0h_vm_load_elf(r0h_vm* vm, const uint8_t* elf, size_t n); /* ELF32 LE RISC-V executable: PT_LOAD segments + entry */
+const char* r0h_vm_set_input(r0h_vm* vm, const uint32_t* words, size_t n); /* the ExecutorEnv word stream (r0h_env_words) */
+const char* r0h_vm_set_pc(r0h_vm* vm, uint32_t pc);
+const char* r0h_vm_set_reg(r0h_vm* vm, uint32_t i, uint32_t value);
+uint32_t r0h_vm_reg(const r0h_vm* vm, uint32_t i);
+uint32_t r0h_vm_pc(const r0h_vm* vm);
+const char* r0h_vm_read(const r0h_vm* vm, uint32_t addr, uint32_t* words, size_t n);
+/* runs to HALT / PAUSE / max_cycles, cutting segments on the way; a guest trap (illegal instruction, misaligned access, unknown
+ * ecall) is an error string, as a guest panic is an Err from `prove` (host/src/main.rs:327-330) */
+const char* r0h_vm_run(r0h_vm* vm, const r0h_vm_limits* limits, int* exit_kind_out, uint32_t* exit_code_out);
+size_t r0h_vm_n_segments(const r0h_vm* vm);
+uint64_t r0h_vm_cycles(const r0h_vm* vm);
+const char* r0h_vm_segment_info(const r0h_vm* vm, size_t i, r0h_vm_segment* out);
+const char* r0h_vm_preflight(const r0h_vm* vm, size_t i, const r0h_preflight_row** rows, size_t* n);
+const char* r0h_vm_journal(const r0h_vm* vm, const uint8_t** bytes, size_t* n);
+/* the ReceiptClaim of segment i: system states and exit code from the run, Output{journal} on the last segment */
+const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* out);
+
 /* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
  * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */
 const char* r0h_kernel_timing(r0h_ctx* ctx, int enable);

@@ -158,11 +158,17 @@ def test_rust_bindings_are_generated_from_the_header_and_name_the_same_symbols()
             nm, ty = a.split(": ")
             assert re.fullmatch(r"(\*(const|mut) )*(u8|u32|u64|usize|f32|c_int|c_char|c_void|r0h_\w+)", ty), (name, a)
         if ret:
-            assert re.fullmatch(r" -> (\*(const|mut) )*(u32|usize|c_int|c_char|c_void)", ret), (name, ret)
+            assert re.fullmatch(r" -> (\*(const|mut) )*(u32|u64|usize|c_int|c_char|c_void)", ret), (name, ret)
     # spot checks of the translation rules
     assert "pub fn r0h_ctx_create(device: c_int, out: *mut *mut r0h_ctx) -> *const c_char;" in rs
     assert "pub fn r0h_buf_device_ptr(buf: *const r0h_buf) -> *mut c_void;" in rs
     assert "pub fn r0h_free_error(msg: *const c_char);" in rs
     assert "pub fn r0h_claim_digest(claim: *const r0h_receipt_claim, digest_out: *mut u8) -> *const c_char;" in rs
+    # every type a prototype names is declared in the file: the opaque handles and the plain structs, field for field
+    declared = set(re.findall(r"pub struct (r0h_\w+)", rs))
+    assert set(re.findall(r"\b(r0h_\w+)\b", " ".join(a + (r or "") for _, a, r in fns))) - {n for n, _, _ in fns} <= declared
+    assert "pub struct r0h_system_state { pub pc: u32, pub merkle_root: [u8; 32] }" in rs
+    assert "pub struct r0h_vm_limits { pub segment_po2: u32, pub page_in_cycles: u32, pub page_out_cycles: u32, pub keep_trace: u32, pub max_cycles: u64 }" in rs
+    assert "pub struct r0h_ctx { _private: [u8; 0] }" in rs and "pub struct r0h_vm { _private: [u8; 0] }" in rs
     # INTEGRATION.md points at the generated file instead of carrying its own (partial) copy
     assert "bindings/r0hip_sys.rs" in open(os.path.join(ROOT, "INTEGRATION.md")).read()
