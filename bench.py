@@ -37,8 +37,14 @@ def device_code_fingerprint(circuit="bench"):
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "hyperfridge-r0_amd", "csrc")
-    files = sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".hpp")))
-    files += [os.path.join(ROOT, "include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))]
+    # device code only: the translation units that define kernels and every header they can include (host-only units -- receipts,
+    # claims, the verifier, the EBICS pre-processor, the RV32IM executor -- change nothing that runs on the GPU)
+    files = []
+    for f in sorted(os.listdir(src)):
+        path = os.path.join(src, f)
+        if f.endswith(".hpp") or (f.endswith(".hip") and b"__global__" in open(path, "rb").read()):
+            files.append(path)
+    files.append(os.path.join(ROOT, "include", "r0hip_circuit.h"))
     files.append(os.path.join(ROOT, "circuits", circuit + ".r0c"))
     for path in files:
         h.update(os.path.basename(path).encode() + b"\0")

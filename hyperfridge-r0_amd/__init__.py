@@ -132,6 +132,7 @@ _SIGNATURES = {
     "r0h_vm_preflight": [_vp, _sz, _pp, _c.POINTER(_sz)],
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
+    "r0h_prove_elf": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _pp, _vp, _c.POINTER(_u64)],
     "r0h_kernel_timing": [_vp, _c.c_int],
     "r0h_kernel_stats": [_vp, _vp, _sz],
     "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],
@@ -912,6 +913,15 @@ class Hal:
                 own.free()
                 code.free()
         return out
+
+    def prove_elf(self, circuit, elf, input_words, segment_po2=20, max_cycles=0):
+        """`default_prover().prove(env, elf)` (r0h_prove_elf): returns (Receipt, image id, guest cycles)."""
+        elf = bytes(elf)
+        w, pw = _u32arr(input_words if len(input_words) else [0])
+        h, image_id, cycles = _vp(), (ctypes.c_uint8 * 32)(), _u64(0)
+        _check(lib().r0h_prove_elf(self.ctx, circuit.handle, elf, len(elf), pw, len(input_words), segment_po2, max_cycles, ctypes.byref(h), image_id,
+                                   ctypes.byref(cycles)))
+        return Receipt(h), bytes(image_id), cycles.value
 
     def proof_begin(self, circuit, po2, code, data, glob):
         """Commit CODE and DATA; returns (proof handle, accumulation mix words)."""

@@ -374,6 +374,15 @@ const char* r0h_vm_journal(const r0h_vm* vm, const uint8_t** bytes, size_t* n);
 /* the ReceiptClaim of segment i: system states and exit code from the run, Output{journal} on the last segment */
 const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* out);
 
+/* ---- `default_prover().prove(env, elf)` (host/src/main.rs:420-423) in one call: execute the ELF on the word stream of `env`,
+ * cut the run into segments of at most 2^segment_po2 cycles, prove each at the smallest trace size that holds it, return the
+ * composite receipt with every segment's claim bound to its seal, plus the image id `receipt.verify` is given.  A guest that
+ * traps, exits non-zero or exceeds max_cycles (0 = unlimited) is an error, as it is an Err from `prove`.  The witness of every
+ * segment is the circuit's synthetic column program with the claim planted, NOT the execution trace (csrc/session.hip). ---- */
+const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words,
+                          size_t n_input, uint32_t segment_po2, uint64_t max_cycles, r0h_receipt** receipt_out,
+                          uint8_t image_id_out[32], uint64_t* cycles_out);
+
 /* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
  * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */
 const char* r0h_kernel_timing(r0h_ctx* ctx, int enable);
