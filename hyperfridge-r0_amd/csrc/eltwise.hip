@@ -40,29 +40,30 @@ __global__ void eval_tables_kernel(uint32_t* __restrict__ tabs, const uint32_t* 
   else if (i < rl + rows) st4(tab + 4 * (size_t)i, fp4_pow(x, bitrev_coeffs ? (uint64_t)bitrev(i - rl, rows_log) : (uint64_t)(i - rl) << rl_log));
 }
 
-// A column is read ONCE and evaluated at all NP points asked of it (a register's taps sit at 1-3 points z w^-back): the lanes keep
-// NP sets of 2^rl_log / 64 powers, the loaded coefficients are shared by the NP sums.  (Round 1 ran one pass per point: 2.0 GB
-// read per segment for 1.09 GB of distinct columns.)
+// A column is read ONCE and evaluated at all NP points asked of it (a register's taps sit at 1-3 points z w^-back).
+// sum_i c[i] x^i = sum_lo A[lo] * (sum_hi c[hi*RL + lo] * B[hi]): a lane owns KP fixed positions lo of every row and keeps, per
+// point, one 64-bit running sum per (position, extension component).  A row costs one v_mad_u64_u32 per coefficient and component
+// against the wave-uniform B[hi] (scalar loads) and a correction of the high words every second row -- no cross-lane step and no
+// extension product inside the loop; the A[lo] products and the wave reduction happen once per wave at the end.  (Round 1, and the
+// first form of this kernel, multiplied by A[lo] first and reduced every row across the wave: 1,150 instead of ~400 SIMD cycles per
+// row and point.)
 template <int NP>
 __global__ __launch_bounds__(256) void eval_rows_kernel(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
                                                          const uint32_t* __restrict__ which, const uint32_t* __restrict__ tabs,
                                                          uint32_t po2, uint32_t rl_log) {
-  constexpr int KP = 8;  // powers per lane and point: rows of up to 512 coefficients
+  constexpr int KP = 8;  // positions per lane: rows of up to 512 coefficients
   const uint32_t rl = 1u << rl_log, rows = 1u << (po2 - rl_log);
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t* poly = coeffs + ((size_t)which[blockIdx.y] << po2);
   const size_t tab_stride = 4 * (size_t)(rl + rows);
-  Fp4 a[NP][KP];
+  uint64_t acc[NP][KP][4];
 #pragma unroll
   for (int p = 0; p < NP; p++)
 #pragma unroll
-    for (int k = 0; k < KP; k++) {
-      uint32_t lo = lane + 64 * k;
-      a[p][k] = lo < rl ? ld4(tabs + p * tab_stride + 4 * (size_t)lo) : fp4_zero();
-    }
-  Fp4 tot[NP];
+    for (int k = 0; k < KP; k++)
 #pragma unroll
-  for (int p = 0; p < NP; p++) tot[p] = fp4_zero();
+      for (int q = 0; q < 4; q++) acc[p][k][q] = 0;
+  uint32_t n_rows = 0;
 #pragma unroll 1
   for (uint32_t hi = blockIdx.x * 4 + wave; hi < rows; hi += gridDim.x * 4) {
     const uint32_t* row = poly + ((size_t)hi << rl_log);
@@ -72,37 +73,50 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(uint32_t* __restrict__ p
       uint32_t lo = lane + 64 * k;
       cf[k] = lo < rl ? row[lo] : 0u;
     }
+    // four terms fit a 64-bit sum as they are; from then on the high words are brought below p before every second term
+    const bool fix = n_rows >= 4 && (n_rows & 1) == 0;
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-      Fp4 s = fp4_zero();
+      const uint32_t* bp = tabs + p * tab_stride + 4 * (size_t)(rl + hi);  // wave-uniform address
+      const uint32_t b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
 #pragma unroll
-      for (int g = 0; g < KP / 4; g++) {  // four coefficient * power products per 64-bit sum, one reduction per component
-        uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+      for (int k = 0; k < KP; k++) {
+        if (fix) {
 #pragma unroll
-        for (int k = 4 * g; k < 4 * g + 4; k++) {
-          t0 += (uint64_t)a[p][k].e[0] * cf[k]; t1 += (uint64_t)a[p][k].e[1] * cf[k];
-          t2 += (uint64_t)a[p][k].e[2] * cf[k]; t3 += (uint64_t)a[p][k].e[3] * cf[k];
+          for (int q = 0; q < 4; q++) acc[p][k][q] = ((uint64_t)reduce1((uint32_t)(acc[p][k][q] >> 32)) << 32) | (uint32_t)acc[p][k][q];
         }
-        s = s + Fp4{{reduce64(t0), reduce64(t1), reduce64(t2), reduce64(t3)}};
-        __builtin_amdgcn_sched_barrier(0);  // keep the 64-bit sums of one group from being interleaved with the next (register pressure)
+        acc[p][k][0] += (uint64_t)cf[k] * b0; acc[p][k][1] += (uint64_t)cf[k] * b1;
+        acc[p][k][2] += (uint64_t)cf[k] * b2; acc[p][k][3] += (uint64_t)cf[k] * b3;
       }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        Fp4 o;
-#pragma unroll
-        for (int q = 0; q < 4; q++) o.e[q] = __shfl_xor(s.e[q], off);
-        s = s + o;
-      }
-      if (lane == 0) tot[p] = tot[p] + s * ld4(tabs + p * tab_stride + 4 * (size_t)(rl + hi));
-      __builtin_amdgcn_sched_barrier(0);
     }
+    n_rows++;
   }
   __shared__ uint32_t red[4][NP][4];
-  if (lane == 0) {
 #pragma unroll
-    for (int p = 0; p < NP; p++)
+  for (int p = 0; p < NP; p++) {
+    Fp4 tot = fp4_zero();
 #pragma unroll
-      for (int q = 0; q < 4; q++) red[wave][p][q] = tot[p].e[q];
+    for (int k = 0; k < KP; k++) {
+      const uint32_t lo = lane + 64 * k;
+      Fp4 v;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        uint64_t t = ((uint64_t)reduce1((uint32_t)(acc[p][k][q] >> 32)) << 32) | (uint32_t)acc[p][k][q];  // high word below 2p by the invariant
+        v.e[q] = reduce64(t);
+      }
+      if (lo < rl) tot = tot + v * ld4(tabs + p * tab_stride + 4 * (size_t)lo);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      Fp4 o;
+#pragma unroll
+      for (int q = 0; q < 4; q++) o.e[q] = __shfl_xor(tot.e[q], off);
+      tot = tot + o;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) red[wave][p][q] = tot.e[q];
+    }
   }
   __syncthreads();
   if (threadIdx.x < NP) {
@@ -394,7 +408,7 @@ const char* evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, cons
   const size_t n_polys = coeffs->bytes >> (po2 + 2);
   // evaluations of one column share a single read of it: group the requests by column, then the columns by the list of points
   // asked of them (in the prover: one list per tap combo), at most MAX_NP points per pass
-  constexpr uint32_t MAX_NP = 2;  // three or four points at once need 246+ VGPRs: a third point takes a second pass over its column
+  constexpr uint32_t MAX_NP = 2;  // 64 VGPRs of running sums per point: a third point takes a second pass over its column
   struct ColJob { uint32_t col; std::vector<uint32_t> dest; };
   std::map<uint32_t, std::vector<uint32_t>> by_col;  // column -> request indices
   for (uint32_t k = 0; k < n_eval; k++) {
@@ -440,12 +454,8 @@ const char* evaluate_any(r0h_ctx* ctx, const r0h_buf* coeffs, uint32_t po2, cons
     gb = gb < 4 ? 4 : gb;
     gb = gb > blocks ? blocks : gb;
     hipLaunchKernelGGL(eval_tables_kernel, dim3((rl + rows + 255) / 256, np), dim3(256), 0, ctx->stream, tab, pts, rl_log, po2 - rl_log, bitrev_coeffs ? 1u : 0u);
-    switch (np) {
-      case 1: hipLaunchKernelGGL(eval_rows_kernel<1>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log); break;
-      case 2: hipLaunchKernelGGL(eval_rows_kernel<2>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log); break;
-      case 3: hipLaunchKernelGGL(eval_rows_kernel<3>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log); break;
-      default: hipLaunchKernelGGL(eval_rows_kernel<4>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log); break;
-    }
+    if (np == 1) hipLaunchKernelGGL(eval_rows_kernel<1>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log);
+    else hipLaunchKernelGGL(eval_rows_kernel<2>, dim3(gb, ng), dim3(256), 0, ctx->stream, part, u32(coeffs), idx, tab, po2, rl_log);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((ng * np + 63) / 64), dim3(64), 0, ctx->stream, u32(out), part, idx + ng, gb, ng * np);
     R0H_TRY(launch_ok("batch_evaluate_any kernels"));  // scratch reuse by the next group is ordered by the stream
   }
