@@ -33,7 +33,9 @@ def main():
         if not n:
             continue
         raw, wr = fs * 1024 / n, ws * 1024 / max(wn, 1)
-        corr = 2 * raw
+        # the scan kernels (divide_*, prefix_*) give every lane its own run of 16-byte elements, 256 bytes apart from its neighbour's:
+        # their requests are 64-byte ones, which FETCH_SIZE counts in full
+        corr = raw if k.startswith(("divide_", "prefix_")) else 2 * raw
         out["kernels"][k] = {"launches": n, "fetch_raw_bytes": round(raw), "fetch_corrected_bytes": round(corr), "write_bytes": round(wr),
                              "hbm_bytes_per_launch": round(corr + wr)}
     if len(sys.argv) > 5:
