@@ -395,6 +395,10 @@ static const char* proof_finish(r0h_proof& st, const r0h_buf* accum, std::vector
     R0H_TRY(stage_h2d(ctx, d_fix->ptr, fix.data(), fix.size() * 4));
     uint32_t nf = (uint32_t)(fix.size() / 2);
     hipLaunchKernelGGL(sub_head_kernel, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, u32(combos), u32(d_fix), nf);
+    {
+      hipError_t e = hipGetLastError();
+      R0H_REQUIRE(e == hipSuccess, "sub_head_kernel: %s", hipGetErrorString(e));
+    }
     sc.release(d_fix);
   }
   phase(ctx, "deep_divide");

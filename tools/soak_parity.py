@@ -20,7 +20,14 @@ def main():
     cases, t0, n = [("tiny", p) for p in (9, 10, 11, 12, 13)] + [("small", p) for p in (9, 10, 11, 12)] + [("recursion", 10), ("bench", 9), ("bench", 10)], time.time(), 0
     full = 0
     loaded = {}
+    roots = {}  # (circuit, po2) -> control root: every seal is verified bound to its program, by both verifiers
     seed = 10_000
+
+    def root_of(name, gc, po2):
+        if (name, po2) not in roots:
+            roots[(name, po2)] = hal.code_root(gc, po2)
+        return roots[(name, po2)]
+
     while time.time() - t0 < budget:
         for name, po2 in cases:
             if name not in loaded:
@@ -36,7 +43,8 @@ def main():
                 bad = int(np.nonzero(seal[:min(seal.size, want.size)] != want[:min(seal.size, want.size)])[0][0]) if seal.size and want.size else -1
                 print("MISMATCH circuit %s po2 %d seed %d at word %d" % (name, po2, seed, bad))
                 sys.exit(1)
-            assert r0.verify_seal(blob, seal)[0] == 0
+            root = root_of(name, gc, po2)
+            assert r0.verify_seal(blob, seal, code_root=root)[0] == 0 and oc.verify(seal, code_root=root)[0] == 0
             code.free(); data.free()
             n += 1
         # one full-size segment per sweep: too large for the oracle's prover, so both verifiers must accept it
@@ -45,12 +53,13 @@ def main():
         code, data, glob = hal.witgen(gc, 20, seed)
         seal = hal.prove_segment(gc, 20, code, data, glob)
         code.free(); data.free()
-        if r0.verify_seal(blob, seal)[0] != 0 or oc.verify(seal)[0] != 0:
+        root = root_of("bench", gc, 20)
+        if r0.verify_seal(blob, seal, code_root=root)[0] != 0 or oc.verify(seal, code_root=root)[0] != 0:
             print("FULL-SIZE seal rejected, seed %d" % seed)
             sys.exit(1)
         full += 1
         print("%d seals identical, %d full-size seals accepted by both verifiers after %.0f s" % (n, full, time.time() - t0), flush=True)
-    print("soak ok: %d seals device == oracle word for word; %d seals at 2^20 rows accepted by both verifiers" % (n, full))
+    print("soak ok: %d seals device == oracle word for word; %d seals at 2^20 rows accepted by both verifiers; all bound to their control roots" % (n, full))
 
 
 if __name__ == "__main__":
