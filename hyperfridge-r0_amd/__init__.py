@@ -113,6 +113,8 @@ _SIGNATURES = {
     "r0h_ebics_verify_bank_signature": [_vp, _vp, _sz, _c.POINTER(_c.c_int)],
     "r0h_ebics_check_transaction_key": [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_c.c_int)],
     "r0h_ebics_verify_witness": [_vp, _vp, _sz, _vp, _sz, _c.POINTER(_c.c_int)],
+    "r0h_ebics_decrypt_transaction_key": [_vp, _vp, _sz, _vp, _sz, _c.POINTER(_sz), _vp, _c.POINTER(_c.c_int)],
+    "r0h_ebics_witness_sign": [_vp, _vp, _sz, _pp],
     "r0h_ebics_decrypt_order_data": [_vp, _vp],
     "r0h_ebics_document": [_vp, _sz, _pp, _pp, _c.POINTER(_sz)],
     "r0h_rsa_public_key_decimal": [_vp, _sz, _pp, _pp],
@@ -379,6 +381,22 @@ class Ebics:
         raw, key = bytes(raw_block), (ctypes.c_uint8 * 16)()
         ok = self._flag(lib().r0h_ebics_check_transaction_key, pem, len(pem), raw, len(raw), key)
         return ok, bytes(key)
+
+    def decrypt_transaction_key(self, client_private_pem):
+        """(ok, raw RSA-decrypted block, 16-byte AES key) with the client's PRIVATE key (checkResponse.sh:231-236)."""
+        pem = client_private_pem.encode() if isinstance(client_private_pem, str) else bytes(client_private_pem)
+        raw, n, key, ok = (ctypes.c_uint8 * 1024)(), _sz(0), (ctypes.c_uint8 * 16)(), _c.c_int(-1)
+        _check(lib().r0h_ebics_decrypt_transaction_key(self.handle, pem, len(pem), raw, 1024, ctypes.byref(n), key, ctypes.byref(ok)))
+        return bool(ok.value), bytes(raw[:n.value]), bytes(key)
+
+    def witness_sign(self, witness_private_pem):
+        """The witness signature over SHA-256(decoded order data) as the `xxd -p` text of `<xml>-Witness.hex` (checkResponse.sh:276-279)."""
+        pem = witness_private_pem.encode() if isinstance(witness_private_pem, str) else bytes(witness_private_pem)
+        p = _vp()
+        _check(lib().r0h_ebics_witness_sign(self.handle, pem, len(pem), ctypes.byref(p)))
+        text = ctypes.cast(p, _cp).value
+        lib().r0h_free_error(p)
+        return text
 
     def verify_witness(self, pub_witness_pem, witness_hex):
         pem = pub_witness_pem.encode() if isinstance(pub_witness_pem, str) else bytes(pub_witness_pem)

@@ -258,6 +258,43 @@ bool pkcs1_sha256_verify(const RsaPub& key, const Bytes& sig, const uint8_t dige
   return em[ps_end] == 0 && memcmp(&em[ps_end + 1], info, sizeof info) == 0 && memcmp(&em[ps_end + 1 + sizeof info], digest, 32) == 0;
 }
 
+// RSA private key from PEM: PKCS#8 "PRIVATE KEY" (what the reference's test keys are, data/client.pem) or PKCS#1 "RSA PRIVATE KEY".
+// The private exponentiation below is plain square-and-multiply over the full exponent (no CRT, not constant time): this is the
+// pre-processing tool's stand-in for `openssl pkeyutl -decrypt / -sign` (checkResponse.sh:231-236, 276-279), run by the key's owner.
+struct RsaPriv { Big n, e, d; size_t bytes = 0; };
+const char* parse_rsa_private_pem(const char* pem, size_t len, RsaPriv& key) {
+  std::string text(pem, len);
+  bool pkcs8 = true;
+  size_t a = text.find("-----BEGIN PRIVATE KEY-----"), b = text.find("-----END PRIVATE KEY-----"), skip = 27;
+  if (a == std::string::npos) { pkcs8 = false; a = text.find("-----BEGIN RSA PRIVATE KEY-----"); b = text.find("-----END RSA PRIVATE KEY-----"); skip = 31; }
+  R0H_REQUIRE(a != std::string::npos && b != std::string::npos && b > a, "RSA private key: no PEM \"PRIVATE KEY\" / \"RSA PRIVATE KEY\" block");
+  Bytes der;
+  R0H_REQUIRE(b64_decode(text.data() + a + skip, b - a - skip, der), "RSA private key: bad base64 in the PEM body");
+  Der d{der.data(), der.size()};
+  const uint8_t* body; size_t l;
+  R0H_REQUIRE(d.tlv(0x30, &body, &l), "RSA private key: DER does not start with a SEQUENCE");
+  Der seq{body, l};
+  const uint8_t* v; size_t vl;
+  if (pkcs8) {
+    const uint8_t *alg, *oct; size_t al, ol;
+    R0H_REQUIRE(seq.tlv(0x02, &v, &vl) && seq.tlv(0x30, &alg, &al) && seq.tlv(0x04, &oct, &ol), "RSA private key: not a PKCS#8 PrivateKeyInfo");
+    static const uint8_t rsa_oid[] = {0x06, 0x09, 0x2a, 0x86, 0x48, 0x86, 0xf7, 0x0d, 0x01, 0x01, 0x01};
+    R0H_REQUIRE(al >= sizeof rsa_oid && memcmp(alg, rsa_oid, sizeof rsa_oid) == 0, "RSA private key: algorithm is not rsaEncryption");
+    Der inner{oct, ol};
+    R0H_REQUIRE(inner.tlv(0x30, &body, &l), "RSA private key: no RSAPrivateKey SEQUENCE");
+    seq = Der{body, l};
+  }
+  const uint8_t *np, *ep, *dp; size_t nl, el, dl;
+  R0H_REQUIRE(seq.tlv(0x02, &v, &vl) && seq.tlv(0x02, &np, &nl) && seq.tlv(0x02, &ep, &el) && seq.tlv(0x02, &dp, &dl), "RSA private key: version / n / e / d missing");
+  key.n = Big::from_bytes(np, nl);
+  key.e = Big::from_bytes(ep, el);
+  key.d = Big::from_bytes(dp, dl);
+  key.bytes = (key.n.bits() + 7) / 8;
+  R0H_REQUIRE(key.n.bits() >= 512 && (key.n.w[0] & 1) && !key.d.w.empty(), "RSA private key: implausible modulus / exponent");
+  return nullptr;
+}
+Bytes rsa_private_op(const RsaPriv& key, const Bytes& in) { return Mont(key.n).pow(Big::from_bytes(in.data(), in.size()), key.d).to_bytes(key.bytes); }
+
 // ---------------------------------------------------------------- AES-128 (FIPS 197), decryption direction, CBC
 struct Aes128 {
   uint8_t sbox[256], inv[256], rk[176];
@@ -811,6 +848,58 @@ const char* r0h_ebics_check_transaction_key(const r0h_ebics* e, const char* pub_
   if (c != e->transaction_key) return nullptr;
   memcpy(key_out, raw_block + sep + 1, 16);
   *ok = 1;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+// data/checkResponse.sh:231-236: `openssl pkeyutl -decrypt ... rsa_padding_mode:none` with the client's PRIVATE key gives the raw
+// block the guest is handed ("<xml>-TransactionKeyDecrypt.bin"); the padded form must be 00 02 PS 00 key16 (:236-248).
+const char* r0h_ebics_decrypt_transaction_key(const r0h_ebics* e, const char* client_private_pem, size_t pem_len, uint8_t* raw_out, size_t raw_capacity, size_t* raw_len_out,
+                                              uint8_t key_out[16], int* ok) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && client_private_pem && raw_out && raw_len_out && key_out && ok, "r0h_ebics_decrypt_transaction_key: NULL argument");
+  RsaPriv key;
+  R0H_TRY(parse_rsa_private_pem(client_private_pem, pem_len, key));
+  R0H_REQUIRE(raw_capacity >= key.bytes, "r0h_ebics_decrypt_transaction_key: %zu bytes needed for the raw block", key.bytes);
+  *ok = 0;
+  *raw_len_out = key.bytes;
+  if (e->transaction_key.size() != key.bytes || cmp(Big::from_bytes(e->transaction_key.data(), e->transaction_key.size()), key.n) >= 0) return nullptr;
+  const Bytes raw = rsa_private_op(key, e->transaction_key);
+  memcpy(raw_out, raw.data(), raw.size());
+  size_t sep = 2;
+  while (sep < raw.size() && raw[sep] != 0) sep++;
+  if (raw[0] != 0 || raw[1] != 2 || sep < 10 || raw.size() - sep - 1 != 16) return nullptr;
+  memcpy(key_out, &raw[sep + 1], 16);
+  *ok = 1;
+  return nullptr;
+  R0H_GUARD_END
+}
+
+// data/checkResponse.sh:276-279: the witness signs SHA-256 of the decoded order data (RSASSA-PKCS1-v1_5, deterministic); the file is
+// `xxd -p` of the signature: lower-case hex, 60 digits per line
+const char* r0h_ebics_witness_sign(const r0h_ebics* e, const char* witness_private_pem, size_t pem_len, char** hex_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && witness_private_pem && hex_out, "r0h_ebics_witness_sign: NULL argument");
+  RsaPriv key;
+  R0H_TRY(parse_rsa_private_pem(witness_private_pem, pem_len, key));
+  static const uint8_t info[] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, 0x01, 0x05, 0x00, 0x04, 0x20};
+  R0H_REQUIRE(key.bytes >= sizeof info + 32 + 11, "r0h_ebics_witness_sign: modulus too short for a SHA-256 DigestInfo");
+  Bytes em(key.bytes, 0xff);
+  em[0] = 0; em[1] = 1;
+  const size_t t = key.bytes - sizeof info - 32;
+  em[t - 1] = 0;
+  memcpy(&em[t], info, sizeof info);
+  sha256(e->order_data_bin.data(), e->order_data_bin.size(), &em[t + sizeof info]);
+  const Bytes sig = rsa_private_op(key, em);
+  std::string hex;
+  static const char digits[] = "0123456789abcdef";
+  for (size_t i = 0; i < sig.size(); i++) {
+    hex += digits[sig[i] >> 4]; hex += digits[sig[i] & 15];
+    if (i % 30 == 29 || i + 1 == sig.size()) hex += '\n';
+  }
+  *hex_out = (char*)malloc(hex.size() + 1);
+  R0H_REQUIRE(*hex_out, "r0h_ebics_witness_sign: out of memory");
+  memcpy(*hex_out, hex.c_str(), hex.size() + 1);
   return nullptr;
   R0H_GUARD_END
 }

@@ -2,10 +2,11 @@
 // before proving): cut the guest inputs out of an EBICS response, run the script's checks, write the `<xml>-*` files `host` then
 // reads (host/src/main.rs:206-227).  Host only -- no GPU, no openssl / xmllint / perl / zlib-flate.
 //   usage: r0h_preprocess <response.xml> --pub-bank bank.pem --pub-client client.pem --pub-witness witness.pem
-//                         --tx-key-raw <xml>-TransactionKeyDecrypt.bin --witness-hex <xml>-Witness.hex [--out-dir dir]
-// The two inputs that need a PRIVATE key -- the RSA-decrypted transaction key block and the witness signature -- are taken as files
-// (the script makes them with `openssl pkeyutl -decrypt` / `-sign`, checkResponse.sh:231-236, 276-279); everything else is derived
-// and checked here.  Exit status: 0 all checks passed, 1 a check failed (named on stdout), 2 unusable input.
+//                         (--client-key client_private.pem | --tx-key-raw <xml>-TransactionKeyDecrypt.bin)
+//                         (--witness-key witness_private.pem | --witness-hex <xml>-Witness.hex) [--out-dir dir]
+// The two steps that need a PRIVATE key -- decrypting the transaction key and signing as the witness (`openssl pkeyutl -decrypt` /
+// `-sign`, checkResponse.sh:231-236, 276-279) -- are done here when the key is given, or their results are taken as files.
+// Exit status: 0 all checks passed, 1 a check failed (named on stdout), 2 unusable input.
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -38,25 +39,39 @@ static bool spill(const std::string& path, const uint8_t* p, size_t n) {
 
 int main(int argc, char** argv) {
   if (argc < 2 || !strcmp(argv[1], "--help")) {
-    printf("usage: r0h_preprocess <response.xml> --pub-bank f --pub-client f --pub-witness f --tx-key-raw f --witness-hex f [--out-dir d]\n%s\n", r0h_version());
+    printf("usage: r0h_preprocess <response.xml> --pub-bank f --pub-client f --pub-witness f (--client-key f | --tx-key-raw f) (--witness-key f | --witness-hex f) [--out-dir d]\n%s\n", r0h_version());
     return argc < 2 ? 2 : 0;
   }
-  std::string xml_path = argv[1], pub_bank, pub_client, pub_witness, tx_raw, witness_hex, out_dir;
+  std::string xml_path = argv[1], pub_bank, pub_client, pub_witness, tx_raw, witness_hex, out_dir, client_key, witness_key;
   for (int i = 2; i + 1 < argc; i += 2) {
     std::string* dst = !strcmp(argv[i], "--pub-bank") ? &pub_bank : !strcmp(argv[i], "--pub-client") ? &pub_client : !strcmp(argv[i], "--pub-witness") ? &pub_witness
-                       : !strcmp(argv[i], "--tx-key-raw") ? &tx_raw : !strcmp(argv[i], "--witness-hex") ? &witness_hex : nullptr;
+                       : !strcmp(argv[i], "--tx-key-raw") ? &tx_raw : !strcmp(argv[i], "--witness-hex") ? &witness_hex : !strcmp(argv[i], "--client-key") ? &client_key
+                       : !strcmp(argv[i], "--witness-key") ? &witness_key : nullptr;
     if (!strcmp(argv[i], "--out-dir")) { out_dir = argv[i + 1]; continue; }
     if (!dst) { fprintf(stderr, "r0h_preprocess: unknown option %s\n", argv[i]); return 2; }
     if (!slurp(argv[i + 1], dst)) { fprintf(stderr, "r0h_preprocess: cannot read %s\n", argv[i + 1]); return 2; }
   }
   std::string xml;
   if (!slurp(xml_path, &xml)) { fprintf(stderr, "r0h_preprocess: cannot read %s\n", xml_path.c_str()); return 2; }
-  if (pub_bank.empty() || pub_client.empty() || pub_witness.empty() || tx_raw.empty() || witness_hex.empty()) {
-    fprintf(stderr, "r0h_preprocess: --pub-bank, --pub-client, --pub-witness, --tx-key-raw and --witness-hex are all needed\n");
+  if (pub_bank.empty() || pub_client.empty() || pub_witness.empty() || (tx_raw.empty() && client_key.empty()) || (witness_hex.empty() && witness_key.empty())) {
+    fprintf(stderr, "r0h_preprocess: --pub-bank, --pub-client, --pub-witness, (--client-key | --tx-key-raw) and (--witness-key | --witness-hex) are all needed\n");
     return 2;
   }
   r0h_ebics* e = nullptr;
   CHECK(r0h_ebics_parse(xml.data(), xml.size(), &e));
+  if (!client_key.empty()) {  // checkResponse.sh:231-236
+    uint8_t raw[1024], k[16];
+    size_t n = 0;
+    int ok = 0;
+    CHECK(r0h_ebics_decrypt_transaction_key(e, client_key.data(), client_key.size(), raw, sizeof raw, &n, k, &ok));
+    tx_raw.assign((const char*)raw, n);  // re-checked against the public key below, like a block read from a file
+  }
+  if (!witness_key.empty()) {  // checkResponse.sh:276-279
+    char* hex = nullptr;
+    CHECK(r0h_ebics_witness_sign(e, witness_key.data(), witness_key.size(), &hex));
+    witness_hex = hex;
+    r0h_free_error(hex);
+  }
   int digest = 0, bank = 0, txk = 0, wit = 0;
   uint8_t key[16];
   CHECK(r0h_ebics_check_digest(e, &digest));

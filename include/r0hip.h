@@ -306,6 +306,13 @@ const char* r0h_ebics_verify_bank_signature(const r0h_ebics* e, const char* pub_
 /* raw_block: the RSA-decrypted transaction key with its padding ("<xml>-TransactionKeyDecrypt.bin"); key_out: the AES key in it */
 const char* r0h_ebics_check_transaction_key(const r0h_ebics* e, const char* pub_client_pem, size_t pem_len, const uint8_t* raw_block,
                                             size_t raw_len, uint8_t key_out[16], int* ok_out);
+/* the two private-key steps of the script (checkResponse.sh:231-236, 276-279; `openssl pkeyutl -decrypt / -sign`): the raw
+ * RSA-decrypted transaction key block ("<xml>-TransactionKeyDecrypt.bin") with the AES key in it, and the witness signature as the
+ * `xxd -p` text of "<xml>-Witness.hex" (free with r0h_free_error).  PKCS#8 or PKCS#1 PEM; plain square-and-multiply, not constant
+ * time: a tool for the key's owner, as the openssl command line in the script is. */
+const char* r0h_ebics_decrypt_transaction_key(const r0h_ebics* e, const char* client_private_pem, size_t pem_len, uint8_t* raw_out,
+                                              size_t raw_capacity, size_t* raw_len_out, uint8_t key_out[16], int* ok_out);
+const char* r0h_ebics_witness_sign(const r0h_ebics* e, const char* witness_private_pem, size_t pem_len, char** hex_out);
 const char* r0h_ebics_verify_witness(const r0h_ebics* e, const char* pub_witness_pem, size_t pem_len, const char* witness_hex,
                                      size_t hex_len, int* ok_out);
 /* AES-128-CBC (zero IV) -> RFC 1950 inflate -> ZIP members; an error means the key or the data is wrong */

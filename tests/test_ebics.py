@@ -153,3 +153,31 @@ def test_preprocess_cli_writes_the_files_the_host_reads(tmp_path):
     out = subprocess.run(swapped, capture_output=True, text=True)
     assert out.returncode == 1 and json.loads(out.stdout)["bank_signature"] is False and json.loads(out.stdout)["digest"] is True
     assert subprocess.run([cli, str(tmp_path / "missing.xml")], capture_output=True).returncode == 2
+
+
+def test_private_key_steps_reproduce_the_fixture_files(tmp_path):
+    """data/checkResponse.sh:231-236 and 276-279 (`openssl pkeyutl -decrypt ... rsa_padding_mode:none`, `-sign ... digest:sha256`) with
+    the reference's PRIVATE test keys (data/client.pem, data/witness.pem, copied as fixtures): the raw transaction-key block is
+    `<xml>-TransactionKeyDecrypt.bin` and the deterministic PKCS#1 v1.5 witness signature is `<xml>-Witness.hex`, byte for byte
+    (methods/guest/src/test_xmlparse.rs:89-136 is the same decryption inside the guest)."""
+    import json
+    import shutil
+    import subprocess
+    e = r0.Ebics(rd("response.xml"))
+    ok, raw, key = e.decrypt_transaction_key(rd("client.pem"))
+    assert ok is True and raw == rd("test.xml-TransactionKeyDecrypt.bin") and key == raw[-16:] and len(key) == 16
+    assert e.witness_sign(rd("witness.pem")) == rd("test.xml-Witness.hex")
+    assert e.verify_witness(rd("pub_witness.pem"), e.witness_sign(rd("witness.pem"))) is True
+    # the wrong private key does not give a padded block; a public key is not a private key
+    assert e.decrypt_transaction_key(rd("witness.pem"))[0] is False
+    with pytest.raises(r0.R0HipError, match="PRIVATE KEY"):
+        e.decrypt_transaction_key(rd("pub_client.pem"))
+    # the compiled pre-processor with the keys instead of the two files: the same six files
+    cli = os.path.join(ROOT, "hyperfridge-r0_amd", "r0h_preprocess")
+    xml = tmp_path / "test.xml"
+    shutil.copy(os.path.join(D, "response.xml"), xml)
+    out = subprocess.run([cli, str(xml), "--pub-bank", os.path.join(D, "pub_bank.pem"), "--pub-client", os.path.join(D, "pub_client.pem"), "--pub-witness", os.path.join(D, "pub_witness.pem"),
+                          "--client-key", os.path.join(D, "client.pem"), "--witness-key", os.path.join(D, "witness.pem"), "--out-dir", str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and json.loads(out.stdout)["ok"] is True, out.stdout + out.stderr
+    for name in ("authenticated", "SignedInfo", "SignatureValue", "OrderData", "TransactionKeyDecrypt.bin", "Witness.hex"):
+        assert (tmp_path / ("test.xml-" + name)).read_bytes() == rd("test.xml-" + name), name
