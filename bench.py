@@ -93,6 +93,8 @@ def spawn_ranks(script, argv, n, extra_env=None):
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+    import atexit
+    atexit.register(lambda: [p.kill() for p in procs if p.poll() is None])  # a parent that dies takes exactly its own ranks with it
     # a rank that dies before a barrier would leave its peers waiting in it (RCCL: until the watchdog's timeout): as soon as one
     # rank has failed, the others -- exactly the processes started above -- are ended
     while any(p.poll() is None for p in procs):

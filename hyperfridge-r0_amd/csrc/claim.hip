@@ -188,8 +188,9 @@ const char* r0h_receipt_verify_reason(int verdict) {
                                       "no control root known for a segment's trace size", "a segment carries no claim",
                                       "a seal's public inputs do not name its claim", "segments do not chain (index / post-state / exit code)",
                                       "the journal is not the one the last segment's claim commits to", "the first pre-state is not the expected image id",
-                                      "the final exit code is not Halted(0) or Paused(0)", "the circuit exposes fewer than 8 globals: claims cannot be bound"};
-  return verdict >= 0 && verdict <= R0H_RECEIPT_V_NO_BINDING ? names[verdict] : "unknown";
+                                      "the final exit code is not Halted(0) or Paused(0)", "the circuit exposes fewer than 8 globals: claims cannot be bound",
+                                      "a segment names a hash function other than poseidon2"};
+  return verdict >= 0 && verdict <= R0H_RECEIPT_V_HASHFN ? names[verdict] : "unknown";
 }
 
 // risc0-zkvm receipt/composite.rs `verify_integrity_with_context` + receipt/mod.rs `Receipt::verify(image_id)`
@@ -207,6 +208,7 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
   const size_t n = rc->segments.size();
   for (size_t i = 0; i < n; i++) {
     const r0h_receipt::Segment& g = rc->segments[i];
+    if (g.hashfn != "poseidon2") return done(R0H_RECEIPT_V_HASHFN, i);  // the only suite this prover and this verifier implement
     if (!g.has_claim) return done(R0H_RECEIPT_V_NO_CLAIM, i);
     // the seal names its trace size in its public part (globals, then po2): pick that size's control root, then verify bound to it
     if (g.seal.size() < (size_t)circ.n_global + 1 || g.seal[circ.n_global] >= P) {

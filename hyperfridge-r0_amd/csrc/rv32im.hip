@@ -57,6 +57,7 @@ struct r0h_vm {
   size_t input_pos = 0;
   std::vector<uint8_t> journal;
   uint64_t cycles = 0;  // user cycles (instructions) over the whole run
+  bool finished = false; // a run ended in HALT / PAUSE / the cycle limit: its segments are final
   std::vector<Segment> segments;
   // hashing caches
   uint8_t zero_level[N_PAGE_BITS + 1][32];
@@ -432,6 +433,8 @@ const char* r0h_vm_run(r0h_vm* vm, const r0h_vm_limits* limits, int* exit_kind, 
   R0H_GUARD_BEGIN
   R0H_REQUIRE(vm && limits && exit_kind && exit_code, "r0h_vm_run: NULL argument");
   R0H_REQUIRE(limits->segment_po2 >= 6 && limits->segment_po2 <= 24, "r0h_vm_run: segment_po2 %u outside [6, 24]", limits->segment_po2);
+  R0H_REQUIRE(!vm->finished, "r0h_vm_run: this machine has already run to its end (one run per r0h_vm: load a new one)");
+  vm->finished = true;
   Run run(*vm, *limits);
   run.begin_segment();
   *exit_kind = R0H_VM_LIMIT;

@@ -278,6 +278,7 @@ const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out);
 #define R0H_RECEIPT_V_IMAGE_ID 8
 #define R0H_RECEIPT_V_EXIT_CODE 9
 #define R0H_RECEIPT_V_NO_BINDING 10
+#define R0H_RECEIPT_V_HASHFN 11
 const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots,
                                size_t n_roots, const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out);
 const char* r0h_receipt_verify_reason(int verdict); /* static string, do not free */

@@ -146,6 +146,10 @@ def test_receipt_verification_rejects_what_the_reference_verifier_exists_to_reje
     foreign = c.prove(s["po2"], code, data, glob)
     v = ok(r0.Receipt.new(s["journal"], [foreign] + s["seals"][1:], s["claims"]))
     assert v[0] == 2 and v[2] == 0 and v[3] == 10
+    # a segment that claims another hash suite
+    other_suite = json.loads(r0.Receipt.new(s["journal"], s["seals"], s["claims"]).to_json())
+    other_suite["inner"]["Composite"]["segments"][1]["hashfn"] = "sha-256"
+    assert r0.Receipt.parse(json.dumps(other_suite)).verify(blob, roots, img)[:3] == (11, "a segment names a hash function other than poseidon2", 1)
     # a circuit that cannot name a claim
     tiny = np.fromfile(circuit_path("tiny"), dtype=np.uint32)
     assert r0.Receipt.new(s["journal"], s["seals"], s["claims"]).verify(tiny, roots, img)[0] == 10

@@ -305,6 +305,8 @@ def test_elf_loader():
     vm = r0.Vm()
     vm.load_elf(ehdr + phdr + code)
     assert vm.pc == entry and vm.run() == (0, 42) and vm.read(vaddr + len(code), 4).tolist() == [0, 0, 0, 0]
+    with pytest.raises(r0.R0HipError, match="already run"):
+        vm.run()
     for bad, why in [(b"\x7fELG" + bytes(60), "magic"), (ehdr[:18] + struct.pack("<H", 62) + ehdr[20:] + phdr + code, "RISC-V"), (ehdr + phdr[:16] + struct.pack("<I", 9999) + phdr[20:] + code, "malformed")]:
         with pytest.raises(r0.R0HipError, match=why):
             r0.Vm().load_elf(bad)
