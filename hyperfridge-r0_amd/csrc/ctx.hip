@@ -165,7 +165,8 @@ void ctx_release(r0h_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int d = 0; d < 2; d++) { (void)hipFree(ctx->tw_lo[d]); (void)hipFree(ctx->tw_hi[d]); (void)hipFree(ctx->tw12[d]); }
-  (void)hipFree(ctx->pow3_lo); (void)hipFree(ctx->pow3_hi); (void)hipFree(ctx->p2); (void)hipFree(ctx->scratch);
+  for (int d = 0; d < 2; d++) { (void)hipFree(ctx->twb_lo[d]); (void)hipFree(ctx->twb_hi[d]); }
+  (void)hipFree(ctx->pow3_lo); (void)hipFree(ctx->pow3_hi); (void)hipFree(ctx->pow3_top); (void)hipFree(ctx->p2); (void)hipFree(ctx->scratch);
   (void)hipHostFree(ctx->pinned);
   for (auto& kv : ctx->pool) (void)hipFree(kv.second);
   for (hipEvent_t e : ctx->prof.events) (void)hipEventDestroy(e);
@@ -205,13 +206,16 @@ const char* r0h_ctx_create(int device, r0h_ctx** out) {
   ctx->device = device;
   R0H_TRY_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (int d = 0; d < 2; d++) {
-    uint32_t w22 = d == 0 ? rou_fwd(MAX_DOMAIN_PO2) : rou_rev(MAX_DOMAIN_PO2);
+    uint32_t w22 = d == 0 ? rou_fwd(TW_TOP) : rou_rev(TW_TOP), w26 = d == 0 ? rou_fwd(MAX_DOMAIN_PO2) : rou_rev(MAX_DOMAIN_PO2);
+    R0H_TRY(upload_pow_table(&ctx->twb_lo[d], w26, TWB_SIZE));
+    R0H_TRY(upload_pow_table(&ctx->twb_hi[d], fpow(w26, TWB_SIZE), TWB_SIZE));
     R0H_TRY(upload_pow_table(&ctx->tw_lo[d], w22, TW_SIZE));
     R0H_TRY(upload_pow_table(&ctx->tw_hi[d], fpow(w22, TW_SIZE), TW_SIZE));
     R0H_TRY(upload_pow_table(&ctx->tw12[d], d == 0 ? rou_fwd(TWL_BITS) : rou_rev(TWL_BITS), 1u << (TWL_BITS - 1)));
   }
   R0H_TRY(upload_pow_table(&ctx->pow3_lo, enc(3), TW_SIZE));
   R0H_TRY(upload_pow_table(&ctx->pow3_hi, fpow(enc(3), TW_SIZE), TW_SIZE));
+  R0H_TRY(upload_pow_table(&ctx->pow3_top, fpow(enc(3), (uint64_t)1 << TW_TOP), 1u << (MAX_DOMAIN_PO2 - TW_TOP)));
   R0H_TRY_HIP(hipMalloc((void**)&ctx->p2, sizeof(P2Consts)));
   fill_p2(ctx->p2_host, R0H_P2_ROUND_CONSTANTS, R0H_P2_INT_DIAG_M1);
   R0H_TRY_HIP(hipMemcpy(ctx->p2, &ctx->p2_host, sizeof(P2Consts), hipMemcpyHostToDevice));

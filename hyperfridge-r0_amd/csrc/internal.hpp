@@ -42,8 +42,11 @@ constexpr int P2_PART_SIGMA_WORDS = (P2_PARTIAL - 1) * (P2_CELLS - 1) + (P2_PART
 constexpr uint32_t TW_BITS = 11;            // two-level twiddle tables of 2^11 entries each
 constexpr uint32_t TW_SIZE = 1u << TW_BITS;
 constexpr uint32_t TWL_BITS = 13;           // in-chunk twiddle table: ROU[13]^i, i < 2^12 (chunks of up to 2^13 words)
-constexpr uint32_t MAX_DOMAIN_PO2 = 22;
-constexpr size_t POOL_LIMIT = (size_t)48 << 30;  // one po2 = 20 segment parks about 8 GiB     // 2^R0H_MAX_PO2 rows x INV_RATE
+constexpr uint32_t TW_TOP = 22;             // the two-level tables hold powers of ROU[22]: every transform of the default segment size
+constexpr uint32_t TWB_BITS = 13;           // second table pair for domains above 2^22: powers of ROU[26], 2^13 entries each
+constexpr uint32_t TWB_SIZE = 1u << TWB_BITS;
+constexpr uint32_t MAX_DOMAIN_PO2 = 26;     // 2^R0H_MAX_PO2 rows x INV_RATE
+constexpr size_t POOL_LIMIT = (size_t)48 << 30;  // one po2 = 20 segment parks about 8 GiB; larger segments release what exceeds this
 
 // Device-resident Poseidon2 tables (Montgomery form).
 struct P2Consts {
@@ -85,8 +88,12 @@ struct r0h_ctx {
   uint32_t* tw_hi[2] = {nullptr, nullptr};
   // local table: tw12[d][i] = ROU[12]^i for i < 2048
   uint32_t* tw12[2] = {nullptr, nullptr};
+  // the same for w = ROU_{FWD,REV}[26] with 2^13 entries per level: outer pass of transforms above 2^22 points
+  uint32_t* twb_lo[2] = {nullptr, nullptr};
+  uint32_t* twb_hi[2] = {nullptr, nullptr};
   uint32_t* pow3_lo = nullptr;  // 3^i, i < 2^11
   uint32_t* pow3_hi = nullptr;  // 3^(i*2^11), i < 2^11 (covers exponents < 2^22)
+  uint32_t* pow3_top = nullptr; // 3^(i*2^22), i < 16 (exponents up to 2^26)
   r0h::P2Consts* p2 = nullptr;  // device
   r0h::P2Consts p2_host;
   void* scratch = nullptr;      // small device scratch for scans / partial sums

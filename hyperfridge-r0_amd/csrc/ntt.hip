@@ -9,18 +9,27 @@
 //            local DIFs with the 1/N normalisation folded into the final store.
 // The strided pass stages a [2^H][T] tile (T consecutive residues, 64-byte rows at T=16) so every global access is a
 // run of T words; the local pass moves whole contiguous chunks.  Column-major batches map to blockIdx.y.
+#include <algorithm>
+
 #include "internal.hpp"
 
 namespace r0h {
 
 struct TwTables {
-  const uint32_t* lo;    // w22^i
-  const uint32_t* hi;    // w22^(i << 11)
+  const uint32_t* lo;    // w22^i            (w26^i for the BIG kernels)
+  const uint32_t* hi;    // w22^(i << 11)    (w26^(i << 13))
   const uint32_t* tw12;  // ROU[TWL_BITS]^i, i < 2^(TWL_BITS - 1): the twiddles of every layer inside a contiguous chunk
 };
 
+// w_n^e from a two-level table: powers of ROU[22] (2 x 2^11 words) for n <= 22; BIG: powers of ROU[26] (2 x 2^13 words) for
+// the outer pass of larger transforms (the host hands over the matching table pair)
+template <int BIG = 0>
 __device__ __forceinline__ uint32_t omega_n(const TwTables& t, uint32_t e, uint32_t n) {
-  uint32_t E = e << (MAX_DOMAIN_PO2 - n);
+  if (BIG) {
+    const uint32_t E = e << (MAX_DOMAIN_PO2 - n);
+    return mul(t.lo[E & (TWB_SIZE - 1)], t.hi[E >> TWB_BITS]);
+  }
+  const uint32_t E = e << (TW_TOP - n);
   return mul(t.lo[E & (TW_SIZE - 1)], t.hi[E >> TW_BITS]);
 }
 
@@ -171,9 +180,9 @@ __device__ __forceinline__ uint32_t field_index(uint32_t rest0, int s, int j) {
 // Inter-pass twiddles of one thread: element e = q*16 + j needs w_n^(brev_H(e) * lo) with
 // brev_H(e) = brev_4(j) << (H-4) | brev_{H-4}(q), i.e. base * g^brev_4(j) with base = w_n^(brev(q) * lo), g = w_n^(lo << (H-4)):
 // four table words and 29 products per 16 elements instead of 32 table words and 16 products.
-template <uint32_t H>
+template <uint32_t H, int BIG>
 __device__ __forceinline__ void interpass_twiddles(uint32_t (&t)[16], const TwTables& tw, uint32_t q, uint32_t lo, uint32_t n) {
-  const uint32_t base = omega_n(tw, bitrev(q, H - 4) * lo, n), g = omega_n(tw, lo << (H - 4), n);
+  const uint32_t base = omega_n<BIG>(tw, bitrev(q, H - 4) * lo, n), g = omega_n<BIG>(tw, lo << (H - 4), n);
   uint32_t gp[16];  // base * g^k
   gp[0] = base;
 #pragma unroll
@@ -188,7 +197,8 @@ __device__ __forceinline__ void interpass_twiddles(uint32_t (&t)[16], const TwTa
 // 64-byte rows in a plain copy of the same shape (tools/microbench/tile_copy_bench.hip).  The tile has to stay small enough
 // for two blocks per CU (load, butterflies and store of different blocks overlap): H <= 9, i.e. the contiguous pass takes
 // up to 2^13 words.  LDS rows are padded by two words so that the four row groups of a wave fall into different banks.
-template <int WL, int DIR, int WORDS>
+// BIG: the rows are 2^L <= 2^18 words apart and the transform has more than 2^22 points (third level, see the host side).
+template <int WL, int DIR, int WORDS, int BIG = 0>
 __global__ __launch_bounds__(16 << (4 + WL)) void ntt_strided16_kernel(uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, TwTables tw, W16 c) {
   extern __shared__ uint32_t s[];
   constexpr uint32_t H = 8 + WL;
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(16 << (4 + WL)) void ntt_strided16_kernel(uint32_t*
 #pragma unroll
     for (int w = 0; w < WORDS; w++) {
       uint32_t tws[16];
-      interpass_twiddles<H>(tws, tw, q, lo + w, n);
+      interpass_twiddles<H, BIG>(tws, tw, q, lo + w, n);
 #pragma unroll
       for (int j = 0; j < 16; j++) x[w][j] = mul(x[w][j], tws[j]);
       field_layers<4, 0, 0, 0>(x[w], q, tw.tw12, c);
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(16 << (4 + WL)) void ntt_strided16_kernel(uint32_t*
     for (int w = 0; w < WORDS; w++) {
       field_layers<4, 0, 1, 0>(x[w], q, tw.tw12, c);
       uint32_t tws[16];
-      interpass_twiddles<H>(tws, tw, q, lo + w, n);
+      interpass_twiddles<H, BIG>(tws, tw, q, lo + w, n);
 #pragma unroll
       for (int j = 0; j < 16; j++) x[w][j] = mul(x[w][j], tws[j]);
     }
@@ -489,11 +499,13 @@ __global__ void bit_reverse_ext_kernel(uint4* io, uint32_t po2) {
   }
 }
 
-__global__ void zk_shift_kernel(uint32_t* io, uint32_t po2, const uint32_t* pow3_lo, const uint32_t* pow3_hi) {
+__global__ void zk_shift_kernel(uint32_t* io, uint32_t po2, const uint32_t* pow3_lo, const uint32_t* pow3_hi, const uint32_t* pow3_top) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t* col = io + ((size_t)blockIdx.y << po2);
   uint32_t e = bitrev(i, po2);
-  col[i] = mul(col[i], mul(pow3_lo[e & (TW_SIZE - 1)], pow3_hi[e >> TW_BITS]));
+  uint32_t s = mul(pow3_lo[e & (TW_SIZE - 1)], pow3_hi[(e >> TW_BITS) & (TW_SIZE - 1)]);
+  if (po2 > TW_TOP) s = mul(s, pow3_top[e >> TW_TOP]);
+  col[i] = mul(col[i], s);
 }
 
 struct Split {
@@ -514,15 +526,21 @@ static Split split_for(uint32_t n) {
 
 
 struct Split16 {
-  bool use16;       // radix-16 kernels apply
-  uint32_t L, H;    // contiguous chunk 2^L, strided 2^H (0 = single pass)
+  bool use16;      // radix-16 kernels apply
+  uint32_t L, H;   // contiguous chunk 2^L, strided 2^H (0 = single pass)
+  uint32_t outer;  // third level (domains above 2^23): a column is 2^outer blocks of 2^(L + H) words (0 = none)
 };
+// 2^16 .. 2^22: two passes (H = 8 or 9: two strided tiles per CU).  2^23: two passes with 2^10-row tiles (139 KB of LDS, one
+// block per CU).  2^24 .. 2^26 (segments of 2^22 .. 2^24 rows -- what 288 GB of HBM has room for): three levels.  A column's
+// 2^8 blocks of 2^16 .. 2^18 contiguous words are transformed like 2^8 columns by the two passes above, then one more strided
+// pass runs across the blocks (rows 2^(n-8) words apart, twiddles from the ROU[26] tables).
 static Split16 split16_for(uint32_t n) {
-  Split16 sp{false, n, 0};
+  Split16 sp{false, n, 0, 0};
   if (n >= 8 && n <= 12) { sp.use16 = true; return sp; }
   if (n >= 16 && n <= MAX_DOMAIN_PO2) {
     sp.use16 = true;
-    sp.H = n <= 20 ? 8 : 9;  // strided tiles of at most 2^9 rows (two blocks per CU); the contiguous pass takes up to 2^13 words
+    if (n > 23) { sp.outer = 8; n -= 8; }
+    sp.H = n <= 20 ? 8 : (n <= 22 ? 9 : 10);  // the contiguous pass takes up to 2^13 words
     sp.L = n - sp.H;
   }
   return sp;
@@ -535,64 +553,163 @@ static W16 make_w16(bool inverse) {
 }
 static size_t local16_lds_bytes(uint32_t L) { return (((size_t)1 << L) + ((size_t)1 << (L - 4))) * 4; }
 
+constexpr size_t GRID_Y_MAX = 32768;  // columns per launch (blockIdx.y): the blocks of large transforms count as columns
+
 template <int DIR, int EXP_BITS, int ZK = 0>
-static void launch_local16(r0h_ctx* ctx, uint32_t L, dim3 grid, uint32_t* out, const uint32_t* in, uint32_t n_out, const uint32_t* tw12, const W16& c, uint32_t scale,
-                           const ZkShift& zk = ZkShift{}) {
+static void launch_local16(r0h_ctx* ctx, uint32_t L, uint32_t blocks_x, size_t count, uint32_t* out, const uint32_t* in, uint32_t n_out, const uint32_t* tw12,
+                           const W16& c, uint32_t scale, const ZkShift& zk = ZkShift{}) {
   const size_t lds = local16_lds_bytes(L);
   const dim3 block(1u << (L - 4));
-  switch (L) {
-    case 8: hipLaunchKernelGGL((ntt_local16_kernel<0, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
-    case 9: hipLaunchKernelGGL((ntt_local16_kernel<1, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
-    case 10: hipLaunchKernelGGL((ntt_local16_kernel<2, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
-    case 11: hipLaunchKernelGGL((ntt_local16_kernel<3, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
-    case 12: hipLaunchKernelGGL((ntt_local16_kernel<4, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
-    default: hipLaunchKernelGGL((ntt_local16_kernel<5, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, out, in, n_out, tw12, c, scale, zk); break;
+  for (size_t c0 = 0; c0 < count; c0 += GRID_Y_MAX) {
+    const dim3 grid(blocks_x, (uint32_t)std::min(count - c0, GRID_Y_MAX));
+    uint32_t* o = out + (c0 << n_out);
+    const uint32_t* i = in + (c0 << (DIR == 0 ? n_out - EXP_BITS : n_out));
+    switch (L) {
+      case 8: hipLaunchKernelGGL((ntt_local16_kernel<0, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, o, i, n_out, tw12, c, scale, zk); break;
+      case 9: hipLaunchKernelGGL((ntt_local16_kernel<1, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, o, i, n_out, tw12, c, scale, zk); break;
+      case 10: hipLaunchKernelGGL((ntt_local16_kernel<2, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, o, i, n_out, tw12, c, scale, zk); break;
+      case 11: hipLaunchKernelGGL((ntt_local16_kernel<3, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, o, i, n_out, tw12, c, scale, zk); break;
+      case 12: hipLaunchKernelGGL((ntt_local16_kernel<4, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, o, i, n_out, tw12, c, scale, zk); break;
+      default: hipLaunchKernelGGL((ntt_local16_kernel<5, DIR, EXP_BITS, ZK>), grid, block, lds, ctx->stream, o, i, n_out, tw12, c, scale, zk); break;
+    }
   }
 }
-template <int WL, int DIR>
-static void launch_strided16_wl(r0h_ctx* ctx, dim3 grid, uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, const TwTables& tw, const W16& c) {
+constexpr size_t strided16_lds_bytes(uint32_t H) { return ((size_t)1 << H) * (16 * 2 + 2) * 4; }
+template <int WL, int DIR, int BIG>
+static void launch_strided16_wl(r0h_ctx* ctx, uint32_t blocks_x, size_t count, uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, const TwTables& tw,
+                                const W16& c) {
   constexpr uint32_t H = 8 + WL;
   const dim3 block(16u << (H - 4));
-  if (L >= 5) {  // two residues per thread: 128-byte rows
-    constexpr size_t lds = ((size_t)1 << H) * (16 * 2 + 2) * 4;
-    // tiles above 64 KB of LDS: the limit was raised for this device when its first context was created (ntt_init_device)
-    hipLaunchKernelGGL((ntt_strided16_kernel<WL, DIR, 2>), dim3(grid.x / 2, grid.y), block, lds, ctx->stream, io, in, n, L, tw, c);
-    return;
+  for (size_t c0 = 0; c0 < count; c0 += GRID_Y_MAX) {
+    const uint32_t cols = (uint32_t)std::min(count - c0, GRID_Y_MAX);
+    uint32_t* o = io + (c0 << n);
+    const uint32_t* i = in + (c0 << n);
+    if (L >= 5) {  // two residues per thread: 128-byte rows
+      // tiles above 64 KB of LDS: the limit was raised for this device when its first context was created (ntt_init_device)
+      hipLaunchKernelGGL((ntt_strided16_kernel<WL, DIR, 2, BIG>), dim3(blocks_x / 2, cols), block, strided16_lds_bytes(H), ctx->stream, o, i, n, L, tw, c);
+    } else {
+      hipLaunchKernelGGL((ntt_strided16_kernel<WL, DIR, 1, BIG>), dim3(blocks_x, cols), block, ((size_t)16 << H) * 4, ctx->stream, o, i, n, L, tw, c);
+    }
   }
-  hipLaunchKernelGGL((ntt_strided16_kernel<WL, DIR, 1>), grid, block, ((size_t)16 << H) * 4, ctx->stream, io, in, n, L, tw, c);
 }
-template <int DIR>
-static void launch_strided16(r0h_ctx* ctx, uint32_t H, dim3 grid, uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L, const TwTables& tw, const W16& c) {
+template <int DIR, int BIG>
+static void launch_strided16(r0h_ctx* ctx, uint32_t H, uint32_t blocks_x, size_t count, uint32_t* io, const uint32_t* in, uint32_t n, uint32_t L,
+                             const TwTables& tw, const W16& c) {
   switch (H) {
-    case 8: launch_strided16_wl<0, DIR>(ctx, grid, io, in, n, L, tw, c); break;
-    case 9: launch_strided16_wl<1, DIR>(ctx, grid, io, in, n, L, tw, c); break;
-    default: launch_strided16_wl<2, DIR>(ctx, grid, io, in, n, L, tw, c); break;
+    case 8: launch_strided16_wl<0, DIR, BIG>(ctx, blocks_x, count, io, in, n, L, tw, c); break;
+    case 9: launch_strided16_wl<1, DIR, BIG>(ctx, blocks_x, count, io, in, n, L, tw, c); break;
+    default: launch_strided16_wl<2, DIR, BIG>(ctx, blocks_x, count, io, in, n, L, tw, c); break;
   }
 }
 
 // Dynamic LDS above the 64 KB default has to be asked for per kernel instantiation and device.  Done for every instantiation
 // that needs it when a context is created (r0h_ctx_create, after hipSetDevice), so no launch can race the request and a
 // refusal is reported instead of surfacing later as "launch failed".
-template <int WL, int DIR>
+template <int WL, int DIR, int BIG>
 static const char* raise_lds_limit() {
-  constexpr size_t lds = ((size_t)1 << (8 + WL)) * (16 * 2 + 2) * 4;
+  constexpr size_t lds = strided16_lds_bytes(8 + WL);
   if (lds <= 65536) return nullptr;
-  R0H_TRY_HIP(hipFuncSetAttribute((const void*)ntt_strided16_kernel<WL, DIR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  R0H_TRY_HIP(hipFuncSetAttribute((const void*)ntt_strided16_kernel<WL, DIR, 2, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return nullptr;
 }
 const char* ntt_init_device() {
-  R0H_TRY((raise_lds_limit<0, 0>()));
-  R0H_TRY((raise_lds_limit<0, 1>()));
-  R0H_TRY((raise_lds_limit<1, 0>()));
-  R0H_TRY((raise_lds_limit<1, 1>()));
-  R0H_TRY((raise_lds_limit<2, 0>()));
-  R0H_TRY((raise_lds_limit<2, 1>()));
+  R0H_TRY((raise_lds_limit<0, 0, 0>()));
+  R0H_TRY((raise_lds_limit<0, 1, 0>()));
+  R0H_TRY((raise_lds_limit<1, 0, 0>()));
+  R0H_TRY((raise_lds_limit<1, 1, 0>()));
+  R0H_TRY((raise_lds_limit<2, 0, 0>()));
+  R0H_TRY((raise_lds_limit<2, 1, 0>()));
+  R0H_TRY((raise_lds_limit<0, 0, 1>()));
+  R0H_TRY((raise_lds_limit<0, 1, 1>()));
+  R0H_TRY((raise_lds_limit<1, 0, 1>()));
+  R0H_TRY((raise_lds_limit<1, 1, 1>()));
+  R0H_TRY((raise_lds_limit<2, 0, 1>()));
+  R0H_TRY((raise_lds_limit<2, 1, 1>()));
   return nullptr;
 }
 
 static const char* launch_check(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return make_error("%s: launch failed: %s", what, hipGetErrorString(e));
+  return nullptr;
+}
+
+static const char* zk_shift_cols(r0h_ctx* ctx, uint32_t* io, size_t count, uint32_t po2) {
+  const uint32_t threads = po2 >= 8 ? 256 : (1u << po2);
+  KScope ks(ctx, "zk_shift_kernel", 8.0 * count * (double)((size_t)1 << po2));
+  for (size_t c0 = 0; c0 < count; c0 += GRID_Y_MAX) {
+    const dim3 grid((1u << po2) / threads, (uint32_t)std::min(count - c0, GRID_Y_MAX));
+    hipLaunchKernelGGL(zk_shift_kernel, grid, dim3(threads), 0, ctx->stream, io + (c0 << po2), po2, ctx->pow3_lo, ctx->pow3_hi, ctx->pow3_top);
+  }
+  return launch_check("zk_shift_kernel");
+}
+
+// Radix-16 forward transform of `count` columns (bit-reversed coefficients, 2^(n - expand_bits) words apart at `in`; natural
+// evaluations, 2^n words apart at `out`); split16_for(n).use16 holds and expand_bits is 0 or 2.
+static const char* forward16(r0h_ctx* ctx, uint32_t* out, const uint32_t* in, size_t count, uint32_t n, uint32_t expand_bits) {
+  const Split16 sp = split16_for(n);
+  const W16 c = make_w16(false);
+  const TwTables tw{ctx->tw_lo[0], ctx->tw_hi[0], ctx->tw12[0]}, twb{ctx->twb_lo[0], ctx->twb_hi[0], ctx->tw12[0]};
+  const uint32_t n_in = n - sp.outer;       // what the first two levels transform
+  const size_t blocks = count << sp.outer;  // a column's blocks are contiguous on both sides: they are columns of the inner transform
+  const double words = (double)((size_t)1 << n);
+  {
+    KScope ks(ctx, "ntt_local_kernel", 4.0 * count * (words + (double)((size_t)1 << (n - expand_bits))));
+    if (expand_bits == 2) launch_local16<0, 2>(ctx, sp.L, 1u << (n_in - sp.L), blocks, out, in, n_in, tw.tw12, c, 0u);
+    else launch_local16<0, 0>(ctx, sp.L, 1u << (n_in - sp.L), blocks, out, in, n_in, tw.tw12, c, 0u);
+  }
+  R0H_TRY(launch_check("ntt_local16_kernel<fwd>"));
+  if (sp.H) {
+    KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * words);
+    if (n_in > TW_TOP) launch_strided16<0, 1>(ctx, sp.H, 1u << (sp.L - 4), blocks, out, out, n_in, sp.L, twb, c);
+    else launch_strided16<0, 0>(ctx, sp.H, 1u << (sp.L - 4), blocks, out, out, n_in, sp.L, tw, c);
+    R0H_TRY(launch_check("ntt_strided16_kernel<fwd>"));
+  }
+  if (sp.outer) {
+    KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * words);
+    launch_strided16<0, 1>(ctx, sp.outer, 1u << (n_in - 4), count, out, out, n, n_in, twb, c);
+    R0H_TRY(launch_check("ntt_strided16_kernel<fwd, outer>"));
+  }
+  return nullptr;
+}
+
+// The transpose: natural evaluations at `src` (may be `io`) -> bit-reversed coefficients at `io`, scaled by 1/2^n, f(x) -> f(3x) on request
+static const char* inverse16(r0h_ctx* ctx, uint32_t* io, const uint32_t* src, size_t count, uint32_t n, bool zk_shift) {
+  const Split16 sp = split16_for(n);
+  const W16 c = make_w16(true);
+  const TwTables tw{ctx->tw_lo[1], ctx->tw_hi[1], ctx->tw12[1]}, twb{ctx->twb_lo[1], ctx->twb_hi[1], ctx->tw12[1]};
+  const uint32_t n_in = n - sp.outer, norm = inv(enc(1u << n));
+  const size_t blocks = count << sp.outer;
+  const double words = (double)((size_t)1 << n);
+  const uint32_t* cur = src;
+  if (sp.outer) {
+    KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * words);
+    launch_strided16<1, 1>(ctx, sp.outer, 1u << (n_in - 4), count, io, cur, n, n_in, twb, c);
+    R0H_TRY(launch_check("ntt_strided16_kernel<inv, outer>"));
+    cur = io;
+  }
+  if (sp.H) {
+    KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * words);
+    if (n_in > TW_TOP) launch_strided16<1, 1>(ctx, sp.H, 1u << (sp.L - 4), blocks, io, cur, n_in, sp.L, twb, c);
+    else launch_strided16<1, 0>(ctx, sp.H, 1u << (sp.L - 4), blocks, io, cur, n_in, sp.L, tw, c);
+    R0H_TRY(launch_check("ntt_strided16_kernel<inv>"));
+    cur = io;
+  }
+  const bool fused_zk = zk_shift && !sp.outer && n <= TW_TOP;  // the fused form reads 3^e from the two 2^11-word tables
+  {
+    KScope ks(ctx, "ntt_local_kernel", 8.0 * count * words);
+    if (fused_zk) {
+      ZkShift zk{ctx->pow3_lo, ctx->pow3_hi, {0}};
+      const uint32_t g = fpow(enc(3), (uint64_t)1 << (n - 4));
+      uint32_t pw = ONE;
+      for (int k = 0; k < 16; k++) { zk.g[k] = pw; pw = mul(pw, g); }
+      launch_local16<1, 0, 1>(ctx, sp.L, 1u << (n_in - sp.L), blocks, io, cur, n_in, tw.tw12, c, norm, zk);
+    } else {
+      launch_local16<1, 0>(ctx, sp.L, 1u << (n_in - sp.L), blocks, io, cur, n_in, tw.tw12, c, norm);
+    }
+  }
+  R0H_TRY(launch_check("ntt_local16_kernel<inv>"));
+  if (zk_shift && !fused_zk) return zk_shift_cols(ctx, io, count, n);
   return nullptr;
 }
 
@@ -614,28 +731,9 @@ const char* interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, const r0h_buf* src, uint3
   R0H_REQUIRE(po2 >= 1 && po2 <= MAX_DOMAIN_PO2, "r0h_batch_interpolate_ntt: po2 %u outside [1, %u]", po2, MAX_DOMAIN_PO2);
   R0H_REQUIRE(((size_t)count << po2) * 4 <= io->bytes, "r0h_batch_interpolate_ntt: %u columns of 2^%u exceed the buffer", count, po2);
   if (!count) return nullptr;
+  if (split16_for(po2).use16) return inverse16(ctx, u32(io), u32(src), count, po2, zk_shift);
   const uint32_t norm = inv(enc(1u << po2));
   TwTables tw{ctx->tw_lo[1], ctx->tw_hi[1], ctx->tw12[1]};
-  const Split16 s16 = split16_for(po2);
-  if (s16.use16) {
-    const W16 c = make_w16(true);
-    if (s16.H) {
-      KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << po2));
-      launch_strided16<1>(ctx, s16.H, dim3(1u << (s16.L - 4), count), u32(io), u32(src), po2, s16.L, tw, c);
-      R0H_TRY(launch_check("ntt_strided16_kernel<inv>"));
-    }
-    KScope ks(ctx, "ntt_local_kernel", 8.0 * count * (double)(1u << po2));
-    if (zk_shift) {
-      ZkShift zk{ctx->pow3_lo, ctx->pow3_hi, {0}};
-      const uint32_t g = fpow(enc(3), (uint64_t)1 << (po2 - 4));
-      uint32_t cur = ONE;
-      for (int k = 0; k < 16; k++) { zk.g[k] = cur; cur = mul(cur, g); }
-      launch_local16<1, 0, 1>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), s16.H ? u32(io) : u32(src), po2, tw.tw12, c, norm, zk);
-    } else {
-      launch_local16<1, 0>(ctx, s16.L, dim3(1u << (po2 - s16.L), count), u32(io), s16.H ? u32(io) : u32(src), po2, tw.tw12, c, norm);
-    }
-    return launch_check("ntt_local16_kernel<inv>");
-  }
   if (src->ptr != io->ptr) R0H_TRY_HIP(hipMemcpyAsync(io->ptr, src->ptr, ((size_t)count << po2) * 4, hipMemcpyDeviceToDevice, ctx->stream));
   const Split sp = split_for(po2);
   if (sp.H) {
@@ -666,24 +764,9 @@ const char* r0h_batch_expand_into_evaluate_ntt(r0h_ctx* ctx, r0h_buf* out, const
               "r0h_batch_expand_into_evaluate_ntt: %u columns exceed the buffers", count);
   R0H_REQUIRE(out->ptr != in->ptr || expand_bits == 0, "r0h_batch_expand_into_evaluate_ntt: in-place expansion is not supported");
   if (!count) return nullptr;
+  if (split16_for(n).use16 && (expand_bits == 0 || expand_bits == 2)) return forward16(ctx, u32(out), u32(in), count, n, expand_bits);
+  R0H_REQUIRE(n <= TW_TOP, "r0h_batch_expand_into_evaluate_ntt: expand_bits %u is not supported above 2^%u points (0 or 2 are)", expand_bits, TW_TOP);
   TwTables tw{ctx->tw_lo[0], ctx->tw_hi[0], ctx->tw12[0]};
-  const Split16 s16 = split16_for(n);
-  if (s16.use16 && (expand_bits == 0 || expand_bits == 2)) {
-    const W16 c = make_w16(false);
-    {
-      KScope ks(ctx, "ntt_local_kernel", 4.0 * count * ((double)(1u << n) + (double)(1u << in_po2)));
-      dim3 grid(1u << (n - s16.L), count);
-      if (expand_bits == 2) launch_local16<0, 2>(ctx, s16.L, grid, u32(out), u32(in), n, tw.tw12, c, 0u);
-      else launch_local16<0, 0>(ctx, s16.L, grid, u32(out), u32(in), n, tw.tw12, c, 0u);
-    }
-    R0H_TRY(launch_check("ntt_local16_kernel<fwd>"));
-    if (s16.H) {
-      KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * (double)(1u << n));
-      launch_strided16<0>(ctx, s16.H, dim3(1u << (s16.L - 4), count), u32(out), u32(out), n, s16.L, tw, c);
-      R0H_TRY(launch_check("ntt_strided16_kernel<fwd>"));
-    }
-    return nullptr;
-  }
   const Split sp = split_for(n);
   R0H_REQUIRE(expand_bits < sp.L, "r0h_batch_expand_into_evaluate_ntt: expand_bits %u too large for size 2^%u", expand_bits, n);
   dim3 grid(1u << (n - sp.L), count);
@@ -746,11 +829,7 @@ const char* r0h_zk_shift(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2
   R0H_REQUIRE(po2 <= MAX_DOMAIN_PO2, "r0h_zk_shift: po2 %u too large", po2);
   R0H_REQUIRE(((size_t)count << po2) * 4 <= io->bytes, "r0h_zk_shift: %u columns of 2^%u exceed the buffer", count, po2);
   if (!count) return nullptr;
-  uint32_t threads = po2 >= 8 ? 256 : (1u << po2);
-  KScope ks(ctx, "zk_shift_kernel", 8.0 * count * (double)(1u << po2));
-  dim3 grid((1u << po2) / threads, count);
-  hipLaunchKernelGGL(zk_shift_kernel, grid, dim3(threads), 0, ctx->stream, u32(io), po2, ctx->pow3_lo, ctx->pow3_hi);
-  return launch_check("zk_shift_kernel");
+  return zk_shift_cols(ctx, u32(io), count, po2);
   R0H_GUARD_END
 }
 

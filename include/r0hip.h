@@ -36,8 +36,9 @@ extern "C" {
 #define R0H_GROUP_ACCUM 0
 #define R0H_GROUP_CODE 1
 #define R0H_GROUP_DATA 2
-#define R0H_MAX_PO2 20 /* trace rows of a segment (risc0's default segment size); the evaluation domain is 4x that, and the NTT
-                        * entry points take up to 2^22 points (the twiddle tables of a context cover exactly that) */
+#define R0H_MAX_PO2 24 /* trace rows of a segment: risc0's default segment size is 2^20, its largest 2^24.  The evaluation domain is
+                        * 4x that and the NTT entry points take up to 2^26 points: two passes up to 2^23, three above
+                        * (a 256-column segment of 2^22 rows keeps about 32 GiB resident, one of 2^24 rows about 128 GiB) */
 
 typedef struct r0h_ctx r0h_ctx;
 typedef struct r0h_buf r0h_buf;
