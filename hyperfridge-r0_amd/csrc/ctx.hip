@@ -149,7 +149,17 @@ const char* buf_alloc_pooled(r0h_ctx* ctx, size_t bytes, r0h_buf** out) {
     ctx->pool_bytes -= sz;
   } else {
     hipError_t e = hipMalloc(&b->ptr, sz);
+    if (e != hipSuccess && !ctx->pool.empty()) {
+      // out of memory with blocks of other sizes parked: give them back and try once more
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(ctx->stream);
+      for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+      ctx->pool.clear();
+      ctx->pool_bytes = 0;
+      e = hipMalloc(&b->ptr, sz);
+    }
     if (e != hipSuccess) {
+      (void)hipGetLastError();
       delete b;
       return make_error("device allocation of %zu bytes failed: %s", sz, hipGetErrorString(e));
     }

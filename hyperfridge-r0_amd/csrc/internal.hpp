@@ -46,7 +46,9 @@ constexpr uint32_t TW_TOP = 22;             // the two-level tables hold powers 
 constexpr uint32_t TWB_BITS = 13;           // second table pair for domains above 2^22: powers of ROU[26], 2^13 entries each
 constexpr uint32_t TWB_SIZE = 1u << TWB_BITS;
 constexpr uint32_t MAX_DOMAIN_PO2 = 26;     // 2^R0H_MAX_PO2 rows x INV_RATE
-constexpr size_t POOL_LIMIT = (size_t)48 << 30;  // one po2 = 20 segment parks about 8 GiB; larger segments release what exceeds this
+// Per context: one po2 = 20 segment parks about 8 GiB, one of 2^24 rows about 130 GiB.  What exceeds the limit is released on
+// free; an allocation the device refuses drains the context's own pool and is tried once more (buf_alloc_pooled).
+constexpr size_t POOL_LIMIT = (size_t)192 << 30;
 
 // Device-resident Poseidon2 tables (Montgomery form).
 struct P2Consts {

@@ -303,6 +303,29 @@ __global__ __launch_bounds__(16 << (4 + WL)) void ntt_strided16_kernel(uint32_t*
   }
 }
 
+// Third level of transforms above 2^23 points: the top four bits of the index -- 16 rows, 2^(n-4) words apart.  A thread owns one
+// residue: sixteen words, the inter-pass twiddles w_n^(brev_4(j) * lo) as powers of one table product, one radix-16 butterfly in
+// registers.  No LDS; every access of a wave is a 256-byte run per row, sixteen of them in flight per lane.
+template <int DIR>
+__global__ __launch_bounds__(256) void ntt_outer16_kernel(uint32_t* io, const uint32_t* in /* may alias io */, uint32_t n, TwTables twb, W16 c) {
+  const uint32_t L = n - 4, lo = blockIdx.x * 256 + threadIdx.x;
+  uint32_t* col = io + ((size_t)blockIdx.y << n) + lo;
+  const uint32_t* src = in + ((size_t)blockIdx.y << n) + lo;
+  uint32_t x[16], gp[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) x[j] = src[(size_t)j << L];
+  gp[0] = ONE;
+  gp[1] = omega_n<1>(twb, lo, n);
+#pragma unroll
+  for (int k = 2; k < 16; k++) gp[k] = mul_lazy(gp[k - 1], gp[1]);  // multipliers may stay below 2p
+  if (DIR == 1) field_layers<4, 0, 1, 0>(x, 0, twb.tw12, c);
+#pragma unroll
+  for (int j = 1; j < 16; j++) x[j] = mul(x[j], gp[((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3)]);
+  if (DIR == 0) field_layers<4, 0, 0, 0>(x, 0, twb.tw12, c);
+#pragma unroll
+  for (int j = 0; j < 16; j++) col[(size_t)j << L] = x[j];
+}
+
 __device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + (e >> 4); }
 
 // One contiguous chunk of 2^L words (L = 8 + WL) per block of 2^(L-4) threads.
@@ -531,15 +554,15 @@ struct Split16 {
   uint32_t outer;  // third level (domains above 2^23): a column is 2^outer blocks of 2^(L + H) words (0 = none)
 };
 // 2^16 .. 2^22: two passes (H = 8 or 9: two strided tiles per CU).  2^23: two passes with 2^10-row tiles (139 KB of LDS, one
-// block per CU).  2^24 .. 2^26 (segments of 2^22 .. 2^24 rows -- what 288 GB of HBM has room for): three levels.  A column's
-// 2^8 blocks of 2^16 .. 2^18 contiguous words are transformed like 2^8 columns by the two passes above, then one more strided
-// pass runs across the blocks (rows 2^(n-8) words apart, twiddles from the ROU[26] tables).
+// block per CU) and the ROU[26] tables.  2^24 .. 2^26 (segments of 2^22 .. 2^24 rows -- what 288 GB of HBM has room for): three
+// levels.  A column's 16 blocks of 2^20 .. 2^22 contiguous words are transformed like 16 columns by the two tuned passes above,
+// and one register-only radix-16 pass runs across the blocks (ntt_outer16_kernel).
 static Split16 split16_for(uint32_t n) {
   Split16 sp{false, n, 0, 0};
   if (n >= 8 && n <= 12) { sp.use16 = true; return sp; }
   if (n >= 16 && n <= MAX_DOMAIN_PO2) {
     sp.use16 = true;
-    if (n > 23) { sp.outer = 8; n -= 8; }
+    if (n > 23) { sp.outer = 4; n -= 4; }
     sp.H = n <= 20 ? 8 : (n <= 22 ? 9 : 10);  // the contiguous pass takes up to 2^13 words
     sp.L = n - sp.H;
   }
@@ -599,6 +622,14 @@ static void launch_strided16(r0h_ctx* ctx, uint32_t H, uint32_t blocks_x, size_t
     case 8: launch_strided16_wl<0, DIR, BIG>(ctx, blocks_x, count, io, in, n, L, tw, c); break;
     case 9: launch_strided16_wl<1, DIR, BIG>(ctx, blocks_x, count, io, in, n, L, tw, c); break;
     default: launch_strided16_wl<2, DIR, BIG>(ctx, blocks_x, count, io, in, n, L, tw, c); break;
+  }
+}
+
+template <int DIR>
+static void launch_outer16(r0h_ctx* ctx, size_t count, uint32_t* io, const uint32_t* in, uint32_t n, const TwTables& twb, const W16& c) {
+  for (size_t c0 = 0; c0 < count; c0 += GRID_Y_MAX) {
+    const dim3 grid((1u << (n - 4)) / 256, (uint32_t)std::min(count - c0, GRID_Y_MAX));
+    hipLaunchKernelGGL(ntt_outer16_kernel<DIR>, grid, dim3(256), 0, ctx->stream, io + (c0 << n), in + (c0 << n), n, twb, c);
   }
 }
 
@@ -666,9 +697,9 @@ static const char* forward16(r0h_ctx* ctx, uint32_t* out, const uint32_t* in, si
     R0H_TRY(launch_check("ntt_strided16_kernel<fwd>"));
   }
   if (sp.outer) {
-    KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * words);
-    launch_strided16<0, 1>(ctx, sp.outer, 1u << (n_in - 4), count, out, out, n, n_in, twb, c);
-    R0H_TRY(launch_check("ntt_strided16_kernel<fwd, outer>"));
+    KScope ks(ctx, "ntt_outer_kernel", 8.0 * count * words);
+    launch_outer16<0>(ctx, count, out, out, n, twb, c);
+    R0H_TRY(launch_check("ntt_outer16_kernel<fwd>"));
   }
   return nullptr;
 }
@@ -683,9 +714,9 @@ static const char* inverse16(r0h_ctx* ctx, uint32_t* io, const uint32_t* src, si
   const double words = (double)((size_t)1 << n);
   const uint32_t* cur = src;
   if (sp.outer) {
-    KScope ks(ctx, "ntt_strided_kernel", 8.0 * count * words);
-    launch_strided16<1, 1>(ctx, sp.outer, 1u << (n_in - 4), count, io, cur, n, n_in, twb, c);
-    R0H_TRY(launch_check("ntt_strided16_kernel<inv, outer>"));
+    KScope ks(ctx, "ntt_outer_kernel", 8.0 * count * words);
+    launch_outer16<1>(ctx, count, io, cur, n, twb, c);
+    R0H_TRY(launch_check("ntt_outer16_kernel<inv>"));
     cur = io;
   }
   if (sp.H) {
