@@ -48,6 +48,7 @@ _SIGNATURES = {
     "r0h_batch_expand_into_evaluate_ntt": [_vp, _vp, _vp, _u32, _u32, _u32],
     "r0h_batch_bit_reverse": [_vp, _vp, _u32, _u32],
     "r0h_zk_shift": [_vp, _vp, _u32, _u32],
+    "r0h_batch_interpolate_ntt_zk_shift": [_vp, _vp, _u32, _u32],
     "r0h_poseidon2_set_consts": [_vp, _vp, _vp],
     "r0h_hash_rows": [_vp, _vp, _vp, _u32, _u32],
     "r0h_hash_fold": [_vp, _vp, _u32],
@@ -786,6 +787,10 @@ class Hal:
 
     def zk_shift(self, io, count, po2):
         _check(lib().r0h_zk_shift(self.ctx, io.handle, count, po2))
+
+    def batch_interpolate_ntt_zk_shift(self, io, count, po2):
+        """batch_interpolate_ntt + zk_shift in one call (the shift fused into the transform's last pass)."""
+        _check(lib().r0h_batch_interpolate_ntt_zk_shift(self.ctx, io.handle, count, po2))
 
     def poseidon2_set_consts(self, rc, diag_m1):
         a, pa = _u32arr(rc)

@@ -334,7 +334,10 @@ __device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + (e >> 4); }
 struct ZkShift {        // optional fused f(x) -> f(3x) on the inverse transform's output
   const uint32_t* lo;   // 3^i, i < 2^11
   const uint32_t* hi;   // 3^(i << 11)
-  uint32_t g[16];       // 3^(k << (n - 4)), k < 16
+  const uint32_t* top;  // 3^(i << 22), i < 16
+  uint32_t outer;       // the columns are the 2^outer blocks of a larger transform (third level): block b of a column holds the
+                        // coefficients whose index ends in brev(b)
+  uint32_t g[16];       // 3^(k << (n - 4)), k < 16, n = log2 of the whole transform
 };
 
 template <int WL, int DIR, int EXP_BITS, int ZK>
@@ -445,9 +448,10 @@ __global__ __launch_bounds__(1 << (4 + (WL < 4 ? 4 : WL))) void ntt_local16_kern
     for (int j = 0; j < 16; j++) x[j] = s[lds_pad(q * 16 + j)];
     field_layers<4, 0, 1, 0>(x, q, tw12, c);
     if (ZK) {
-      // position p = base + 16 q + j holds the coefficient of x^brev_n(p), brev_n(p) = brev_n(base + 16 q) + (brev_4(j) << (n - 4))
-      const uint32_t e0 = bitrev(base + q * 16, n_out);
-      const uint32_t s0 = mul(scale, mul(zk.lo[e0 & (TW_SIZE - 1)], zk.hi[e0 >> TW_BITS]));
+      // position p = base + 16 q + j holds the coefficient of x^brev_n(p), brev_n(p) = brev_n(base + 16 q) + (brev_4(j) << (n - 4));
+      // as block b of a transform 2^outer times larger: x^(brev_n(p) << outer | brev_outer(b))
+      const uint32_t e0 = (bitrev(base + q * 16, n_out) << zk.outer) | bitrev((uint32_t)colid & ((1u << zk.outer) - 1u), zk.outer);
+      const uint32_t s0 = mul(scale, mul(mul(zk.lo[e0 & (TW_SIZE - 1)], zk.hi[(e0 >> TW_BITS) & (TW_SIZE - 1)]), zk.top[e0 >> TW_TOP]));
 #pragma unroll
       for (int j = 0; j < 16; j++) x[j] = mul(x[j], mul(s0, zk.g[((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3)]));
 #pragma unroll
@@ -726,11 +730,10 @@ static const char* inverse16(r0h_ctx* ctx, uint32_t* io, const uint32_t* src, si
     R0H_TRY(launch_check("ntt_strided16_kernel<inv>"));
     cur = io;
   }
-  const bool fused_zk = zk_shift && !sp.outer && n <= TW_TOP;  // the fused form reads 3^e from the two 2^11-word tables
   {
     KScope ks(ctx, "ntt_local_kernel", 8.0 * count * words);
-    if (fused_zk) {
-      ZkShift zk{ctx->pow3_lo, ctx->pow3_hi, {0}};
+    if (zk_shift) {  // fused into the last pass: no separate sweep over the coefficients
+      ZkShift zk{ctx->pow3_lo, ctx->pow3_hi, ctx->pow3_top, sp.outer, {0}};
       const uint32_t g = fpow(enc(3), (uint64_t)1 << (n - 4));
       uint32_t pw = ONE;
       for (int k = 0; k < 16; k++) { zk.g[k] = pw; pw = mul(pw, g); }
@@ -739,9 +742,7 @@ static const char* inverse16(r0h_ctx* ctx, uint32_t* io, const uint32_t* src, si
       launch_local16<1, 0>(ctx, sp.L, 1u << (n_in - sp.L), blocks, io, cur, n_in, tw.tw12, c, norm);
     }
   }
-  R0H_TRY(launch_check("ntt_local16_kernel<inv>"));
-  if (zk_shift && !fused_zk) return zk_shift_cols(ctx, io, count, n);
-  return nullptr;
+  return launch_check("ntt_local16_kernel<inv>");
 }
 
 }  // namespace r0h
@@ -751,6 +752,7 @@ using namespace r0h;
 extern "C" {
 
 const char* r0h_batch_interpolate_ntt(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2) { return r0h::interpolate_ntt(ctx, io, io, count, po2, false); }
+const char* r0h_batch_interpolate_ntt_zk_shift(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2) { return r0h::interpolate_ntt(ctx, io, io, count, po2, true); }
 
 }  // extern "C"
 

@@ -71,6 +71,9 @@ const char* r0h_batch_expand_into_evaluate_ntt(r0h_ctx* ctx, r0h_buf* out, const
 const char* r0h_batch_bit_reverse(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
 /* coefficient at bit-reversed position i is multiplied by 3^brev(i): f(x) -> f(3x) */
 const char* r0h_zk_shift(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
+/* `batch_interpolate_ntt` followed by `zk_shift` as the prover issues them (prove/prover.rs commit_group), in one call: the shift
+ * rides on the last pass of the inverse transform instead of sweeping the coefficients again.  Same words as the two calls. */
+const char* r0h_batch_interpolate_ntt_zk_shift(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t po2);
 
 /* ---- Hal: Poseidon2 Merkle commitment (`hash_rows`, `hash_fold`; prove/merkle.rs) ---- */
 /* rc: 24*29 canonical round constants, diag_m1: 24 canonical (mu_i - 1); the default table is compiled in */

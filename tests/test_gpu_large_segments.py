@@ -57,6 +57,16 @@ def test_bit_reverse_and_zk_shift_large(hal, orc, po2, count):
     assert np.array_equal(buf.to_host(), orc.zk_shift(x, count, po2))
 
 
+@pytest.mark.parametrize("po2,count", [(5, 3), (10, 2), (14, 2), (20, 2), (22, 1), (23, 2), (24, 2), (25, 1), (26, 1)])
+def test_interpolate_with_the_coset_shift_fused_equals_the_two_calls(hal, orc, po2, count):
+    """what the sequencer issues for every group: one-pass, two-pass, ROU[26]-table and three-level transforms all carry the shift"""
+    rng = np.random.default_rng(950 + po2)
+    x = rnd(rng, count << po2)
+    buf = hal.copy_from(x)
+    hal.batch_interpolate_ntt_zk_shift(buf, count, po2)
+    assert np.array_equal(buf.to_host(), orc.zk_shift(orc.batch_interpolate_ntt(x, count, po2), count, po2))
+
+
 def test_more_columns_than_one_launch_takes(hal, orc):
     """The blocks of a large transform count as columns of its inner passes, so launches are cut at 32,768 columns: the same cut
     with plain columns -- 33,000 of 2^8 (one pass) and of 2^16 (two passes) -- checked on columns either side of it."""
