@@ -186,11 +186,31 @@ struct Run {
   bool step(int* exit_kind, uint32_t* exit_code) {
     r0h_vm& m = vm;
     if (m.pc & 3) { err = "misaligned pc"; return false; }
-    // segment boundary: the next instruction (plus the worst case of one more page in and out) must still fit
-    if (cur.info.user_cycles + 1 + paging_cycles() + lim.page_in_cycles * 2 + lim.page_out_cycles > seg_budget) {
-      if (cur.info.user_cycles == 0) { err = "segment limit too small for a single instruction and its pages"; return false; }
-      end_segment(2, 0);  // SystemSplit
-      begin_segment();
+    // segment boundary: the next instruction and the pages it may bring in and write back must still fit.  An ordinary
+    // instruction touches its own page and one more (in and out); an I/O ecall touches every page of its buffer, so its span
+    // is priced before it runs (the word at pc is peeked without being charged to this segment yet).
+    uint64_t worst = (uint64_t)lim.page_in_cycles * 2 + lim.page_out_cycles;
+    bool io = false;
+    {
+      auto it = m.pages.find(m.pc >> PAGE_SHIFT);
+      const uint32_t peek = it == m.pages.end() ? 0u : it->second[(m.pc & (PAGE_BYTES - 1)) >> 2];
+      if (peek == 0x00000073u && (m.x[17] == 1 || m.x[17] == 2) && m.x[11] != 0) {
+        const uint64_t bytes = m.x[17] == 1 ? (uint64_t)m.x[11] * 4 : (uint64_t)m.x[11];
+        const uint64_t span = (((uint64_t)m.x[10] + bytes - 1) >> PAGE_SHIFT) - (m.x[10] >> PAGE_SHIFT) + 1;
+        worst = lim.page_in_cycles + span * ((uint64_t)lim.page_in_cycles + (m.x[17] == 1 ? lim.page_out_cycles : 0));
+        io = true;
+      }
+    }
+    if (cur.info.user_cycles + 1 + paging_cycles() + worst > seg_budget) {
+      if (cur.info.user_cycles != 0) {
+        end_segment(2, 0);  // SystemSplit
+        begin_segment();
+      }
+      if (1 + worst > seg_budget) {  // not even alone in a fresh segment
+        err = io ? "an I/O ecall spans more pages than one segment can pay for: transfer in smaller pieces or raise segment_po2"
+                 : "segment limit too small for a single instruction and its pages";
+        return false;
+      }
     }
     const uint32_t insn = load_word(m.pc);
     const uint32_t op = insn & 0x7f, rd = (insn >> 7) & 31, f3 = (insn >> 12) & 7, rs1 = (insn >> 15) & 31, rs2 = (insn >> 20) & 31, f7 = insn >> 25;

@@ -296,6 +296,38 @@ def test_segmenter_cuts_a_run_and_the_claims_chain_like_a_receipts(orc):
     assert rc.verify(blob, roots, other.segments()[0].pre.digest())[0] == 8  # another program's image id
 
 
+def test_an_io_ecall_is_priced_for_every_page_of_its_buffer():
+    """Found by tools/fuzz: a READ_WORDS or COMMIT touches every page of its buffer inside ONE instruction, so the segmenter has to
+    price the whole span before the ecall runs -- cut the segment first if it does not fit behind what is already there, and refuse a
+    transfer no segment of that size could pay for -- instead of assuming one page in and out per instruction."""
+    buf = 0x40000
+    def prog(n_words):
+        return flat([ADDI(T0, T0, 1)] * 40, LI(A0, buf), LI(A1, n_words), ADDI(A7, 0, 1), ECALL,   # 40 cheap cycles, then READ_WORDS(buf, n)
+                    LI(A0, buf), LI(A1, 4 * n_words), ADDI(A7, 0, 2), ECALL,                         # COMMIT(buf, 4 n)
+                    ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
+    def run(n_words, po2, cin, cout):
+        vm = r0.Vm()
+        vm.load(0x400, prog(n_words))
+        vm.set_pc(0x400)
+        vm.set_input(list(range(1, n_words + 1)))
+        return vm, vm.run(segment_po2=po2, page_in_cycles=cin, page_out_cycles=cout)
+    # 20 pages of 1 KiB: 20 * (8 + 8) = 320 cycles of paging for the read alone; a 2^9-cycle segment takes it only at its start
+    vm, (kind, code) = run(20 * 256, 9, 8, 8)
+    segs = vm.segments()
+    assert (kind, code) == (0, 0) and len(segs) >= 2 and vm.journal == struct.pack("<%dI" % (20 * 256), *range(1, 20 * 256 + 1))
+    for s in segs:
+        assert s.user_cycles + s.paging_cycles <= 1 << 9, (s.index, s.user_cycles, s.paging_cycles)
+    # the same transfer with dearer pages fits no segment of that size: reported, not silently over budget
+    with pytest.raises(r0.R0HipError, match="spans more pages"):
+        run(20 * 256, 9, 30, 30)
+    # and a count in the millions does not grind through memory first (the fuzzer's input: 33 M words)
+    vm = r0.Vm()
+    vm.load(0x1000, flat(LI(2, 0x02001000), ADDI(A1, 2, 4), ADDI(A7, 0, 1), ADDI(A0, 2, 0), ECALL))
+    vm.set_pc(0x1000)
+    with pytest.raises(r0.R0HipError, match="spans more pages"):
+        vm.run(segment_po2=10, page_in_cycles=16, page_out_cycles=16)
+
+
 def test_elf_loader():
     prog = flat(ADDI(A0, 0, 42), ADDI(A7, 0, 0), ECALL)
     code = struct.pack("<%dI" % len(prog), *prog)
