@@ -37,7 +37,7 @@ const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
       case R0H_SEC_TAPS: {
         R0H_REQUIRE(len >= 1 && len == 1 + 3 * (size_t)p[0], "circuit blob: TAPS length mismatch");
         c->taps.resize(p[0]);
-        memcpy(c->taps.data(), p + 1, 12 * (size_t)p[0]);
+        if (p[0]) memcpy(c->taps.data(), p + 1, 12 * (size_t)p[0]);
         break;
       }
       case R0H_SEC_GLOBALS:
@@ -50,22 +50,22 @@ const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
         R0H_REQUIRE(len >= 2 && len == 2 + 4 * (size_t)p[0], "circuit blob: POLY length mismatch");
         c->ret = p[1];
         c->steps.resize(p[0]);
-        memcpy(c->steps.data(), p + 2, 16 * (size_t)p[0]);
+        if (p[0]) memcpy(c->steps.data(), p + 2, 16 * (size_t)p[0]);
         break;
       case R0H_SEC_WITGEN: {
         R0H_REQUIRE(len >= 1 && len >= 2 + 2 * (size_t)p[0], "circuit blob: WITGEN too short");
         c->code_cols.resize(p[0]);
-        memcpy(c->code_cols.data(), p + 1, 8 * (size_t)p[0]);
+        if (p[0]) memcpy(c->code_cols.data(), p + 1, 8 * (size_t)p[0]);
         const uint32_t* q = p + 1 + 2 * (size_t)p[0];
         R0H_REQUIRE(len == 2 + 2 * (size_t)p[0] + 5 * (size_t)q[0], "circuit blob: WITGEN length mismatch");
         c->data_cols.resize(q[0]);
-        memcpy(c->data_cols.data(), q + 1, 20 * (size_t)q[0]);
+        if (q[0]) memcpy(c->data_cols.data(), q + 1, 20 * (size_t)q[0]);
         break;
       }
       case R0H_SEC_ACCUM:
         R0H_REQUIRE(len >= 1 && len == 1 + 3 * (size_t)p[0], "circuit blob: ACCUM length mismatch");
         c->acc_cols.resize(p[0]);
-        memcpy(c->acc_cols.data(), p + 1, 12 * (size_t)p[0]);
+        if (p[0]) memcpy(c->acc_cols.data(), p + 1, 12 * (size_t)p[0]);
         break;
       case R0H_SEC_INFO:
         R0H_REQUIRE(len == 4, "circuit blob: INFO must be 4 words");

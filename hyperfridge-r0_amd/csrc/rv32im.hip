@@ -410,9 +410,17 @@ const char* r0h_vm_load_elf(r0h_vm* vm, const uint8_t* elf, size_t n) {
     if (u32(ph) != 1) continue;  // PT_LOAD
     const uint32_t off = u32(ph + 4), vaddr = u32(ph + 8), filesz = u32(ph + 16), memsz = u32(ph + 20);
     R0H_REQUIRE((vaddr & 3) == 0 && filesz <= memsz && (uint64_t)off + filesz <= n && (uint64_t)vaddr + memsz <= ((uint64_t)1 << 32), "ELF: segment %u is malformed", i);
-    std::vector<uint32_t> words((memsz + 3) / 4, 0);
+    std::vector<uint32_t> words((filesz + 3) / 4, 0);
     for (uint32_t b = 0; b < filesz; b++) words[b / 4] |= (uint32_t)elf[off + b] << (8 * (b % 4));
     R0H_TRY(r0h_vm_load(vm, vaddr, words.data(), words.size()));
+    // [filesz, memsz) is .bss: memory nothing has touched reads as zero already, so only what an earlier segment put there is
+    // cleared -- a header may claim hundreds of megabytes, none of which need exist
+    const uint64_t z0 = (uint64_t)vaddr + 4 * (uint64_t)words.size(), z1 = (uint64_t)vaddr + memsz;
+    for (auto it = vm->pages.lower_bound((uint32_t)(z0 >> PAGE_SHIFT)); it != vm->pages.end() && ((uint64_t)it->first << PAGE_SHIFT) < z1; ++it) {
+      const uint64_t base = (uint64_t)it->first << PAGE_SHIFT;
+      for (uint32_t w = 0; w < PAGE_WORDS; w++)
+        if (base + 4 * w >= z0 && base + 4 * w < z1) it->second[w] = 0;
+    }
   }
   vm->pc = entry;
   return nullptr;

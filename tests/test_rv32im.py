@@ -339,6 +339,13 @@ def test_elf_loader():
     assert vm.pc == entry and vm.run() == (0, 42) and vm.read(vaddr + len(code), 4).tolist() == [0, 0, 0, 0]
     with pytest.raises(r0.R0HipError, match="already run"):
         vm.run()
+    # .bss is not materialised (a header may claim 369 MB: found by tools/fuzz), but it does clear what an earlier segment loaded there
+    big = struct.pack("<IIIIIIII", 1, 84 + 32, vaddr, vaddr, len(code), 0x1600004C, 5, 4)
+    two = ehdr[:44] + struct.pack("<H", 2) + ehdr[46:]
+    later = struct.pack("<IIIIIIII", 1, 84 + 32, vaddr + 0x2000, vaddr + 0x2000, len(code), len(code), 5, 4)
+    vm = r0.Vm()
+    vm.load_elf(two + later + big + code)   # first the small segment at +0x2000, then one whose .bss covers it
+    assert vm.read(vaddr, 3).tolist() == list(prog) and vm.read(vaddr + 0x2000, 3).tolist() == [0, 0, 0] and vm.run() == (0, 42)
     for bad, why in [(b"\x7fELG" + bytes(60), "magic"), (ehdr[:18] + struct.pack("<H", 62) + ehdr[20:] + phdr + code, "RISC-V"), (ehdr + phdr[:16] + struct.pack("<I", 9999) + phdr[20:] + code, "malformed")]:
         with pytest.raises(r0.R0HipError, match=why):
             r0.Vm().load_elf(bad)
