@@ -1,5 +1,6 @@
-"""BASELINE.json configs[2], [3] and [4] at their stated sizes, on the one GPU a test box has (the 8-GPU side of each is the
-driver's to run; the code path per rank is the one exercised here):
+"""BASELINE.json configs[0] and configs[2], [3], [4] at their stated sizes, on the one GPU a test box has (the 8-GPU side of each
+is the driver's to run; the code path per rank is the one exercised here; configs[1] is bench.py's default):
+  configs[0]  one 2^18-row segment, the size a CPU prover still runs                           -> device seal == CPU port's seal, word for word
   configs[2]  the same trace as ~64 segments at po2 = 20, sharded segment-parallel          -> bench.py --segments 64
   configs[3]  a batch of 32 independent receipts, throughput mode                            -> r0h_prove --receipts 32 --segments 2
   configs[4]  lift + join of segment receipts up a binary tree, ranks exchanging seals       -> tools/bench_recursion.py --gpus 2 (gloo, one GPU)
@@ -33,6 +34,23 @@ def bench_circuit(hal, orc):
     assert np.array_equal(oc.code_root(ocode, PO2), root)
     yield dict(blob=blob, oc=oc, root=root)
     gc.free()
+
+
+def test_config0_single_segment_at_po2_18_equals_the_cpu_port_word_for_word(hal, orc):
+    """configs[0] is the one size where both sides prove the full 256-column circuit: the CPU port (what bench.py times as
+    cpu_baseline) and the device produce the same 59,705 words, and the verifier accepts them bound to the control root."""
+    blob = np.fromfile(circuit_path("bench"), dtype=np.uint32)
+    gc = hal.load_circuit(blob, entry.code_object_path("bench"))
+    oc = orc.circuit(blob)
+    code, data, glob_ = hal.witgen(gc, 18, 1000)
+    seal = hal.prove_segment(gc, 18, code, data, glob_)
+    ocode, odata, oglob = oc.witgen(18, seed=1000)  # the sample bench.py's cpu_baseline proves
+    assert np.array_equal(oglob, glob_)
+    want = oc.prove(18, ocode, odata, oglob)
+    assert seal.size == want.size and np.array_equal(seal, want)
+    root = hal.code_root(gc, 18, code)
+    assert oc.verify(seal, code_root=root) == (0, "ok") and r0.verify_seal(blob, seal, code_root=root)[0] == 0
+    code.free(); data.free(); gc.free()
 
 
 def test_config2_fixed_batch_of_64_segments(tmp_path, bench_circuit):
