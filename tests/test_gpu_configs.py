@@ -1,6 +1,6 @@
 """BASELINE.json configs[0] and configs[2], [3], [4] at their stated sizes, on the one GPU a test box has (the 8-GPU side of each
-is the driver's to run; the code path per rank is the one exercised here; configs[1] is bench.py's default):
-  configs[0]  one 2^18-row segment, the size a CPU prover still runs                           -> device seal == CPU port's seal, word for word
+is the driver's to run; the code path per rank is the one exercised here; configs[1] is also bench.py's default):
+  configs[0]  one 2^18-row segment, the size a CPU prover still runs; configs[1] one 2^20-row segment -> device seal == CPU port's seal, word for word
   configs[2]  the same trace as ~64 segments at po2 = 20, sharded segment-parallel          -> bench.py --segments 64
   configs[3]  a batch of 32 independent receipts, throughput mode                            -> r0h_prove --receipts 32 --segments 2
   configs[4]  lift + join of segment receipts up a binary tree, ranks exchanging seals       -> tools/bench_recursion.py --gpus 2 (gloo, one GPU)
@@ -36,19 +36,21 @@ def bench_circuit(hal, orc):
     gc.free()
 
 
-def test_config0_single_segment_at_po2_18_equals_the_cpu_port_word_for_word(hal, orc):
-    """configs[0] is the one size where both sides prove the full 256-column circuit: the CPU port (what bench.py times as
-    cpu_baseline) and the device produce the same 59,705 words, and the verifier accepts them bound to the control root."""
+@pytest.mark.parametrize("po2,seed", [(18, 1000), (20, 1001)])
+def test_config0_and_config1_single_segment_equals_the_cpu_port_word_for_word(hal, orc, po2, seed):
+    """configs[0] (2^18 rows: the sample bench.py's cpu_baseline proves) and configs[1] (2^20 rows: the headline size, about
+    half a minute and 12 GiB for the CPU port on 16 threads): both sides prove the full 256-column circuit and produce the same
+    words -- 59,705 and 66,073 of them -- and both verifiers accept them bound to the control root."""
     blob = np.fromfile(circuit_path("bench"), dtype=np.uint32)
     gc = hal.load_circuit(blob, entry.code_object_path("bench"))
     oc = orc.circuit(blob)
-    code, data, glob_ = hal.witgen(gc, 18, 1000)
-    seal = hal.prove_segment(gc, 18, code, data, glob_)
-    ocode, odata, oglob = oc.witgen(18, seed=1000)  # the sample bench.py's cpu_baseline proves
+    code, data, glob_ = hal.witgen(gc, po2, seed)
+    seal = hal.prove_segment(gc, po2, code, data, glob_)
+    ocode, odata, oglob = oc.witgen(po2, seed=seed)
     assert np.array_equal(oglob, glob_)
-    want = oc.prove(18, ocode, odata, oglob)
+    want = oc.prove(po2, ocode, odata, oglob)
     assert seal.size == want.size and np.array_equal(seal, want)
-    root = hal.code_root(gc, 18, code)
+    root = hal.code_root(gc, po2, code)
     assert oc.verify(seal, code_root=root) == (0, "ok") and r0.verify_seal(blob, seal, code_root=root)[0] == 0
     code.free(); data.free(); gc.free()
 
