@@ -117,6 +117,29 @@ def spawn_ranks(script, argv, n, extra_env=None):
     return 0
 
 
+_RESULT_FD = None
+
+
+def guard_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries underneath write there too -- gloo announces its peers on std::cout,
+    RCCL prints its warnings to stdout, build steps chat -- so a process that is going to measure points descriptor 1 at stderr
+    for its whole life and keeps the real stdout for the result line alone (emit_result)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_result(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +167,7 @@ def main():
         entry.ensure_built()
         raise SystemExit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
+    guard_stdout()
     if args.rehearse_without_gpu > 0:
         return rehearse(args)
 
@@ -344,7 +368,7 @@ def main():
             "kernels_alg_GBs": {k: round(v["alg_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])
                                 if v["total_ms"] > 0 and v.get("alg_bytes")},
         }
-        print(json.dumps(line))
+        emit_result(line)
     for ln in lanes:
         for key in ("code", "data", "circuit"):
             ln[key].free()
@@ -369,9 +393,9 @@ def rehearse(args):
 
     elapsed, units = driver.run_timed(env, step, args.steps, args.warmup)
     if env.rank == 0:
-        print(json.dumps({"metric": "REHEARSAL of the multi-process harness -- no proving, not a measurement", "value": round(units / elapsed, 4),
-                          "unit": "sleeps/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
-                          "data": "none", "scaling": "weak"}))
+        emit_result({"metric": "REHEARSAL of the multi-process harness -- no proving, not a measurement", "value": round(units / elapsed, 4),
+                     "unit": "sleeps/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+                     "data": "none", "scaling": "weak"})
     env.close()
     return 0
 

@@ -101,6 +101,8 @@ def test_bench_py_gpus_n_starts_its_own_ranks():
     out, lines = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--contexts", "2", "--rehearse-without-gpu", "30")
     assert out.returncode == 0, out.stderr[-2000:]
     assert len(lines) == 1
+    # stdout carries that line and nothing else: what gloo (and RCCL) print to stdout themselves went to stderr (bench.guard_stdout)
+    assert out.stdout.strip().splitlines() == [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     d = lines[0]
     assert d["n_gpus"] == 2 and d["steps"] == 3 and "REHEARSAL" in d["metric"]
     assert 25.0 < d["ms_per_step"] < 200.0

@@ -37,6 +37,9 @@ def main():
         entry.ensure_built()
         raise SystemExit(bench.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
+    import bench
+    bench.guard_stdout()  # stdout carries the one result line; what gloo / RCCL print to stdout themselves goes to stderr
+
     import numpy as np
     import torch
 
@@ -96,13 +99,13 @@ def main():
         if args.root_out:
             np.save(args.root_out, node.seal)
         steps = len(recursion.tree_schedule(world))
-        print(json.dumps({
+        bench.emit_result({
             "metric": "lift+join tree over segment seals (configs[4] in shape; recursion-shaped circuit, see hyperfridge-r0_amd/recursion.py)",
             "n_gpus": world, "segments": args.segments, "segment_po2": args.segment_po2, "recursion_po2": args.recursion_po2,
             "prove_segments_s": round(t1 - t0, 4), "lift_and_local_fold_s": round(t2 - t1, 4), "cross_rank_joins_s": round(t3 - t2, 4),
             "cross_rank_join_steps": steps, "tree_latency_s": round(t3 - t1, 4), "end_to_end_s": round(t3 - t0, 4),
             "root_verifies": verdict[0] == 0, "root_seal_words": int(node.seal.size), "backend": args.backend if world > 1 else "none",
-            "data": "synthetic"}))
+            "data": "synthetic"})
     code.free(); data.free()
     rec.close(); seg.free()
     hal.close()
