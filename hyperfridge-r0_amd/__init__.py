@@ -133,6 +133,7 @@ _SIGNATURES = {
     "r0h_vm_run": [_vp, _vp, _c.POINTER(_c.c_int), _c.POINTER(_u32)],
     "r0h_vm_segment_info": [_vp, _sz, _vp],
     "r0h_vm_preflight": [_vp, _sz, _pp, _c.POINTER(_sz)],
+    "r0h_vm_trace_witness": [_vp, _sz, _u32, _vp, _vp],
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
     "r0h_prove_elf": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _pp, _vp, _c.POINTER(_u64)],
@@ -509,6 +510,10 @@ class ReceiptClaim(ctypes.Structure):
         return claim_globals(self.digest())
 
 
+TRACE_COLUMNS = 20  # R0H_TRACE_COLUMNS
+MEM_NONE, MEM_READ, MEM_WRITE = 0, 1, 2  # r0h_preflight_row.mem_kind
+
+
 class VmLimits(ctypes.Structure):
     _fields_ = [("segment_po2", _u32), ("page_in_cycles", _u32), ("page_out_cycles", _u32), ("keep_trace", _u32), ("max_cycles", _u64)]
 
@@ -579,6 +584,14 @@ class Vm:
             _check(lib().r0h_vm_segment_info(self.handle, i, ctypes.byref(s)))
             out.append(s)
         return out
+
+    def trace_witness(self, i, po2):
+        """DATA group of the trace circuit (20 columns x 2^po2, Montgomery words, column-major) from segment i's preflight rows, and
+        its three public inputs (r0h_vm_trace_witness)."""
+        data = np.zeros(TRACE_COLUMNS << po2, dtype=np.uint32)
+        glob = np.zeros(3, dtype=np.uint32)
+        _check(lib().r0h_vm_trace_witness(self.handle, i, po2, data.ctypes.data_as(_vp), glob.ctypes.data_as(_vp)))
+        return data, glob
 
     def preflight(self, i):
         p, n = _vp(), _sz(0)

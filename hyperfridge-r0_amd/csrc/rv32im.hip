@@ -502,6 +502,43 @@ const char* r0h_vm_preflight(const r0h_vm* vm, size_t i, const r0h_preflight_row
   *n = vm->segments[i].rows.size();
   return nullptr;
 }
+// The DATA group of the trace circuit (tools/gen_circuit.py trace: R0H_TRACE_COLUMNS columns of 2^po2 rows, column-major,
+// Montgomery words) from the preflight rows of segment i, and its three public inputs (first pc, pc after the last row, number of
+// rows).  Row r of the witness is cycle r of the segment; rows past the end are blank.  32-bit words enter as 16-bit halves where
+// the circuit only carries them, and reduced mod p where it does arithmetic on them (pc, addresses).
+const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint32_t* data_out, uint32_t globals_out[3]) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(vm && data_out && globals_out, "r0h_vm_trace_witness: NULL argument");
+  R0H_REQUIRE(i < vm->segments.size(), "r0h_vm_trace_witness: segment %zu of %zu", i, vm->segments.size());
+  const std::vector<r0h_preflight_row>& rows = vm->segments[i].rows;
+  R0H_REQUIRE(!rows.empty(), "r0h_vm_trace_witness: segment %zu has no preflight rows (run with keep_trace)", i);
+  R0H_REQUIRE(po2 <= R0H_MAX_PO2 && rows.size() <= ((size_t)1 << po2), "r0h_vm_trace_witness: %zu rows do not fit 2^%u", rows.size(), po2);
+  const size_t n = (size_t)1 << po2;
+  memset(data_out, 0, (size_t)R0H_TRACE_COLUMNS * n * 4);  // the Montgomery form of 0 is 0
+  auto put = [&](uint32_t col, size_t r, uint32_t v) { data_out[(size_t)col * n + r] = enc(v % P); };
+  for (size_t r = 0; r < rows.size(); r++) {
+    const r0h_preflight_row& w = rows[r];
+    put(0, r, 1);
+    put(1, r, (uint32_t)r);
+    put(2, r, w.pc);
+    put(3, r, w.next_pc);
+    put(4, r, w.next_pc == w.pc + 4 ? 1u : 0u);
+    put(5, r, w.insn & 0xffffu); put(6, r, w.insn >> 16);
+    put(7, r, w.rs1_value & 0xffffu); put(8, r, w.rs1_value >> 16);
+    put(9, r, w.rs2_value & 0xffffu); put(10, r, w.rs2_value >> 16);
+    put(11, r, w.rd);
+    put(12, r, w.rd_after & 0xffffu); put(13, r, w.rd_after >> 16);
+    put(14, r, w.mem_kind);
+    put(15, r, w.mem_addr);
+    put(16, r, w.mem_before & 0xffffu); put(17, r, w.mem_before >> 16);
+    put(18, r, w.mem_after & 0xffffu); put(19, r, w.mem_after >> 16);
+  }
+  globals_out[0] = enc(rows.front().pc % P);
+  globals_out[1] = enc(rows.back().next_pc % P);
+  globals_out[2] = enc((uint32_t)(rows.size() % P));
+  return nullptr;
+  R0H_GUARD_END
+}
 const char* r0h_vm_journal(const r0h_vm* vm, const uint8_t** bytes, size_t* n) {
   R0H_REQUIRE(vm && bytes && n, "r0h_vm_journal: NULL argument");
   *bytes = vm->journal.data();

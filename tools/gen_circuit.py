@@ -13,6 +13,7 @@ Shapes:
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
   recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
+  trace  W=(4, 4, 20)                       columns = the executor's preflight rows; constrains that they form one contiguous run
 """
 import argparse
 import struct
@@ -245,6 +246,92 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
     return words, info
 
 
+# ---- the trace circuit: columns ARE the executor's preflight rows (include/r0hip.h: r0h_preflight_row) --------------------------
+# Not the rv32im circuit (risc0's constrains every instruction's semantics; that tap table and polynomial are not reproducible
+# here): this one constrains what can be said without decoding -- the rows form ONE contiguous run.  Public inputs: first pc, pc
+# after the last row, number of rows.  Its witness comes from an execution (r0h_vm_trace_witness), not from a column program.
+TRACE_COLUMNS = ["live", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi", "rs1_lo", "rs1_hi", "rs2_lo", "rs2_hi", "rd", "rd_after_lo",
+                 "rd_after_hi", "mem_kind", "mem_addr", "mem_before_lo", "mem_before_hi", "mem_after_lo", "mem_after_hi"]
+
+
+def generate_trace():
+    col = {name: i for i, name in enumerate(TRACE_COLUMNS)}
+    n_data, n_code, n_acc, n_global = len(TRACE_COLUMNS), 4, 1, 3
+    code_cols = [(0, 0), (1, 0), (2, 0), (3, 3)]  # first-row indicator, last-row indicator, row index, one seeded column
+    data_cols = [(0, 0, 0, 0, 0)] * n_data        # all free: the witness is the caller's
+    acc_cols = [(0, col["pc"], col["cycle"])]     # one running product over (pc, cycle), gated like the synthetic ones
+    b = Builder()
+    for g, size in ((G_ACCUM, 4 * n_acc), (G_CODE, n_code), (G_DATA, n_data)):
+        for c in range(size):
+            b.taps.add((g, c, 0))
+
+    def d(name, back=0):
+        return b.get(G_DATA, col[name], back)
+
+    one, two, four = b.const(1), b.const(2), b.const(4)
+    first, last = b.get(G_CODE, 0, 0), b.get(G_CODE, 1, 0)
+    not_first = b.sub(one, first)
+    live, prev_live = d("live"), d("live", 1)
+    cons = []  # (fp var that must vanish on every row, degree)
+    cons.append((b.mul(live, b.sub(live, one)), 2))                                                     # live is a bit
+    cons.append((b.mul(d("is_seq"), b.sub(d("is_seq"), one)), 2))                                       # is_seq is a bit
+    cons.append((b.mul(b.mul(live, d("is_seq")), b.sub(d("next_pc"), b.add(d("pc"), four))), 3))        # sequential rows step by 4
+    gate = b.mul(not_first, live)                                                                       # a live row that has a predecessor
+    cons.append((b.mul(gate, b.sub(d("pc"), d("next_pc", 1))), 3))                                      # ... starts where that one went
+    cons.append((b.mul(gate, b.sub(d("cycle"), b.add(d("cycle", 1), one))), 3))                         # ... one cycle later
+    cons.append((b.mul(gate, b.sub(one, prev_live)), 3))                                                # ... and follows a live row (padding only at the end)
+    mk = d("mem_kind")
+    cons.append((b.mul(b.mul(mk, b.sub(mk, one)), b.sub(mk, two)), 3))                                  # none / read / write
+    rd_only = b.mul(mk, b.sub(two, mk))                                                                 # 1 on reads, 0 otherwise
+    cons.append((b.mul(rd_only, b.sub(d("mem_after_lo"), d("mem_before_lo"))), 3))                      # a read leaves the word as it was
+    cons.append((b.mul(rd_only, b.sub(d("mem_after_hi"), d("mem_before_hi"))), 3))
+    for name in ("pc", "next_pc", "cycle", "mem_kind"):                                                 # padding rows are blank
+        cons.append((b.mul(b.sub(one, live), d(name)), 2))
+    # public inputs: the run starts at pc0 in cycle 0; the row after the last live one (or the last row itself) pins the end
+    cons.append((b.mul(first, b.sub(live, one)), 2))
+    cons.append((b.mul(first, b.sub(d("pc"), b.glob(0, 0))), 2))
+    cons.append((b.mul(first, d("cycle")), 2))
+    ended = b.mul(not_first, b.sub(prev_live, live))                                                    # 1 on the first padding row
+    cons.append((b.mul(ended, b.sub(d("next_pc", 1), b.glob(0, 1))), 3))
+    cons.append((b.mul(ended, b.sub(b.add(d("cycle", 1), one), b.glob(0, 2))), 3))
+    full = b.mul(last, live)                                                                            # a trace that fills every row
+    cons.append((b.mul(full, b.sub(d("next_pc"), b.glob(0, 1))), 3))
+    cons.append((b.mul(full, b.sub(b.add(d("cycle"), one), b.glob(0, 2))), 3))
+    # the accumulator, exactly as in generate()
+    a, bb = d("pc"), d("cycle")
+    m0 = [b.glob(1, i) for i in range(4)]
+    m1 = [b.glob(1, 4 + i) for i in range(4)]
+    term = [b.add(m0[i], b.mul(m1[i], bb)) for i in range(4)]
+    term[0] = b.add(term[0], a)
+    prev = [b.get(G_ACCUM, i, 1) for i in range(4)]
+    sel = [b.mul(not_first, prev[i]) for i in range(4)]
+    sel[0] = b.add(sel[0], first)
+    want = fp4_mul_sym(b, term, sel)
+    cons.extend((b.sub(b.get(G_ACCUM, i, 0), want[i]), 3) for i in range(4))
+    assert max(deg for _, deg in cons) <= 5
+    x = b.true()
+    for v, _ in cons:
+        x = b.and_eqz(x, v)
+    taps = sorted(b.taps)
+    tap_index = {t: i for i, t in enumerate(taps)}
+    steps = [(op, tap_index[(a_[1], a_[2], a_[3])] if op == OP_GET else a_, b_, c_) for op, a_, b_, c_ in b.steps]
+
+    def section(tag, words):
+        return [tag, len(words)] + list(words)
+
+    words = [MAGIC, 1, 7]
+    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_TRACE:v1__")))
+    words += section(SEC_GROUPS, [4 * n_acc, n_code, n_data])
+    words += section(SEC_TAPS, [len(taps)] + [w for t in taps for w in t])
+    words += section(SEC_GLOBALS, [n_global, 8 * n_acc] + [col["pc"], col["next_pc"], col["cycle"]])
+    words += section(SEC_POLY, [len(steps), x] + [w for st in steps for w in st])
+    words += section(SEC_WITGEN, [n_code] + [w for cc in code_cols for w in cc] + [n_data] + [w for dc in data_cols for w in dc])
+    words += section(SEC_ACCUM, [n_acc] + [w for ac in acc_cols for w in ac])
+    info = {"taps": len(taps), "steps": len(steps), "constraints": len(cons), "mul_per_point": b.n_mul, "addsub_per_point": b.n_add,
+            "groups": [4 * n_acc, n_code, n_data], "columns": TRACE_COLUMNS}
+    return words, info
+
+
 SHAPES = {
     "tiny": dict(n_code=4, n_data=12, n_acc=2, n_free=4, n_pad=6, n_global=2, seed=1, comp=6),
     # 8 public inputs: enough to name a receipt claim (r0h_claim_globals), as `bench` can
@@ -258,10 +345,10 @@ SHAPES = {
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("shape", choices=sorted(SHAPES))
+    ap.add_argument("shape", choices=sorted(SHAPES) + ["trace"])
     ap.add_argument("out")
     args = ap.parse_args()
-    words, info = generate(**SHAPES[args.shape])
+    words, info = generate_trace() if args.shape == "trace" else generate(**SHAPES[args.shape])
     with open(args.out, "wb") as f:
         f.write(struct.pack("<%dI" % len(words), *words))
     print(args.shape, info, "words", len(words))
