@@ -91,7 +91,7 @@ def test_the_device_proves_an_execution_trace_word_for_word_like_the_cpu_port(ha
     CPU port's and accepted by both verifiers bound to the control root; a row that breaks the run is rejected."""
     vm, base = _run(n_loop)
     n = len(vm.preflight(0))
-    assert (1 << (po2 - 1)) < n <= (1 << po2)
+    assert (1 << (po2 - 2)) < n <= (1 << po2)
     data, glob = vm.trace_witness(0, po2)
     blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
     c = orc.circuit(blob)
