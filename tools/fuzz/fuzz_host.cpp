@@ -84,6 +84,14 @@ static void run_vm(r0h_vm* vm) {
     drop(r0h_vm_segment_info(vm, i, &seg));
     drop(r0h_vm_preflight(vm, i, &rows, &n));
     drop(r0h_vm_segment_claim(vm, i, &cl));
+    if (i == 0 && n > 0) {  // the trace circuit's witness from these rows
+      uint32_t po2 = 4;
+      while (((size_t)1 << po2) < n) po2++;
+      std::vector<uint32_t> w((size_t)R0H_TRACE_COLUMNS << po2);
+      uint32_t g[3];
+      drop(r0h_vm_trace_witness(vm, i, po2, w.data(), g));
+      drop(r0h_vm_trace_witness(vm, i, po2 - 1, w.data(), g));  // too small: an error, not an overrun
+    }
   }
   const uint8_t* j; size_t nj;
   drop(r0h_vm_journal(vm, &j, &nj));
