@@ -510,7 +510,7 @@ class ReceiptClaim(ctypes.Structure):
         return claim_globals(self.digest())
 
 
-TRACE_COLUMNS = 20  # R0H_TRACE_COLUMNS
+TRACE_COLUMNS = 58  # R0H_TRACE_COLUMNS
 MEM_NONE, MEM_READ, MEM_WRITE = 0, 1, 2  # r0h_preflight_row.mem_kind
 
 
@@ -586,7 +586,7 @@ class Vm:
         return out
 
     def trace_witness(self, i, po2):
-        """DATA group of the trace circuit (20 columns x 2^po2, Montgomery words, column-major) from segment i's preflight rows, and
+        """DATA group of the trace circuit (58 columns x 2^po2, Montgomery words, column-major) from segment i's preflight rows, and
         its three public inputs (r0h_vm_trace_witness)."""
         data = np.zeros(TRACE_COLUMNS << po2, dtype=np.uint32)
         glob = np.zeros(3, dtype=np.uint32)

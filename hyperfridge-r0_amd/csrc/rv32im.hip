@@ -532,6 +532,20 @@ const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint3
     put(15, r, w.mem_addr);
     put(16, r, w.mem_before & 0xffffu); put(17, r, w.mem_before >> 16);
     put(18, r, w.mem_after & 0xffffu); put(19, r, w.mem_after >> 16);
+    for (uint32_t k = 0; k < 32; k++) put(20 + k, r, (w.insn >> k) & 1u);
+  }
+  // opcode classes that may leave the sequential path, pinned both ways by an inverse: flag = 1 iff the opcode is the class's
+  // (blank rows past the end carry opcode 0 and therefore the inverses of -code)
+  const uint32_t codes[3] = {0x6f, 0x67, 0x63};
+  uint32_t inv_of[3][128];
+  for (int c = 0; c < 3; c++)
+    for (uint32_t op = 0; op < 128; op++) inv_of[c][op] = op == codes[c] ? 0u : inv(sub(enc(op), enc(codes[c])));
+  for (size_t r = 0; r < n; r++) {
+    const uint32_t op = r < rows.size() ? rows[r].insn & 0x7fu : 0u;
+    for (int c = 0; c < 3; c++) {
+      data_out[(size_t)(52 + c) * n + r] = op == codes[c] ? ONE : 0u;
+      data_out[(size_t)(55 + c) * n + r] = inv_of[c][op];
+    }
   }
   globals_out[0] = enc(rows.front().pc % P);
   globals_out[1] = enc(rows.back().next_pc % P);

@@ -383,11 +383,14 @@ uint64_t r0h_vm_cycles(const r0h_vm* vm);
 const char* r0h_vm_segment_info(const r0h_vm* vm, size_t i, r0h_vm_segment* out);
 const char* r0h_vm_preflight(const r0h_vm* vm, size_t i, const r0h_preflight_row** rows, size_t* n);
 /* Witness of the trace circuit (circuits/trace.r0c, tools/gen_circuit.py): the DATA group IS the preflight trace of segment i --
- * R0H_TRACE_COLUMNS columns of 2^po2 rows, column-major, Montgomery words, blank past the last row -- and the three public inputs
- * (first pc, pc after the last row, number of rows).  The circuit constrains that the rows form one contiguous run (each live
- * row starts where its predecessor went, one cycle later; sequential rows step by 4; reads leave memory unchanged; padding only at
- * the end); it does NOT decode instructions -- that is the rv32im circuit, which cannot be reproduced here. */
-#define R0H_TRACE_COLUMNS 20
+ * R0H_TRACE_COLUMNS columns of 2^po2 rows, column-major, Montgomery words, blank past the last row: the 20 fields of
+ * r0h_preflight_row (32-bit words as halves), the instruction word bit by bit, three opcode-class flags and their inverses -- and
+ * the three public inputs (first pc, pc after the last row, number of rows).  The circuit constrains that the rows form one
+ * contiguous run (each live row starts where its predecessor went, one cycle later; reads leave memory unchanged; padding only at
+ * the end) whose control flow follows the instruction words: a step leaves pc + 4 only at a JAL / JALR / branch word, JAL goes to
+ * pc + imm_J, a branch to pc + 4 or pc + imm_B.  Branch conditions, JALR targets, register and memory contents are NOT
+ * constrained -- that is the rv32im circuit, which cannot be reproduced here. */
+#define R0H_TRACE_COLUMNS 58
 const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint32_t* data_out, uint32_t globals_out[3]);
 const char* r0h_vm_journal(const r0h_vm* vm, const uint8_t** bytes, size_t* n);
 /* the ReceiptClaim of segment i: system states and exit code from the run, Output{journal} on the last segment */

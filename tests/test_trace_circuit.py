@@ -1,8 +1,10 @@
 """The trace circuit (tools/gen_circuit.py trace, circuits/trace.r0c): a circuit whose DATA group IS the executor's preflight
 trace (r0h_vm_trace_witness) -- the one place where what the prover commits to comes from an execution rather than from a
 synthetic column program.  It constrains that the rows form one contiguous run from the public
-first pc to the public last pc in the public number of cycles; it does not decode instructions (that is risc0's rv32im circuit,
-whose tap table and constraint polynomial cannot be reproduced here).  CPU only: the oracle proves, both verifiers check."""
+first pc to the public last pc in the public number of cycles, and that control flow follows the instruction words (a step
+leaves pc + 4 only at JAL / JALR / branch words; JAL and branches go where their immediates say).  Register and memory contents,
+branch conditions and JALR targets are risc0's rv32im circuit's business (its tap table and constraint polynomial cannot be
+reproduced here) and are not constrained.  The non-gpu tests prove with the oracle; both verifiers check."""
 import numpy as np
 import pytest
 
@@ -10,8 +12,13 @@ import hyperfridge_r0_amd as r0
 from conftest import circuit_path
 from test_rv32im import _guest
 
-COL = {name: i for i, name in enumerate(["live", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi", "rs1_lo", "rs1_hi", "rs2_lo", "rs2_hi", "rd",
-                                          "rd_after_lo", "rd_after_hi", "mem_kind", "mem_addr", "mem_before_lo", "mem_before_hi", "mem_after_lo", "mem_after_hi"])}
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from gen_circuit import TRACE_COLUMNS  # noqa: E402
+
+COL = {name: i for i, name in enumerate(TRACE_COLUMNS)}
+P = 2013265921
 
 
 def _run(n_loop=60):
@@ -32,7 +39,10 @@ def test_the_witness_is_the_preflight_trace(orc):
     data, glob = vm.trace_witness(0, po2)
     m = np.array([orc.dec(int(w)) for w in data], dtype=np.uint64).reshape(r0.TRACE_COLUMNS, 1 << po2)
     assert [orc.dec(int(g)) for g in glob] == [base, rows[-1].next_pc, n]
-    assert m[COL["live"]].tolist() == [1] * n + [0] * ((1 << po2) - n) and not m[:, n:].any()
+    assert m[COL["live"]].tolist() == [1] * n + [0] * ((1 << po2) - n)
+    assert not m[:COL["inv_jal"], n:].any()  # blank past the end, but for the inverses that pin opcode 0 to "no jump"
+    for k, code in enumerate((0x6F, 0x67, 0x63)):
+        assert (m[COL["inv_jal"] + k, n] * (P - code)) % P == 1
     for r in (0, 1, n // 2, n - 1):
         w = rows[r]
         assert (m[COL["pc"], r], m[COL["next_pc"], r], m[COL["cycle"], r]) == (w.pc, w.next_pc, r)
@@ -80,8 +90,54 @@ def test_an_execution_proves_and_an_altered_one_does_not(orc):
         g = glob.copy()
         g[k] = enc(wrong)
         assert rejected(data, g)
-    # what the circuit does not see, by design: the instruction words are carried, not decoded
-    assert not rejected(edit("insn_lo", mid, 0x1234), glob)
+    # control flow follows the instruction words
+    rows = vm.preflight(0)
+    br = next(r for r, w in enumerate(rows) if (w.insn & 0x7f) == 0x63 and w.next_pc != w.pc + 4)   # a taken branch
+    assert rejected(edit("is_branch", br, 0), glob)                   # ... cannot pass as an ordinary instruction
+    assert rejected(edit("bit0", br, 0), glob)                        # ... nor can its word be changed under it (halves and opcode pin the bits)
+    d2 = edit("next_pc", br, rows[br].pc + 8)                         # ... nor can it go anywhere but pc + 4 or pc + imm_B,
+    d2[COL["pc"] * N + br + 1] = enc(rows[br].pc + 8)                 #     even if the next row plays along
+    assert rejected(d2, glob)
+    alu = next(r for r, w in enumerate(rows) if (w.insn & 0x7f) == 0x13 and r > 4)
+    d3 = edit("next_pc", alu, rows[alu].pc + 8)                       # an ALU instruction that skips the next one
+    d3[COL["is_seq"] * N + alu] = enc(0)
+    d3[COL["pc"] * N + alu + 1] = enc(rows[alu].pc + 8)
+    assert rejected(d3, glob)
+    assert rejected(edit("is_jal", alu, 1), glob)                     # ... and cannot be flagged as a jump to get away with it
+    # what the circuit does not see, by design: what an instruction computes
+    assert not rejected(edit("rd_after_lo", alu, 0x1234), glob)
+
+
+def test_jumps_and_branches_of_every_kind_satisfy_the_control_flow_constraints(orc):
+    """JAL forwards and backwards, JALR, taken and untaken branches with positive and negative offsets (the loads / stores /
+    branches / jumps program of test_rv32im): the circuit accepts the genuine trace -- immediates are decoded as the ISA
+    encodes them."""
+    from test_rv32im import A0, A7, ADDI, ECALL, J, B, I, flat, T0, T1
+    prog = flat(ADDI(T0, 0, 3),
+                J(12, 1),                      # jal ra, +12  (skips two)
+                ADDI(T1, T1, 100), ADDI(T1, T1, 100),
+                ADDI(T0, T0, -1),              # loop:
+                B(8, 0, T0, 0),                # beq t0, x0, +8 -> out
+                J(-8, 0),                      # jal x0, loop
+                I(0, 1, 0, 5, 0x67),           # out: jalr t0, ra, 0 -> back to the two skipped instructions
+                ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
+    vm = r0.Vm()
+    vm.load(0x1000, prog)
+    vm.set_pc(0x1000)
+    try:
+        vm.run(segment_po2=20, keep_trace=True, max_cycles=200)
+    except r0.R0HipError:
+        pass  # wherever it ends, the rows so far are a run
+    rows = vm.preflight(0)
+    kinds = {w.insn & 0x7f for w in rows}
+    assert {0x6f, 0x67, 0x63} <= kinds and any(w.next_pc < w.pc for w in rows)
+    po2 = 9
+    data, glob = vm.trace_witness(0, po2)
+    blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
+    c = orc.circuit(blob)
+    code, _, _ = c.witgen(po2, 0)
+    seal = c.prove(po2, code, data, glob)
+    assert c.verify(seal, code_root=c.code_root(code, po2)) == (0, "ok")
 
 
 @pytest.mark.gpu

@@ -13,7 +13,7 @@ Shapes:
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
   recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
-  trace  W=(4, 4, 20)                       columns = the executor's preflight rows; constrains that they form one contiguous run
+  trace  W=(4, 4, 58)                       columns = the executor's preflight rows + instruction bits; one contiguous run, control flow per the words
 """
 import argparse
 import struct
@@ -248,10 +248,13 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
 
 # ---- the trace circuit: columns ARE the executor's preflight rows (include/r0hip.h: r0h_preflight_row) --------------------------
 # Not the rv32im circuit (risc0's constrains every instruction's semantics; that tap table and polynomial are not reproducible
-# here): this one constrains what can be said without decoding -- the rows form ONE contiguous run.  Public inputs: first pc, pc
-# after the last row, number of rows.  Its witness comes from an execution (r0h_vm_trace_witness), not from a column program.
-TRACE_COLUMNS = ["live", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi", "rs1_lo", "rs1_hi", "rs2_lo", "rs2_hi", "rd", "rd_after_lo",
-                 "rd_after_hi", "mem_kind", "mem_addr", "mem_before_lo", "mem_before_hi", "mem_after_lo", "mem_after_hi"]
+# here): this one constrains that the rows form ONE contiguous run whose control flow follows the instruction words -- it leaves
+# the sequential path only at JAL / JALR / branch words, and JAL and branches go where their immediates say.  Public inputs:
+# first pc, pc after the last row, number of rows.  Its witness comes from an execution (r0h_vm_trace_witness), not from a column program.
+TRACE_COLUMNS = (["live", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi", "rs1_lo", "rs1_hi", "rs2_lo", "rs2_hi", "rd", "rd_after_lo",
+                  "rd_after_hi", "mem_kind", "mem_addr", "mem_before_lo", "mem_before_hi", "mem_after_lo", "mem_after_hi"]
+                 + ["bit%d" % k for k in range(32)]                                   # the instruction word, bit by bit
+                 + ["is_jal", "is_jalr", "is_branch", "inv_jal", "inv_jalr", "inv_branch"])  # opcode classes and the inverses that pin them
 
 
 def generate_trace():
@@ -287,6 +290,39 @@ def generate_trace():
     cons.append((b.mul(rd_only, b.sub(d("mem_after_hi"), d("mem_before_hi"))), 3))
     for name in ("pc", "next_pc", "cycle", "mem_kind"):                                                 # padding rows are blank
         cons.append((b.mul(b.sub(one, live), d(name)), 2))
+    # --- control flow from the instruction word.  The word is decomposed into bits; the opcode classes that may leave the
+    # sequential path are flags pinned BOTH ways (flag * (op - code) = 0 and (op - code) * inv = 1 - flag: flag = 1 iff the opcode
+    # is that code); a live row may be non-sequential only under a flag, JAL goes to pc + imm_J, a branch to pc + 4 or pc + imm_B.
+    # (Branch conditions, JALR targets and everything the ALU does are the rv32im circuit's business and are not constrained.)
+    bits = [d("bit%d" % k) for k in range(32)]
+    for bk in bits:
+        cons.append((b.mul(bk, b.sub(bk, one)), 2))
+
+    def lin(terms):  # sum of coeff * var, coeff an integer (negative allowed)
+        acc = None
+        for coeff, v in terms:
+            t = v if coeff == 1 else b.mul(b.const(coeff % P), v)
+            acc = t if acc is None else b.add(acc, t)
+        return acc
+
+    cons.append((b.sub(d("insn_lo"), lin([(1 << k, bits[k]) for k in range(16)])), 1))
+    cons.append((b.sub(d("insn_hi"), lin([(1 << k, bits[16 + k]) for k in range(16)])), 1))
+    op = lin([(1 << k, bits[k]) for k in range(7)])
+    flags = []
+    for name, code in (("jal", 0x6F), ("jalr", 0x67), ("branch", 0x63)):
+        f, inv_ = d("is_" + name), d("inv_" + name)
+        diff = b.sub(op, b.const(code))
+        cons.append((b.mul(f, b.sub(f, one)), 2))
+        cons.append((b.mul(f, diff), 2))
+        cons.append((b.sub(b.mul(diff, inv_), b.sub(one, f)), 2))
+        flags.append(f)
+    jumpy = b.add(b.add(flags[0], flags[1]), flags[2])
+    cons.append((b.mul(b.mul(live, b.sub(one, d("is_seq"))), b.sub(one, jumpy)), 3))
+    step = b.sub(d("next_pc"), d("pc"))
+    imm_j = lin([(-(1 << 20), bits[31])] + [(1 << k, bits[k]) for k in range(12, 20)] + [(1 << 11, bits[20])] + [(1 << (k - 20), bits[k]) for k in range(21, 31)])
+    imm_b = lin([(-(1 << 12), bits[31]), (1 << 11, bits[7])] + [(1 << (k - 20), bits[k]) for k in range(25, 31)] + [(1 << (k - 7), bits[k]) for k in range(8, 12)])
+    cons.append((b.mul(flags[0], b.sub(step, imm_j)), 2))
+    cons.append((b.mul(b.mul(flags[2], b.sub(step, four)), b.sub(step, imm_b)), 3))
     # public inputs: the run starts at pc0 in cycle 0; the row after the last live one (or the last row itself) pins the end
     cons.append((b.mul(first, b.sub(live, one)), 2))
     cons.append((b.mul(first, b.sub(d("pc"), b.glob(0, 0))), 2))
