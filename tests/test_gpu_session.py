@@ -113,3 +113,40 @@ def test_response_to_verified_receipt(hal, orc, tmp_path):
         hal.prove_elf(tiny, elf, stream, segment_po2=11)
     gc.free()
     tiny.free()
+
+
+def test_every_segment_of_the_guest_run_proves_as_a_trace(hal, orc):
+    """The same run -- the stand-in guest over the input stream made from the reference's EBICS response -- cut into 2^11-cycle
+    segments with the preflight trace kept: each segment's rows go through the trace circuit (csrc/rv32im.hip
+    r0h_vm_trace_witness, circuits/trace.r0c) on the device.  The seals chain like the run does: a segment's public first pc is
+    its predecessor's public last pc, the cycle counts add up, and the CPU oracle's verifier accepts every one."""
+    eb = r0.Ebics(rd("response.xml"))
+    tx = rd("test.xml-TransactionKeyDecrypt.bin")
+    frames = eb.env_inputs(rd("pub_bank.pem"), "-----BEGIN PRIVATE KEY-----…", tx, "CH4308307000289537312", "host:main", rd("test.xml-Witness.hex", "r"),
+                           rd("pub_witness.pem"), "verbose")
+    stream = np.concatenate([[frames.size], frames]).astype(np.uint32)
+    elf, _, _ = stand_in_guest_elf()
+    vm = r0.Vm()
+    vm.load_elf(elf)
+    vm.set_input(stream)
+    assert vm.run(segment_po2=11, keep_trace=True) == (0, 0)
+    segs = vm.segments()
+    assert len(segs) >= 4
+    blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
+    c = orc.circuit(blob)
+    gc = hal.load_circuit(blob)
+    po2 = 11
+    code, synthetic, _ = hal.witgen(gc, po2, 0)
+    synthetic.free()
+    root = hal.code_root(gc, po2, code)
+    dev = hal.alloc(r0.TRACE_COLUMNS << po2)
+    publics = []
+    for k, s in enumerate(segs):
+        data, glob = vm.trace_witness(k, po2)
+        dev.upload(data)
+        seal = hal.prove_segment(gc, po2, code, dev, glob)
+        assert c.verify(seal, code_root=root) == (0, "ok"), k
+        publics.append([orc.dec(int(g)) for g in glob])
+        assert publics[-1] == [s.pre.pc, s.post.pc, s.user_cycles]
+    assert all(publics[k][1] == publics[k + 1][0] for k in range(len(segs) - 1)) and sum(p[2] for p in publics) == vm.cycles
+    code.free(); dev.free(); gc.free()
