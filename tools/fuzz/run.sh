@@ -14,7 +14,10 @@ for f in ebics rv32im receipt claim verify ctx circuit; do
     # circuit.hip (the blob parser and the code generator live there) carries kernels: its host stubs need the code object, so it
     # is compiled whole with the sanitizer on the host side only; the rest is host code
     if [ $f = circuit ]; then MODE="--offload-arch=gfx950 -fno-gpu-sanitize"; else MODE="--cuda-host-only"; fi
-    /opt/rocm/bin/hipcc $MODE $FLAGS -w -c "$src" -o "$WORK/obj/$f.o"
+    # field arithmetic (verifier, transcript, claims) gets edge counters only: libFuzzer's compare-tracing hooks slow it down a
+    # hundredfold and guide nothing there; the parsers keep them (magic numbers, lengths)
+    case $f in verify|ctx|claim) F=${FLAGS/fuzzer-no-link/} ; F="${F/-fsanitize=address,undefined,/-fsanitize=address,undefined} -fsanitize-coverage=inline-8bit-counters,pc-table" ;; *) F=$FLAGS ;; esac
+    /opt/rocm/bin/hipcc $MODE $F -w -c "$src" -o "$WORK/obj/$f.o"
   fi
 done
 # what these objects reference from the kernel translation units that are not part of this build (never reached without a GPU)
