@@ -53,7 +53,7 @@ def main():
     fixed = {}
     t0, n, rows_total, taken = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
-        prog = random_program(rng, int(rng.integers(40, 1500)))
+        prog = random_program(rng, int(rng.integers(40, 990)))  # the closing branch reaches back at most 4 KiB
         vm = r0.Vm()
         vm.load(0x1000, prog)
         vm.set_pc(0x1000)
