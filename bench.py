@@ -13,8 +13,8 @@ circuits/bench.r0c, W = (16 CODE, 192 DATA, 48 ACCUM) = 256 columns, 2^20 rows, 
 Extra objects on the JSON line:
   roofline      dominant kernel family (largest share of device time): algorithmic HBM bytes / its HIP-event time,
                 `traffic` = PMC-measured HBM bytes per launch (profiles/*/pmc_traffic.json, separate rocprofv3 --pmc passes)
-  cpu_baseline  the oracle (CPU restatement, OpenMP) proving the same circuit at a reduced po2, scaled to po2 = 20 by the
-                row ratio ("port": the risc0 CPU prover itself cannot be built here); rank 0, N = 1 only
+  cpu_baseline  the oracle (CPU restatement, OpenMP, every host core of the affinity mask) proving the same 2^20-row segment
+                ("port": the risc0 CPU prover itself cannot be built here); rank 0, N = 1 only
 """
 import argparse
 import glob
@@ -148,11 +148,13 @@ def main():
     ap.add_argument("--po2", type=int, default=20)
     ap.add_argument("--circuit", default="bench")
     ap.add_argument("--contexts", type=int, default=8, help="segments in flight per GPU (one context + host thread each)")
-    ap.add_argument("--cpu-po2", type=int, default=18, help="po2 of the bounded CPU-baseline sample: 18 = BASELINE.json configs[0] (0 disables)")
+    ap.add_argument("--cpu-po2", type=int, default=-1, help="po2 of the CPU-baseline sample: default = --po2 (the headline segment itself, about half a minute "
+                                                              "on 16 cores, no scaling); smaller = a bounded sample scaled by rows; 0 disables")
     ap.add_argument("--segments", type=int, default=0, help="BASELINE configs[2]/[3]: prove a fixed batch of this many segments, sharded "
                                                               "round-robin over the ranks (strong scaling); 0 = the default weak-scaling steps")
     ap.add_argument("--seal-dir", default="", help="with --segments: write the seal of every --keep-every-th segment there (seal_<index>.npy) for checking")
     ap.add_argument("--keep-every", type=int, default=8)
+    ap.add_argument("--recommit-code", action="store_true", help="commit the CODE group inside every proof (rounds 1-2 behaviour) instead of once per (circuit, po2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rehearsing ranks on one box)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--rehearse-without-gpu", type=float, default=0.0, metavar="MS",
@@ -189,6 +191,8 @@ def main():
     import hyperfridge_r0_amd as r0
 
     po2, n_ctx = args.po2, max(1, args.contexts)
+    if args.cpu_po2 < 0:
+        args.cpu_po2 = min(po2, 20)
     blob = np.fromfile(entry.circuit_blob_path(args.circuit), dtype=np.uint32)
     co = entry.code_object_path(args.circuit)
     lanes = []
@@ -199,11 +203,15 @@ def main():
         code, data, glob_ = hal.witgen(circuit, po2, seed=1000 + env.rank * 16 + k)
         hal.sync()
         lanes.append(dict(hal=hal, circuit=circuit, code=code, data=data, glob=glob_, seal_words=0))
+    # CODE depends on (circuit, po2) only (its Merkle root is the control root): committed once per rank, read by every lane's
+    # proofs (r0h_code_commit_new / r0h_prove_segment_committed) -- the seals are word for word those of r0h_prove_segment
+    code_commit = None if args.recommit_code else lanes[0]["hal"].code_commit(lanes[0]["circuit"], po2, lanes[0]["code"])
+    use_commit = [code_commit is not None]
 
     def prove_on(lane, seed=None, keep_as=None):
         if seed is not None:  # another segment: its witness is generated on the device, into the lane's buffers
             lane["glob"] = lane["hal"].witgen_into(lane["circuit"], po2, seed, lane["code"], lane["data"])
-        seal = lane["hal"].prove_segment(lane["circuit"], po2, lane["code"], lane["data"], lane["glob"])
+        seal = lane["hal"].prove_segment(lane["circuit"], po2, code_commit if use_commit[0] else lane["code"], lane["data"], lane["glob"])
         lane["seal_words"] = seal.size
         lane["proved"] = lane.get("proved", 0) + 1
         if keep_as is not None:
@@ -272,10 +280,16 @@ def main():
             for ln in lanes:
                 for idx, seal in ln.get("kept", []):
                     np.save(os.path.join(args.seal_dir, "seal_%04d.npy" % idx), seal)
-        incl = None
+        incl = uncached = None
     else:
         elapsed, units = driver.run_timed(env, step, args.steps, args.warmup, device_sync, many_fn=steps_back_to_back if n_ctx > 1 else None)
         scaling = "weak"
+        uncached = None
+        if code_commit is not None:  # the same K steps with CODE committed inside every proof, for comparison.  Not `value`.
+            use_commit[0] = False
+            el1, un1 = driver.run_timed(env, step, args.steps, 1, device_sync, many_fn=steps_back_to_back if n_ctx > 1 else None)
+            uncached = un1 / el1
+            use_commit[0] = True
         # the same K steps once more with witness generation inside the timed region (risc0's prove_segment includes it, SURVEY.md
         # 3.4 step 2): every segment gets a fresh synthetic witness, generated on the device into the lane's buffers.  Not `value`.
         counter = [0]
@@ -349,12 +363,14 @@ def main():
             "value": round(value, 4), "unit": "segments/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "value_with_witgen_in_timed_region": round(value, 4) if incl is None else round(incl, 4),
+            "value_with_code_committed_in_every_proof": None if uncached is None else round(uncached, 4),
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": ("configs[2] shape" if args.segments else "configs[1] shape") + ": 2^%d-row segments, synthetic circuit %s.r0c W=(%d code,%d data,%d accum), %d segment(s) "
                                    "in flight per GPU, %s; no bundled camt53 trace exists (needs the risc0 executor)" % (
                                        po2, args.circuit, circuit.group_size[1], circuit.group_size[2], circuit.group_size[0], n_ctx,
-                                       "fixed batch of %d distinct segments, witness generated on the device inside the timed region" % args.segments if args.segments
-                                       else "witness resident in HBM"),
+                                       ("fixed batch of %d distinct segments, witness generated on the device inside the timed region" % args.segments if args.segments
+                                        else "witness resident in HBM") + ("; CODE committed in every proof" if code_commit is None else
+                                                                            "; CODE commitment cached per (circuit, po2): committed once per rank before timing, read by every proof")),
                        "po2": po2, "columns": cols, "taps": circuit.n_taps, "seal_words": int(lanes[0]["seal_words"]),
                        "segments_per_step_per_gpu": n_ctx, "fixed_batch_segments": args.segments or None,
                        "parallelism": "segment-parallel x%d" % env.world},
@@ -369,6 +385,8 @@ def main():
                                 if v["total_ms"] > 0 and v.get("alg_bytes")},
         }
         emit_result(line)
+    if code_commit is not None:
+        code_commit.free()
     for ln in lanes:
         for key in ("code", "data", "circuit"):
             ln[key].free()
@@ -401,27 +419,60 @@ def rehearse(args):
 
 
 def cpu_baseline(blob, cpu_po2, po2):
-    """Oracle (CPU restatement) on a bounded sample: the same circuit at 2^cpu_po2 rows on the host cores."""
+    """Oracle (CPU restatement, OpenMP) proving the same circuit on every host core this process may run on.  At the default
+    (cpu_po2 == po2 == 20) it proves the headline-size segment itself -- no scaling -- and a 2^18-row segment (BASELINE.json
+    configs[0]) as a second sample; a smaller --cpu-po2 gives the bounded sample scaled by rows, labelled as such."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc_binding
     orc = orc_binding.load()
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 16)  # the GPU box's CPU share for one GPU
-    orc.L.orc_set_threads(cores)
+    quota = None  # the cgroup's CPU share, when one is set (a GPU box hands one GPU's job a slice of a many-core host)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
     oc = orc.circuit(blob)
-    code, data, glob_ = oc.witgen(cpu_po2, seed=1000)
-    t0 = time.perf_counter()
-    seal = oc.prove(cpu_po2, code, data, glob_)
-    dt = time.perf_counter() - t0
+    # every core this process may run on is offered to the port; because a box may expose more cores in the affinity mask than its
+    # share lets run at once, the thread count is calibrated on a small segment first and the fastest one is used (and printed)
+    candidates = sorted({avail, min(avail, quota or avail), min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True)
+    calib = {}
+    if len(candidates) > 1:
+        ccode, cdata, cglob = oc.witgen(14, seed=1)
+        for t in candidates:
+            orc.L.orc_set_threads(t)
+            t0 = time.perf_counter()
+            oc.prove(14, ccode, cdata, cglob)
+            calib[t] = round(time.perf_counter() - t0, 3)
+        cores = min(calib, key=calib.get)
+    else:
+        cores = candidates[0]
+    orc.L.orc_set_threads(cores)
+
+    def timed(p):
+        code, data, glob_ = oc.witgen(p, seed=1000)
+        t0 = time.perf_counter()
+        seal = oc.prove(p, code, data, glob_)
+        return time.perf_counter() - t0, seal.size
+
+    dt, words = timed(cpu_po2)
     scale = 1 << (po2 - cpu_po2)
-    return {"value": round(1.0 / (dt * scale), 6), "unit": "segments/s", "cores": cores, "kind": "port",
-            "sample": "oracle/liborc.so (C, OpenMP, %d threads) proved one 2^%d-row segment of the same circuit in %.2f s; scaled x%d by rows "
-                      "to 2^%d (favours the CPU: drops the log factor); seal %d words.  The risc0 CPU prover cannot be built here (Rust)." % (
-                          cores, cpu_po2, dt, scale, po2, seal.size)}
+    out = {"value": round(1.0 / (dt * scale), 6), "unit": "segments/s", "cores": cores, "kind": "port",
+           "cores_in_affinity_mask": avail, "cgroup_cpu_quota": quota, "thread_calibration_s_at_po2_14": calib or None,
+           "sample": "oracle/liborc.so (C, OpenMP) proved one 2^%d-row segment of the same circuit in %.2f s on %d threads (%d cores in the affinity "
+                     "mask, cgroup quota %s; the thread count is the fastest of a calibration over %s)%s; seal %d words.  The risc0 CPU prover cannot "
+                     "be built here (Rust)." % (cpu_po2, dt, cores, avail, quota, sorted(calib) or [cores],
+                                                "" if scale == 1 else "; scaled x%d by rows to 2^%d (favours the CPU: drops the log factor)" % (scale, po2), words)}
+    if scale == 1 and po2 > 18:
+        dt18, words18 = timed(18)
+        out["sample_po2_18"] = {"seconds": round(dt18, 3), "segments_per_s_at_po2_18": round(1.0 / dt18, 5), "seal_words": words18,
+                                "note": "BASELINE.json configs[0] size (one 2^18-row segment), same circuit, same threads"}
+    return out
 
 
 if __name__ == "__main__":

@@ -83,6 +83,11 @@ _SIGNATURES = {
     "r0h_verify_seal": [_vp, _sz, _vp, _vp, _vp, _sz, _c.POINTER(_c.c_int), _c.POINTER(_u32)],
     "r0h_verify_seal_bound": [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _c.POINTER(_c.c_int), _c.POINTER(_u32), _vp],
     "r0h_code_root": [_vp, _vp, _u32, _u32, _vp],
+    "r0h_code_commit_new": [_vp, _vp, _u32, _u32, _pp],
+    "r0h_code_commit_free": [_vp],
+    "r0h_code_commit_root": [_vp, _vp],
+    "r0h_prove_segment_committed": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)],
+    "r0h_proof_begin_committed": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _pp],
     "r0h_serde_encode_str": [_vp, _sz, _vp, _sz, _c.POINTER(_sz)],
     "r0h_serde_decode_str": [_vp, _sz, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_sz)],
     "r0h_journal_commitment_span": [_vp, _sz, _c.POINTER(_sz), _c.POINTER(_sz)],
@@ -245,6 +250,30 @@ class Circuit:
     def free(self):
         if self.handle:
             _check(lib().r0h_circuit_free(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CodeCommit:
+    """The CODE group of a circuit committed once for one trace size (r0h_code_commit_new): every proof of that size on any
+    context of the same device reads it instead of committing CODE again."""
+
+    def __init__(self, handle, po2):
+        self.handle, self.po2 = handle, po2
+
+    def root(self):
+        out = np.zeros(8, dtype=np.uint32)
+        _check(lib().r0h_code_commit_root(self.handle, out.ctypes.data_as(_vp)))
+        return out
+
+    def free(self):
+        if self.handle:
+            _check(lib().r0h_code_commit_free(self.handle))
             self.handle = None
 
     def __del__(self):
@@ -928,12 +957,28 @@ class Hal:
         return check
 
     def prove_segment(self, circuit, po2, code, data, glob, seal_capacity_words=1 << 20):
+        """code: the CODE witness columns (Buf) or their commitment (CodeCommit, r0h_prove_segment_committed) -- same seal."""
         g, pg = _u32arr(glob)
         seal = np.empty(seal_capacity_words, dtype=np.uint32)
         n = _sz(0)
-        _check(lib().r0h_prove_segment(self.ctx, circuit.handle, po2, code.handle, data.handle, pg,
-                                       seal.ctypes.data_as(_vp), seal.size, ctypes.byref(n)))
+        fn = lib().r0h_prove_segment_committed if isinstance(code, CodeCommit) else lib().r0h_prove_segment
+        _check(fn(self.ctx, circuit.handle, po2, code.handle, data.handle, pg, seal.ctypes.data_as(_vp), seal.size, ctypes.byref(n)))
         return seal[:n.value].copy()
+
+    def code_commit(self, circuit, po2, code=None):
+        """Commit the CODE group of `circuit` at 2^po2 rows once (r0h_code_commit_new).  Synthetic circuits regenerate their fixed
+        CODE columns; pass `code` for a circuit that brings its own."""
+        own = None
+        if code is None:
+            code, own, _ = self.witgen(circuit, po2, seed=0)
+        h = _vp()
+        try:
+            _check(lib().r0h_code_commit_new(self.ctx, code.handle, circuit.group_size[GROUP_CODE], po2, ctypes.byref(h)))
+        finally:
+            if own is not None:
+                own.free()
+                code.free()
+        return CodeCommit(h, po2)
 
     def code_root(self, circuit, po2, code=None):
         """Control root of the circuit at 2^po2 rows: Merkle root of its committed CODE group (r0h_code_root).  Synthetic
@@ -964,7 +1009,8 @@ class Hal:
         g, pg = _u32arr(glob)
         mix = np.zeros(max(circuit.n_mix, 1), dtype=np.uint32)
         h = _vp()
-        _check(lib().r0h_proof_begin(self.ctx, circuit.handle, po2, code.handle, data.handle, pg, mix.ctypes.data_as(_vp), ctypes.byref(h)))
+        fn = lib().r0h_proof_begin_committed if isinstance(code, CodeCommit) else lib().r0h_proof_begin
+        _check(fn(self.ctx, circuit.handle, po2, code.handle, data.handle, pg, mix.ctypes.data_as(_vp), ctypes.byref(h)))
         return h, mix[:circuit.n_mix]
 
     def proof_finish(self, proof, accum, seal_capacity_words=1 << 20):

@@ -8,6 +8,8 @@
 // segment: Merkle tops + roots (<= 2 KB each), ~500 tap evaluations, the FRI final polynomial (4 KB) and the 50
 // query openings (gathered on the device into one packed buffer per tree).  Upstream pulls the combos back to the
 // host for the DEEP division; here the division is a device scan (r0h_poly_divide).
+#include <memory>
+
 #include "circuit.hpp"
 
 namespace r0h {
@@ -211,6 +213,19 @@ __global__ void sub_head_kernel(uint32_t* __restrict__ combos, const uint32_t* _
 
 }  // namespace r0h
 
+// The committed CODE group of a program at one trace size: bit-reversed zk-shifted coefficients, evaluations on the 4N coset, Merkle
+// nodes, and the host copies of what a commit sends to the transcript (top layer, root).  CODE depends on (circuit, po2) only --
+// risc0 keeps one control root per po2 for exactly that reason -- so a prover commits it once and every segment of that size
+// reads it: three device buffers that no kernel of a proof writes.  Complete (stream-synchronised) when r0h_code_commit returns,
+// hence readable from any context of the same device.
+struct r0h_code_commit {
+  r0h_ctx* ctx = nullptr;
+  uint32_t count = 0, po2 = 0;
+  r0h_buf *coeffs = nullptr, *evaluated = nullptr, *nodes = nullptr;
+  std::vector<uint32_t> top;  // the top layer as tree_commit writes it to the seal
+  uint32_t root[8] = {0};
+};
+
 // A proof in flight between r0h_proof_begin (CODE and DATA committed, accumulation mix drawn) and r0h_proof_finish.
 // Mirrors risc0-zkp's `Prover` object between `commit_group(DATA)` and `finalize`.
 struct r0h_proof {
@@ -230,7 +245,7 @@ struct r0h_proof {
 
 namespace r0h {
 
-static const char* proof_begin(r0h_proof& st, const r0h_buf* code, const r0h_buf* data, const uint32_t* global) {
+static const char* proof_begin(r0h_proof& st, const r0h_buf* code, const r0h_code_commit* cc, const r0h_buf* data, const uint32_t* global) {
   r0h_ctx* ctx = st.ctx;
   const r0h_circuit* circ = st.circ;
   const uint32_t po2 = st.po2;
@@ -261,11 +276,21 @@ static const char* proof_begin(r0h_proof& st, const r0h_buf* code, const r0h_buf
     io.write(gv.data(), gv.size());
   }
 
-
-
   phase(ctx, "commit_code");
-  R0H_TRY(group_from_witness(ctx, sc, g_code, code, po2));
-  R0H_TRY(tree_commit(ctx, g_code.tree, io));
+  if (cc) {  // committed ahead of time: the group's buffers are the cache's (not this proof's to free), the transcript sees the same words
+    R0H_REQUIRE(cc->po2 == po2 && cc->count == g_code.count, "prove_segment: the CODE commitment is for %u columns of 2^%u rows, this proof needs %u of 2^%u",
+                cc->count, cc->po2, g_code.count, po2);
+    R0H_REQUIRE(cc->ctx->device == ctx->device, "prove_segment: the CODE commitment lives on device %d, this context on device %d", cc->ctx->device, ctx->device);
+    g_code.coeffs = cc->coeffs;
+    g_code.evaluated = cc->evaluated;
+    g_code.tree.nodes = cc->nodes;
+    g_code.tree.matrix = cc->evaluated;
+    io.write(cc->top.data(), cc->top.size());
+    io.commit(cc->root);
+  } else {
+    R0H_TRY(group_from_witness(ctx, sc, g_code, code, po2));
+    R0H_TRY(tree_commit(ctx, g_code.tree, io));
+  }
   phase(ctx, "commit_data");
   R0H_TRY(group_from_witness(ctx, sc, g_data, data, po2));
   R0H_TRY(tree_commit(ctx, g_data.tree, io));
@@ -507,10 +532,10 @@ using namespace r0h;
 
 extern "C" {
 
-const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
-                              const uint32_t* global, uint32_t* seal_out, size_t seal_cap, size_t* seal_words_out) {
+static const char* prove_segment_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_code_commit* cc,
+                                      const r0h_buf* data, const uint32_t* global, uint32_t* seal_out, size_t seal_cap, size_t* seal_words_out) {
   R0H_GUARD_BEGIN
-  R0H_REQUIRE(ctx && c && code && data && seal_words_out, "r0h_prove_segment: NULL argument");
+  R0H_REQUIRE(ctx && c && (code || cc) && data && seal_words_out, "r0h_prove_segment: NULL argument");
   R0H_REQUIRE(global || r0h_circuit_n_global(c) == 0, "r0h_prove_segment: global is NULL");
   R0H_REQUIRE(po2 >= 9 && po2 <= R0H_MAX_PO2, "r0h_prove_segment: po2 %u outside [9, %u]", po2, R0H_MAX_PO2);
   R0H_REQUIRE(c->has_column_program, "r0h_prove_segment: the circuit has no accumulation program; drive the per-op entry points with your own accum step");
@@ -520,7 +545,7 @@ const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, 
     CircuitView cv;
     circuit_view(c, &cv);
     r0h_proof st(ctx, c, po2, cv);
-    R0H_TRY(proof_begin(st, code, data, global));
+    R0H_TRY(proof_begin(st, code, cc, data, global));
     r0h_buf* accum = nullptr;
     R0H_TRY(st.sc.alloc(ctx, ((size_t)cv.group_size[R0H_GROUP_ACCUM] << po2) * 4, &accum));
     R0H_TRY(r0h_accum(ctx, c, po2, code, data, st.mix.data(), accum));
@@ -533,22 +558,90 @@ const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, 
   R0H_GUARD_END
 }
 
-const char* r0h_proof_begin(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
-                            const uint32_t* global, uint32_t* mix_out, r0h_proof** out) {
+static const char* proof_begin_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_code_commit* cc,
+                                    const r0h_buf* data, const uint32_t* global, uint32_t* mix_out, r0h_proof** out) {
   R0H_GUARD_BEGIN
-  R0H_REQUIRE(ctx && c && code && data && out, "r0h_proof_begin: NULL argument");
+  R0H_REQUIRE(ctx && c && (code || cc) && data && out, "r0h_proof_begin: NULL argument");
   R0H_REQUIRE((global || r0h_circuit_n_global(c) == 0) && (mix_out || r0h_circuit_n_mix(c) == 0), "r0h_proof_begin: NULL globals / mix_out");
   R0H_REQUIRE(po2 >= 9 && po2 <= R0H_MAX_PO2, "r0h_proof_begin: po2 %u outside [9, %u]", po2, R0H_MAX_PO2);
   R0H_TRY_HIP(hipSetDevice(ctx->device));
   CircuitView cv;
   circuit_view(c, &cv);
   r0h_proof* st = new r0h_proof(ctx, c, po2, cv);
-  const char* err = proof_begin(*st, code, data, global);
+  const char* err = proof_begin(*st, code, cc, data, global);
   if (err) { delete st; return err; }
   if (cv.n_mix) memcpy(mix_out, st->mix.data(), (size_t)cv.n_mix * 4);
   *out = st;
   return nullptr;
   R0H_GUARD_END
+}
+
+const char* r0h_prove_segment(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
+                              const uint32_t* global, uint32_t* seal_out, size_t seal_cap, size_t* seal_words_out) {
+  R0H_REQUIRE(code, "r0h_prove_segment: NULL argument");
+  return prove_segment_impl(ctx, c, po2, code, nullptr, data, global, seal_out, seal_cap, seal_words_out);
+}
+const char* r0h_prove_segment_committed(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_code_commit* code, const r0h_buf* data,
+                                        const uint32_t* global, uint32_t* seal_out, size_t seal_cap, size_t* seal_words_out) {
+  R0H_REQUIRE(code, "r0h_prove_segment_committed: NULL argument");
+  return prove_segment_impl(ctx, c, po2, nullptr, code, data, global, seal_out, seal_cap, seal_words_out);
+}
+
+const char* r0h_proof_begin(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
+                            const uint32_t* global, uint32_t* mix_out, r0h_proof** out) {
+  R0H_REQUIRE(code, "r0h_proof_begin: NULL argument");
+  return proof_begin_impl(ctx, c, po2, code, nullptr, data, global, mix_out, out);
+}
+const char* r0h_proof_begin_committed(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_code_commit* code, const r0h_buf* data,
+                                      const uint32_t* global, uint32_t* mix_out, r0h_proof** out) {
+  R0H_REQUIRE(code, "r0h_proof_begin_committed: NULL argument");
+  return proof_begin_impl(ctx, c, po2, nullptr, code, data, global, mix_out, out);
+}
+
+// Commit the CODE group once (same steps as the sequencer's commit_code) and keep it: see r0h_code_commit above.
+const char* r0h_code_commit_new(r0h_ctx* ctx, const r0h_buf* code, uint32_t count, uint32_t po2, r0h_code_commit** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(ctx && code && out, "r0h_code_commit_new: NULL argument");
+  R0H_REQUIRE(count >= 1, "r0h_code_commit_new: the CODE group has no columns");
+  R0H_REQUIRE(po2 >= 9 && po2 <= R0H_MAX_PO2, "r0h_code_commit_new: po2 %u outside [9, %u]", po2, R0H_MAX_PO2);
+  R0H_TRY_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<r0h_code_commit, const char* (*)(r0h_code_commit*)> cc(new r0h_code_commit(), r0h_code_commit_free);
+  cc->ctx = ctx; cc->count = count; cc->po2 = po2;
+  ctx_retain(ctx);
+  {
+    Scope sc;  // the group's buffers are taken out of the scope once everything has succeeded
+    Group g(count, (size_t)4 << po2);
+    R0H_TRY(group_from_witness(ctx, sc, g, code, po2));
+    WriteIop io(&ctx->p2_host);
+    R0H_TRY(tree_commit(ctx, g.tree, io));  // blocking read-back: the stream has drained when it returns
+    cc->top.swap(io.proof);
+    R0H_TRY(r0h_buf_d2h(ctx, g.tree.nodes, 32, cc->root, 32));
+    cc->coeffs = g.coeffs; cc->evaluated = g.evaluated; cc->nodes = g.tree.nodes;
+    sc.bufs.clear();
+    // long-lived and read from other contexts' streams: on release these go back to the device (hipFree waits for every stream),
+    // not into this context's stream-ordered pool
+    for (r0h_buf* b : {cc->coeffs, cc->evaluated, cc->nodes}) { b->pooled = false; b->owned = true; }
+  }
+  *out = cc.release();
+  return nullptr;
+  R0H_GUARD_END
+}
+const char* r0h_code_commit_free(r0h_code_commit* cc) {
+  if (!cc) return nullptr;
+  // a proof on another context may still be reading these buffers on its own stream: the caller frees a commitment only after
+  // the proofs that use it have returned (r0h_prove_segment_committed / r0h_proof_finish block until the seal is out)
+  if (cc->coeffs) r0h_buf_free(cc->coeffs);
+  if (cc->evaluated) r0h_buf_free(cc->evaluated);
+  if (cc->nodes) r0h_buf_free(cc->nodes);
+  r0h_ctx* ctx = cc->ctx;
+  delete cc;
+  if (ctx) ctx_release(ctx);
+  return nullptr;
+}
+const char* r0h_code_commit_root(const r0h_code_commit* cc, uint32_t root_out[8]) {
+  R0H_REQUIRE(cc && root_out, "r0h_code_commit_root: NULL argument");
+  memcpy(root_out, cc->root, 32);
+  return nullptr;
 }
 
 const char* r0h_proof_finish(r0h_proof* proof, const r0h_buf* accum, uint32_t* seal_out, size_t seal_cap, size_t* seal_words_out) {

@@ -90,6 +90,9 @@ int main(int argc, char** argv) {
     CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + k, ln.code, ln.data, ln.global.data()));
     ln.loaded = k;
   }
+  // CODE is the same for every segment of this circuit and size: committed once, read by every lane's proofs
+  r0h_code_commit* code_commit = nullptr;
+  CHECK(r0h_code_commit_new(lanes[0].ctx, lanes[0].code, r0h_circuit_group_size(lanes[0].circ, R0H_GROUP_CODE), po2, &code_commit));
   // the claims of every unit (receipt r, segment s): unit = r * segments + s
   std::vector<uint8_t> journal(journal_text.size() + 8);
   size_t jn = 0;
@@ -139,7 +142,7 @@ int main(int argc, char** argv) {
         CHECK(r0h_witgen(ln.ctx, ln.circ, po2, seed + u, ln.code, ln.data, ln.global.data()));
         ln.loaded = u;
       }
-      CHECK(r0h_prove_segment(ln.ctx, ln.circ, po2, ln.code, ln.data, ln.global.data(), ln.seal.data(), ln.seal.size(), &ln.words));
+      CHECK(r0h_prove_segment_committed(ln.ctx, ln.circ, po2, code_commit, ln.data, ln.global.data(), ln.seal.data(), ln.seal.size(), &ln.words));
       ln.proved++;
       (void)s;
       if (with_claims) ln.kept.emplace_back(u, std::vector<uint32_t>(ln.seal.begin(), ln.seal.begin() + ln.words));
@@ -171,7 +174,7 @@ int main(int argc, char** argv) {
     // the Receipt JSON `host` writes (host/src/main.rs:251-252, 299-316): all segment seals in order + the journal, which for the
     // hyperfridge guest is the serde word stream of the committed JSON string (host/src/main.rs:258-267)
     uint32_t root[8];
-    CHECK(r0h_code_root(lanes[0].ctx, lanes[0].code, r0h_circuit_group_size(lanes[0].circ, R0H_GROUP_CODE), po2, root));
+    CHECK(r0h_code_commit_root(code_commit, root));
     printf("{\"control_root\": {\"po2\": %u, \"root\": [%u, %u, %u, %u, %u, %u, %u, %u]}, \"image_ids\": [", po2, root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7]);
     for (unsigned r = 0; r < receipts; r++) printf("%s\"%s\"", r ? ", " : "", image_ids[r].c_str());
     printf("]}\n");
@@ -200,6 +203,7 @@ int main(int argc, char** argv) {
     if (!o || fwrite(l0.seal.data(), 4, l0.words, o) != l0.words) { fprintf(stderr, "r0h_prove: cannot write %s\n", seal_out.c_str()); return 1; }
     fclose(o);
   }
+  CHECK(r0h_code_commit_free(code_commit));
   for (Lane& ln : lanes) {
     CHECK(r0h_buf_free(ln.code));
     CHECK(r0h_buf_free(ln.data));

@@ -164,6 +164,20 @@ const char* r0h_proof_abort(r0h_proof* proof);
 /* Control root of a program at trace size 2^po2: Merkle root of the committed CODE group (count columns of 2^po2 words),
  * computed exactly as the sequencer commits it.  What a verifier passes to r0h_verify_seal_bound. */
 const char* r0h_code_root(r0h_ctx* ctx, const r0h_buf* code, uint32_t count, uint32_t po2, uint32_t root_out[8]);
+/* The CODE group depends on (circuit, po2) only -- its Merkle root is the control root risc0 tabulates per po2 -- so it is committed
+ * once and kept: bit-reversed zk-shifted coefficients, evaluations on the 4N coset, Merkle nodes, top layer and root.  Every proof of
+ * that size on any context of the same device reads it (nothing writes it), and its seal is word for word the seal of
+ * r0h_prove_segment on the same CODE columns.  r0h_code_commit_new blocks until the commitment is complete; free it only after
+ * the proofs that use it have returned.  r0h_prove_segment == r0h_code_commit_new + r0h_prove_segment_committed. */
+typedef struct r0h_code_commit r0h_code_commit;
+const char* r0h_code_commit_new(r0h_ctx* ctx, const r0h_buf* code, uint32_t count, uint32_t po2, r0h_code_commit** out);
+const char* r0h_code_commit_free(r0h_code_commit* cc);
+const char* r0h_code_commit_root(const r0h_code_commit* cc, uint32_t root_out[8]); /* == r0h_code_root of the same columns */
+const char* r0h_prove_segment_committed(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_code_commit* code,
+                                        const r0h_buf* data, const uint32_t* global_host, uint32_t* seal_out,
+                                        size_t seal_capacity_words, size_t* seal_words_out);
+const char* r0h_proof_begin_committed(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_code_commit* code,
+                                      const r0h_buf* data, const uint32_t* global_host, uint32_t* mix_out, r0h_proof** out);
 /* Per-phase device time of the last r0h_prove_segment on this context (ms), for bench.py; names are static strings. */
 const char* r0h_last_profile(r0h_ctx* ctx, const char*** names_out, const float** ms_out, uint32_t* n_out);
 

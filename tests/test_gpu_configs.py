@@ -50,6 +50,9 @@ def test_config0_and_config1_single_segment_equals_the_cpu_port_word_for_word(ha
     assert np.array_equal(oglob, glob_)
     want = oc.prove(po2, ocode, odata, oglob)
     assert seal.size == want.size and np.array_equal(seal, want)
+    cc = hal.code_commit(gc, po2, code)  # the form bench.py times: CODE committed once per (circuit, po2) -- the same words
+    assert np.array_equal(hal.prove_segment(gc, po2, cc, data, glob_), want)
+    cc.free()
     root = hal.code_root(gc, po2, code)
     assert oc.verify(seal, code_root=root) == (0, "ok") and r0.verify_seal(blob, seal, code_root=root)[0] == 0
     code.free(); data.free(); gc.free()
