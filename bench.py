@@ -84,17 +84,35 @@ def spawn_ranks(script, argv, n, extra_env=None):
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
+    import signal
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   R0H_PARENT_PID=str(os.getpid()))  # the rank asks the kernel to end it with this process (die_with_parent)
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+
+    # A parent that dies takes exactly its own ranks with it, however it dies: atexit covers an orderly exit; SIGTERM / SIGINT / SIGHUP
+    # (a harness time limit, a test's subprocess timeout) are caught and turned into "kill the ranks, exit non-zero"; SIGKILL cannot
+    # be caught, so every rank has also armed PR_SET_PDEATHSIG before touching torch or the GPU (die_with_parent).
+    def kill_ranks():
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+
     import atexit
-    atexit.register(lambda: [p.kill() for p in procs if p.poll() is None])  # a parent that dies takes exactly its own ranks with it
+    atexit.register(kill_ranks)
+
+    def on_signal(signum, _frame):
+        kill_ranks()
+        os._exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, on_signal)
     # a rank that dies before a barrier would leave its peers waiting in it (RCCL: until the watchdog's timeout): as soon as one
     # rank has failed, the others -- exactly the processes started above -- are ended
     while any(p.poll() is None for p in procs):
@@ -115,6 +133,48 @@ def spawn_ranks(script, argv, n, extra_env=None):
         sys.stderr.write("bench.py: rank(s) failed: %s\n" % ", ".join("rank %d exit %d" % rc for rc in bad))
         return 1
     return 0
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """Keep this rank's host threads (one lane thread per in-flight context, transcripts, launches) on the cores of the NUMA node
+    its GPU hangs off, when the PCI device's numa_node is readable and names a node whose cores this process may use; otherwise
+    leave the affinity as it is.  Eight ranks x eight lane threads on a two-socket host otherwise wander across sockets.
+    Returns a short description for the JSON line."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return "numa_node of %s is -1: affinity left as is" % bdf
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        usable = cpus & os.sched_getaffinity(0)
+        if not usable:
+            return "node %d has no core in this process's affinity mask: left as is" % node
+        os.sched_setaffinity(0, usable)  # the calling (main) thread; the lane threads started later inherit it
+        return "pinned to NUMA node %d of %s (%d cores)" % (node, bdf, len(usable))
+    except Exception as exc:  # noqa: BLE001 -- a sysfs layout we do not know is not an error
+        return "not pinned (%s)" % type(exc).__name__
+
+
+def die_with_parent():
+    """In a rank started by spawn_ranks, before any torch / HIP call: have the kernel send SIGKILL to this process when the parent
+    dies (prctl PR_SET_PDEATHSIG), and leave at once if the parent is already gone -- otherwise a rank orphaned inside a gloo / RCCL
+    barrier keeps its GPU until the collective's own timeout.  Nothing is re-exec'd."""
+    parent = os.environ.get("R0H_PARENT_PID")
+    if not parent:
+        return
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)  # PR_SET_PDEATHSIG = 1
+    except Exception:
+        pass
+    if os.getppid() != int(parent):  # the parent died between fork and prctl
+        os._exit(1)
 
 
 _RESULT_FD = None
@@ -169,6 +229,7 @@ def main():
         entry.ensure_built()
         raise SystemExit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
+    die_with_parent()
     guard_stdout()
     if args.rehearse_without_gpu > 0:
         return rehearse(args)
@@ -184,6 +245,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    numa = pin_to_gpu_numa_node(local_rank) if args.gpus > 1 and not args.share_device else "single rank: affinity left as is"
     env = driver.DistEnv(backend=args.backend, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     if env.world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, env.world))
@@ -373,7 +435,7 @@ def main():
                                                                             "; CODE commitment cached per (circuit, po2): committed once per rank before timing, read by every proof")),
                        "po2": po2, "columns": cols, "taps": circuit.n_taps, "seal_words": int(lanes[0]["seal_words"]),
                        "segments_per_step_per_gpu": n_ctx, "fixed_batch_segments": args.segments or None,
-                       "parallelism": "segment-parallel x%d" % env.world},
+                       "parallelism": "segment-parallel x%d" % env.world, "host_threads": "rank 0: " + numa},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline(blob, args.cpu_po2, po2) if (args.cpu_po2 and env.world == 1) else None,
             "segment_hbm_model": {"alg_bytes_per_segment": seg_bytes, "achieved_GBs_per_gpu": round(seg_bytes * value / env.world / 1e9, 2),

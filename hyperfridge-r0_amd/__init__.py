@@ -104,6 +104,8 @@ _SIGNATURES = {
     "r0h_receipt_segment_claim": [_vp, _sz, _vp, _c.POINTER(_c.c_int)],
     "r0h_receipt_verify": [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_c.c_int), _c.POINTER(_sz), _c.POINTER(_c.c_int)],
     "r0h_sha256": [_vp, _sz, _vp],
+    "r0h_image_id_from_hex": [_cp, _vp],
+    "r0h_image_id_to_hex": [_vp, _vp],
     "r0h_tagged_struct": [_cp, _vp, _sz, _vp, _sz, _vp],
     "r0h_system_state_digest": [_vp, _vp],
     "r0h_output_digest": [_vp, _sz, _vp, _vp],
@@ -139,6 +141,11 @@ _SIGNATURES = {
     "r0h_vm_segment_info": [_vp, _sz, _vp],
     "r0h_vm_preflight": [_vp, _sz, _pp, _c.POINTER(_sz)],
     "r0h_vm_trace_witness": [_vp, _sz, _u32, _vp, _vp],
+    "r0h_vm_run_segment": [_vp, _vp, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_u32)],
+    "r0h_vm_release_trace": [_vp, _sz],
+    "r0h_vm_boundary": [_vp, _sz, _pp, _c.POINTER(_sz)],
+    "r0h_trace_witgen": [_vp, _vp, _sz, _vp, _sz, _u32, _vp, _vp],
+    "r0h_last_session_stats": [_vp, _vp],
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
     "r0h_prove_elf": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _pp, _vp, _c.POINTER(_u64)],
@@ -157,6 +164,7 @@ _PLAIN = {
     "r0h_vm_reg": ([_vp, _u32], _u32),
     "r0h_vm_pc": ([_vp], _u32),
     "r0h_verify_reason": ([_c.c_int], _cp),
+    "r0h_trace_column_name": ([_u32], _cp),
     "r0h_receipt_verify_reason": ([_c.c_int], _cp),
     "r0h_buf_device_ptr": ([_vp], _vp),
     "r0h_buf_bytes": ([_vp], _sz),
@@ -539,22 +547,44 @@ class ReceiptClaim(ctypes.Structure):
         return claim_globals(self.digest())
 
 
-TRACE_COLUMNS = 58  # R0H_TRACE_COLUMNS
+TRACE_COLUMNS = 144  # R0H_TRACE_COLUMNS
+TRACE_GLOBALS = 11   # R0H_TRACE_GLOBALS: claim words 0..7, first pc, pc after the last cycle, cycles
+TRACE_MAX_PO2 = 21
+REG_BASE = 0x40000000  # R0H_REG_BASE: address of x[i] in the trace circuit's one address space (memory: word index)
 MEM_NONE, MEM_READ, MEM_WRITE = 0, 1, 2  # r0h_preflight_row.mem_kind
 
 
+def trace_column_names():
+    names, k = [], 0
+    while True:
+        s = lib().r0h_trace_column_name(k)
+        if s is None:
+            return names
+        names.append(s.decode())
+        k += 1
+
+
 class VmLimits(ctypes.Structure):
-    _fields_ = [("segment_po2", _u32), ("page_in_cycles", _u32), ("page_out_cycles", _u32), ("keep_trace", _u32), ("max_cycles", _u64)]
+    _fields_ = [("segment_po2", _u32), ("page_in_cycles", _u32), ("page_out_cycles", _u32), ("keep_trace", _u32), ("max_cycles", _u64),
+                ("boundary_rows", _u32), ("reserved", _u32)]
 
 
 class VmSegment(ctypes.Structure):
-    _fields_ = [("index", _u32), ("exit_system", _u32), ("exit_user", _u32), ("pages_in", _u32), ("pages_out", _u32), ("reserved", _u32),
+    _fields_ = [("index", _u32), ("exit_system", _u32), ("exit_user", _u32), ("pages_in", _u32), ("pages_out", _u32), ("boundary_rows", _u32),
                 ("user_cycles", _u64), ("paging_cycles", _u64), ("pre", SystemState), ("post", SystemState)]
 
 
 class PreflightRow(ctypes.Structure):
-    _fields_ = [("cycle", _u64), ("pc", _u32), ("insn", _u32), ("next_pc", _u32), ("rs1_value", _u32), ("rs2_value", _u32), ("rd", _u32), ("rd_after", _u32),
-                ("mem_kind", _u32), ("mem_addr", _u32), ("mem_before", _u32), ("mem_after", _u32)]
+    _fields_ = [("cycle", _u32), ("pc", _u32), ("insn", _u32), ("next_pc", _u32), ("rs1_value", _u32), ("rs2_value", _u32), ("rd", _u32), ("rd_before", _u32),
+                ("rd_after", _u32), ("mem_kind", _u32), ("mem_addr", _u32), ("mem_before", _u32), ("mem_after", _u32), ("prev", _u32 * 5)]
+
+
+class SessionStats(ctypes.Structure):
+    _fields_ = [("segments", _u32), ("cycles", _u64), ("executor_s", _c.c_double), ("witgen_ms", _c.c_double), ("prove_ms", _c.c_double), ("wall_s", _c.c_double)]
+
+
+class PreflightBound(ctypes.Structure):
+    _fields_ = [("addr", _u32), ("first_value", _u32), ("last_value", _u32), ("last_ts", _u32)]
 
 
 class Vm:
@@ -599,12 +629,22 @@ class Vm:
         _check(lib().r0h_vm_read(self.handle, addr, out.ctypes.data_as(_vp), n))
         return out
 
-    def run(self, segment_po2=20, page_in_cycles=0, page_out_cycles=0, keep_trace=False, max_cycles=0):
+    def run(self, segment_po2=20, page_in_cycles=0, page_out_cycles=0, keep_trace=False, max_cycles=0, boundary_rows=False):
         """Returns (exit kind, exit code); raises R0HipError on a guest trap."""
-        lim = VmLimits(segment_po2, page_in_cycles, page_out_cycles, 1 if keep_trace else 0, max_cycles)
+        lim = VmLimits(segment_po2, page_in_cycles, page_out_cycles, 1 if keep_trace else 0, max_cycles, 1 if boundary_rows else 0, 0)
         kind, code = _c.c_int(-1), _u32(0)
         _check(lib().r0h_vm_run(self.handle, ctypes.byref(lim), ctypes.byref(kind), ctypes.byref(code)))
         return kind.value, code.value
+
+    def run_segment(self, segment_po2=20, page_in_cycles=0, page_out_cycles=0, keep_trace=False, max_cycles=0, boundary_rows=False):
+        """One more segment of the run (r0h_vm_run_segment): returns (finished, exit kind, exit code)."""
+        lim = VmLimits(segment_po2, page_in_cycles, page_out_cycles, 1 if keep_trace else 0, max_cycles, 1 if boundary_rows else 0, 0)
+        fin, kind, code = _c.c_int(0), _c.c_int(-1), _u32(0)
+        _check(lib().r0h_vm_run_segment(self.handle, ctypes.byref(lim), ctypes.byref(fin), ctypes.byref(kind), ctypes.byref(code)))
+        return bool(fin.value), kind.value, code.value
+
+    def release_trace(self, i):
+        _check(lib().r0h_vm_release_trace(self.handle, i))
 
     def segments(self):
         out = []
@@ -614,19 +654,40 @@ class Vm:
             out.append(s)
         return out
 
-    def trace_witness(self, i, po2):
-        """DATA group of the trace circuit (58 columns x 2^po2, Montgomery words, column-major) from segment i's preflight rows, and
-        its three public inputs (r0h_vm_trace_witness)."""
+    def trace_witness(self, i, po2, claim_globals=None):
+        """DATA group of the trace circuit (144 columns x 2^po2, Montgomery words, column-major) from segment i's preflight and
+        boundary rows on the HOST (r0h_vm_trace_witness: the reference the device kernel is compared with), and its eleven public
+        inputs: claim_globals (8 words, zeros when None), first pc, pc after the last cycle, cycles."""
         data = np.zeros(TRACE_COLUMNS << po2, dtype=np.uint32)
-        glob = np.zeros(3, dtype=np.uint32)
+        glob = np.zeros(TRACE_GLOBALS, dtype=np.uint32)
         _check(lib().r0h_vm_trace_witness(self.handle, i, po2, data.ctypes.data_as(_vp), glob.ctypes.data_as(_vp)))
+        if claim_globals is not None:
+            glob[:8] = claim_globals
         return data, glob
 
-    def preflight(self, i):
+    def _preflight_raw(self, i):
         p, n = _vp(), _sz(0)
         _check(lib().r0h_vm_preflight(self.handle, i, ctypes.byref(p), ctypes.byref(n)))
+        q, m = _vp(), _sz(0)
+        _check(lib().r0h_vm_boundary(self.handle, i, ctypes.byref(q), ctypes.byref(m)))
+        return p, n.value, q, m.value
+
+    def preflight(self, i):
+        p, n, _, _ = self._preflight_raw(i)
         rows = ctypes.cast(p, ctypes.POINTER(PreflightRow))
-        return [rows[k] for k in range(n.value)]
+        return [rows[k] for k in range(n)]
+
+    def boundary(self, i):
+        _, _, q, m = self._preflight_raw(i)
+        rows = ctypes.cast(q, ctypes.POINTER(PreflightBound))
+        return [rows[k] for k in range(m)]
+
+    def preflight_arrays(self, i):
+        """The compact rows of segment i as numpy arrays (copies): [n, 18] uint32 cycles, [m, 4] uint32 boundary rows."""
+        p, n, q, m = self._preflight_raw(i)
+        rows = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(_u32)), shape=(n, 18)).copy() if n else np.zeros((0, 18), np.uint32)
+        bounds = np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(_u32)), shape=(m, 4)).copy() if m else np.zeros((0, 4), np.uint32)
+        return rows, bounds
 
     @property
     def journal(self):
@@ -652,6 +713,19 @@ class Vm:
             self.close()
         except Exception:
             pass
+
+
+def image_id_from_hex(text):
+    """32 digest bytes from the reference's image-id text (host/out/IMAGE_ID.hex: eight {:08x} u32 words, little-endian in the digest)."""
+    out = (ctypes.c_uint8 * 32)()
+    _check(lib().r0h_image_id_from_hex(text.encode() if isinstance(text, str) else bytes(text), out))
+    return bytes(out)
+
+
+def image_id_to_hex(image_id):
+    out = ctypes.create_string_buffer(65)
+    _check(lib().r0h_image_id_to_hex(bytes(image_id), out))
+    return out.value.decode()
 
 
 def sha256(data):
@@ -731,8 +805,10 @@ class Receipt:
             out.append(c if has.value else None)
         return out
 
-    def verify(self, blob, control_roots, image_id=None):
-        """`receipt.verify(image_id)` (r0h_receipt_verify): control_roots = {po2: root[8]}.  Returns (verdict, reason, segment, seal verdict)."""
+    def verify(self, blob, control_roots, image_id):
+        """`receipt.verify(image_id)` (r0h_receipt_verify): control_roots = {po2: root[8]}; image_id is required, as it is in the
+        reference (None is passed through and yields verdict 12 "not tied to a program", never 0).  Returns (verdict, reason,
+        segment, seal verdict)."""
         b, pb = _u32arr(blob)
         table = np.zeros(9 * max(len(control_roots), 1), dtype=np.uint32)
         for k, (po2, root) in enumerate(sorted(control_roots.items())):
@@ -934,6 +1010,24 @@ class Hal:
         _check(lib().r0h_witgen(self.ctx, circuit.handle, po2, seed, code.handle, data.handle, glob.ctypes.data_as(_vp)))
         return code, data, glob[:circuit.n_global]
 
+    def trace_witgen(self, rows, bounds, po2, claim_globals=None, into=None):
+        """DATA group of the trace circuit expanded ON THE DEVICE from the compact preflight rows (r0h_trace_witgen): rows [n, 18]
+        and bounds [m, 4] uint32 (Vm.preflight_arrays).  Returns (Buf of TRACE_COLUMNS * 2^po2 words, the eleven public inputs)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32).reshape(-1, 18)
+        bounds = np.ascontiguousarray(bounds, dtype=np.uint32).reshape(-1, 4)
+        data = into if into is not None else self.alloc(TRACE_COLUMNS << po2)
+        glob = np.zeros(TRACE_GLOBALS, dtype=np.uint32)
+        try:
+            _check(lib().r0h_trace_witgen(self.ctx, rows.ctypes.data_as(_vp), rows.shape[0], bounds.ctypes.data_as(_vp), bounds.shape[0], po2, data.handle,
+                                          glob.ctypes.data_as(_vp)))
+        except R0HipError:
+            if into is None:
+                data.free()
+            raise
+        if claim_globals is not None:
+            glob[:8] = claim_globals
+        return data, glob
+
     def witgen_into(self, circuit, po2, seed, code, data):
         """Regenerate the synthetic witness of another segment into existing buffers; returns its public inputs."""
         glob = np.zeros(max(circuit.n_global, 1), dtype=np.uint32)
@@ -996,13 +1090,20 @@ class Hal:
         return out
 
     def prove_elf(self, circuit, elf, input_words, segment_po2=20, max_cycles=0):
-        """`default_prover().prove(env, elf)` (r0h_prove_elf): returns (Receipt, image id, guest cycles)."""
+        """`default_prover().prove(env, elf)` (r0h_prove_elf): returns (Receipt, image id, guest cycles).  max_cycles = 0 selects the
+        library's session limit (2^32 cycles); with circuits/trace.r0c every seal attests the segment it stands for."""
         elf = bytes(elf)
         w, pw = _u32arr(input_words if len(input_words) else [0])
         h, image_id, cycles = _vp(), (ctypes.c_uint8 * 32)(), _u64(0)
         _check(lib().r0h_prove_elf(self.ctx, circuit.handle, elf, len(elf), pw, len(input_words), segment_po2, max_cycles, ctypes.byref(h), image_id,
                                    ctypes.byref(cycles)))
         return Receipt(h), bytes(image_id), cycles.value
+
+    def last_session_stats(self):
+        """Stage timing of the last prove_elf on this context (r0h_last_session_stats)."""
+        st = SessionStats()
+        _check(lib().r0h_last_session_stats(self.ctx, ctypes.byref(st)))
+        return {name: getattr(st, name) for name, _ in SessionStats._fields_}
 
     def proof_begin(self, circuit, po2, code, data, glob):
         """Commit CODE and DATA; returns (proof handle, accumulation mix words)."""

@@ -22,13 +22,13 @@ namespace r0h {
 const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
   R0H_REQUIRE(n_words >= 3 && w[0] == R0H_BLOB_MAGIC && w[1] == 1, "circuit blob: bad magic or version");
   size_t pos = 3;
-  bool seen[8] = {false};
+  bool seen[16] = {false};
   for (uint32_t s = 0; s < w[2]; s++) {
     R0H_REQUIRE(pos + 2 <= n_words, "circuit blob: truncated section header");
     uint32_t tag = w[pos], len = w[pos + 1];
     const uint32_t* p = w + pos + 2;
     R0H_REQUIRE(pos + 2 + len <= n_words, "circuit blob: section %u overruns the blob", tag);
-    if (tag < 8) seen[tag] = true;
+    if (tag < 16) seen[tag] = true;
     switch (tag) {
       case R0H_SEC_GROUPS:
         R0H_REQUIRE(len >= 3, "circuit blob: GROUPS too short");
@@ -67,6 +67,11 @@ const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
         c->acc_cols.resize(p[0]);
         if (p[0]) memcpy(c->acc_cols.data(), p + 1, 12 * (size_t)p[0]);
         break;
+      case R0H_SEC_ACCUM_FP:
+        R0H_REQUIRE(len >= 1 && len == 1 + 13 * (size_t)p[0], "circuit blob: ACCUM_FP length mismatch");
+        c->acc_fp.resize(p[0]);
+        if (p[0]) memcpy(c->acc_fp.data(), p + 1, 52 * (size_t)p[0]);
+        break;
       case R0H_SEC_INFO:
         R0H_REQUIRE(len == 4, "circuit blob: INFO must be 4 words");
         memcpy(c->info, p, 16);
@@ -77,12 +82,17 @@ const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
   }
   for (int t = 1; t <= 4; t++) R0H_REQUIRE(seen[t], "circuit blob: section %d missing", t);
   // WITGEN + ACCUM (the synthetic column program) are optional: a circuit imported from risc0 brings its own witness
-  c->has_column_program = seen[R0H_SEC_WITGEN] && seen[R0H_SEC_ACCUM];
-  R0H_REQUIRE(seen[R0H_SEC_WITGEN] == seen[R0H_SEC_ACCUM], "circuit blob: WITGEN and ACCUM sections must come together");
-  if (c->has_column_program)
-    R0H_REQUIRE(c->code_cols.size() == c->group_size[R0H_GROUP_CODE] && c->data_cols.size() == c->group_size[R0H_GROUP_DATA] &&
-                    4 * c->acc_cols.size() == c->group_size[R0H_GROUP_ACCUM] && c->n_mix == 8 * c->acc_cols.size(),
+  const bool any_accum = seen[R0H_SEC_ACCUM] || seen[R0H_SEC_ACCUM_FP];
+  c->has_column_program = seen[R0H_SEC_WITGEN] && any_accum;
+  R0H_REQUIRE(seen[R0H_SEC_WITGEN] == any_accum && !(seen[R0H_SEC_ACCUM] && seen[R0H_SEC_ACCUM_FP]), "circuit blob: WITGEN comes with exactly one of ACCUM / ACCUM_FP");
+  if (c->has_column_program) {
+    R0H_REQUIRE(c->code_cols.size() == c->group_size[R0H_GROUP_CODE] && c->data_cols.size() == c->group_size[R0H_GROUP_DATA],
                 "circuit blob: group sizes disagree with the column programs");
+    if (seen[R0H_SEC_ACCUM])
+      R0H_REQUIRE(4 * c->acc_cols.size() == c->group_size[R0H_GROUP_ACCUM] && c->n_mix == 8 * c->acc_cols.size(), "circuit blob: group sizes disagree with the accumulators");
+    else
+      R0H_REQUIRE(4 * c->acc_fp.size() == c->group_size[R0H_GROUP_ACCUM] && c->n_mix == 16, "circuit blob: group sizes disagree with the fingerprint accumulators");
+  }
   // taps: sorted, in range, every column owns back 0
   std::vector<std::vector<bool>> has0(3);
   for (int g = 0; g < 3; g++) has0[g].assign(c->group_size[g], false);
@@ -157,6 +167,11 @@ const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
     }
   }
   for (const AccCol& a : c->acc_cols) R0H_REQUIRE(a.a < c->data_cols.size() && a.b < c->data_cols.size(), "accum: column out of range");
+  for (const AccFp& a : c->acc_fp) {
+    R0H_REQUIRE(a.n_f >= 1 && a.n_f <= 3, "accum: a fingerprint accumulator multiplies 1..3 tuples");
+    for (uint32_t f = 0; f < 3; f++)
+      for (uint32_t q = 0; q < 4; q++) R0H_REQUIRE(a.col[f][q] < c->data_cols.size(), "accum: column out of range");
+  }
   c->blob.assign(w, w + n_words);
   return nullptr;
 }
@@ -470,6 +485,18 @@ __global__ void accum_term_kernel(uint32_t* __restrict__ term, const uint32_t* _
   t.e[0] = add(t.e[0], a[r]);
   *(uint4*)(term + 4 * (size_t)r) = make_uint4(t.e[0], t.e[1], t.e[2], t.e[3]);
 }
+// term[r] = prod_{f < n_f} (alpha - addr_f[r] - b1 lo_f[r] - b2 hi_f[r] - b3 t_f[r]): one tuple fingerprint per access (R0H_SEC_ACCUM_FP)
+struct FpCols { const uint32_t* col[3][4]; uint32_t n_f; };
+__global__ void accum_fp_term_kernel(uint32_t* __restrict__ term, FpCols cols, Fp4 alpha, Fp4 b1, Fp4 b2, Fp4 b3) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  Fp4 prod = fp4_one();
+  for (uint32_t f = 0; f < cols.n_f; f++) {
+    Fp4 t = alpha - scale(b1, cols.col[f][1][r]) - scale(b2, cols.col[f][2][r]) - scale(b3, cols.col[f][3][r]);
+    t.e[0] = sub(t.e[0], cols.col[f][0][r]);
+    prod = f ? prod * t : t;
+  }
+  *(uint4*)(term + 4 * (size_t)r) = make_uint4(prod.e[0], prod.e[1], prod.e[2], prod.e[3]);
+}
 __global__ void accum_unpack_kernel(uint32_t* __restrict__ cols, const uint32_t* __restrict__ term, uint32_t po2) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   uint4 v = *(const uint4*)(term + 4 * (size_t)r);
@@ -625,6 +652,18 @@ const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0
   for (uint32_t i = 0; i < c->n_mix; i++) R0H_REQUIRE(mix[i] < P, "r0h_accum: mix[%u] not canonical", i);
   r0h_buf* term = nullptr;
   R0H_TRY(buf_alloc_pooled(ctx, (size_t)n * 16, &term));
+  for (uint32_t j = 0; j < c->acc_fp.size(); j++) {
+    const AccFp& a = c->acc_fp[j];
+    FpCols cols;
+    cols.n_f = a.n_f;
+    for (uint32_t f = 0; f < 3; f++)
+      for (uint32_t q = 0; q < 4; q++) cols.col[f][q] = u32(data) + ((size_t)a.col[f][q] << po2);
+    auto m = [&](uint32_t k) { return Fp4{{mix[4 * k], mix[4 * k + 1], mix[4 * k + 2], mix[4 * k + 3]}}; };
+    hipLaunchKernelGGL(accum_fp_term_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(term), cols, m(0), m(1), m(2), m(3));
+    const char* err = r0h_prefix_products(ctx, term, n);
+    if (err) { r0h_buf_free(term); return err; }
+    hipLaunchKernelGGL(accum_unpack_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(accum) + ((size_t)(4 * j) << po2), u32(term), po2);
+  }
   for (uint32_t j = 0; j < c->acc_cols.size(); j++) {
     Fp4 m0{{mix[8 * j], mix[8 * j + 1], mix[8 * j + 2], mix[8 * j + 3]}}, m1{{mix[8 * j + 4], mix[8 * j + 5], mix[8 * j + 6], mix[8 * j + 7]}};
     hipLaunchKernelGGL(accum_term_kernel, dim3(n / threads), dim3(threads), 0, ctx->stream, u32(term), u32(data) + ((size_t)c->acc_cols[j].a << po2),

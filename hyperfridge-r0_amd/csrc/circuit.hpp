@@ -10,6 +10,7 @@ struct Step { uint32_t op, a, b, c; };
 struct CodeCol { uint32_t kind, param; };
 struct DataCol { uint32_t kind, a, b, c, e; };
 struct AccCol { uint32_t first, a, b; };
+struct AccFp { uint32_t n_f; uint32_t col[3][4]; };  // running product of up to three tuple fingerprints (R0H_SEC_ACCUM_FP)
 struct Term { uint32_t pow, v; std::vector<uint32_t> conds; };
 
 struct Plan {                      // how the constraint program is cut into kernels
@@ -35,6 +36,7 @@ struct r0h_circuit {
   std::vector<r0h::CodeCol> code_cols;
   std::vector<r0h::DataCol> data_cols;
   std::vector<r0h::AccCol> acc_cols;
+  std::vector<r0h::AccFp> acc_fp;
   bool has_column_program = false;  // WITGEN + ACCUM present (synthetic circuits); imported circuits bring their own witness
   std::vector<uint32_t> blob;
   uint8_t info[16] = {'R', '0', 'H', 'I', 'P', '_', 'S', 'Y', 'N', 'T', 'H', ':', 'v', '1', '_', '_'};  // circuit ProtocolInfo tag

@@ -183,14 +183,42 @@ const char* r0h_claim_globals(const uint8_t claim_digest[32], uint32_t globals_o
   R0H_GUARD_END
 }
 
+// The image id as the reference writes and reads it (host/src/main.rs:445-449 `{:08x}` per u32 word of HYPERFRIDGE_ID,
+// verifier/src/main.rs:131-143 `u32::from_str_radix` per 8 digits, fixture host/out/IMAGE_ID.hex): eight big-endian-printed words,
+// each of which risc0's `Digest::from([u32; 8])` stores little-endian -- so digest byte 4i + k is digits [8i + 6 - 2k, 8i + 8 - 2k).
+const char* r0h_image_id_from_hex(const char* hex, uint8_t image_id_out[32]) {
+  R0H_REQUIRE(hex && image_id_out, "r0h_image_id_from_hex: NULL argument");
+  R0H_REQUIRE(strlen(hex) == 64, "image id: exactly 64 hex digits wanted (verifier/src/main.rs:131-134)");
+  for (int i = 0; i < 8; i++) {
+    uint32_t w = 0;
+    for (int d = 0; d < 8; d++) {
+      const char ch = hex[8 * i + d];
+      const int v = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : ch >= 'A' && ch <= 'F' ? ch - 'A' + 10 : -1;
+      R0H_REQUIRE(v >= 0, "image id: '%c' is not a hex digit", ch);
+      w = w << 4 | (uint32_t)v;
+    }
+    for (int k = 0; k < 4; k++) image_id_out[4 * i + k] = (uint8_t)(w >> (8 * k));
+  }
+  return nullptr;
+}
+const char* r0h_image_id_to_hex(const uint8_t image_id[32], char hex_out[65]) {
+  R0H_REQUIRE(image_id && hex_out, "r0h_image_id_to_hex: NULL argument");
+  for (int i = 0; i < 8; i++) {
+    const uint32_t w = (uint32_t)image_id[4 * i] | (uint32_t)image_id[4 * i + 1] << 8 | (uint32_t)image_id[4 * i + 2] << 16 | (uint32_t)image_id[4 * i + 3] << 24;
+    snprintf(hex_out + 8 * i, 9, "%08x", w);
+  }
+  return nullptr;
+}
+
 const char* r0h_receipt_verify_reason(int verdict) {
   static const char* const names[] = {"ok", "not a composite receipt (Fake receipts prove nothing)", "a segment seal was rejected",
                                       "no control root known for a segment's trace size", "a segment carries no claim",
                                       "a seal's public inputs do not name its claim", "segments do not chain (index / post-state / exit code)",
                                       "the journal is not the one the last segment's claim commits to", "the first pre-state is not the expected image id",
                                       "the final exit code is not Halted(0) or Paused(0)", "the circuit exposes fewer than 8 globals: claims cannot be bound",
-                                      "a segment names a hash function other than poseidon2"};
-  return verdict >= 0 && verdict <= R0H_RECEIPT_V_HASHFN ? names[verdict] : "unknown";
+                                      "a segment names a hash function other than poseidon2",
+                                      "seals, claims and chain are valid but no image id was given: nothing ties the receipt to a program"};
+  return verdict >= 0 && verdict <= R0H_RECEIPT_V_UNBOUND ? names[verdict] : "unknown";
 }
 
 // risc0-zkvm receipt/composite.rs `verify_integrity_with_context` + receipt/mod.rs `Receipt::verify(image_id)`
@@ -206,10 +234,12 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
   R0H_TRY(parse_blob(&circ, blob, blob_words));
   if (circ.n_global < 8) return done(R0H_RECEIPT_V_NO_BINDING, 0);
   const size_t n = rc->segments.size();
+  const bool trace_circuit = !memcmp(circ.info, "R0HIP_TRACE:v2__", 16);  // its seals also carry the first and last pc of the segment
+  for (size_t i = 0; i < n; i++)  // before any claim is read (the chain check below looks one segment ahead)
+    if (!rc->segments[i].has_claim) return done(R0H_RECEIPT_V_NO_CLAIM, i);
   for (size_t i = 0; i < n; i++) {
     const r0h_receipt::Segment& g = rc->segments[i];
     if (g.hashfn != "poseidon2") return done(R0H_RECEIPT_V_HASHFN, i);  // the only suite this prover and this verifier implement
-    if (!g.has_claim) return done(R0H_RECEIPT_V_NO_CLAIM, i);
     // the seal names its trace size in its public part (globals, then po2): pick that size's control root, then verify bound to it
     if (g.seal.size() < (size_t)circ.n_global + 1 || g.seal[circ.n_global] >= P) {
       if (seal_verdict_out) *seal_verdict_out = R0H_VERIFY_TRUNCATED;
@@ -232,6 +262,8 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
     claim_digest(g.claim, cd);
     claim_globals(cd, want);
     if (memcmp(want, g.seal.data(), 32) != 0) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
+    // the trace circuit proves a run from its public first pc to its public last pc: they are the claim's
+    if (trace_circuit && (circ.n_global < R0H_TRACE_GLOBALS || g.seal[8] != enc(g.claim.pre.pc) || g.seal[9] != enc(g.claim.post.pc))) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
     // composite.rs: indices count up, every segment but the last ends in SystemSplit with no output, and hands its post-state on
     if (g.index != i) return done(R0H_RECEIPT_V_CHAIN, i);
     if (i + 1 < n) {
@@ -248,11 +280,10 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
   uint8_t out[32];
   R0H_TRY(r0h_output_digest(rc->journal.data(), rc->journal.size(), nullptr, out));
   if (memcmp(out, last.output_digest, 32) != 0) return done(R0H_RECEIPT_V_JOURNAL, n - 1);
-  if (image_id) {
-    uint8_t pre[32];
-    system_state_digest(rc->segments[0].claim.pre, pre);
-    if (memcmp(pre, image_id, 32) != 0) return done(R0H_RECEIPT_V_IMAGE_ID, 0);
-  }
+  if (!image_id) return done(R0H_RECEIPT_V_UNBOUND, 0);  // `receipt.verify(image_id)` always names the program: without it this is not OK
+  uint8_t pre[32];
+  system_state_digest(rc->segments[0].claim.pre, pre);
+  if (memcmp(pre, image_id, 32) != 0) return done(R0H_RECEIPT_V_IMAGE_ID, 0);
   return done(R0H_RECEIPT_V_OK, 0);
   R0H_GUARD_END
 }

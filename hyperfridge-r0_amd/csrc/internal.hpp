@@ -105,6 +105,7 @@ struct r0h_ctx {
   std::multimap<size_t, void*> pool;  // cached device allocations of the sequencer, by size (stream-ordered reuse)
   size_t pool_bytes = 0;              // bytes parked in the pool; above POOL_LIMIT blocks are released instead
   r0h::Profile prof;
+  r0h_session_stats session = {0, 0, 0, 0, 0, 0};  // stage timing of the last r0h_prove_elf
   bool ktime_on = false;
   std::map<std::string, r0h::KTimer> ktimers;
 };
@@ -163,6 +164,9 @@ const char* bit_reverse_ext(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t 
 const char* ntt_init_device();
 // batched synthetic division (DEEP step): job j divides polynomial poly_idx[j] of `polys` by (x - points[4j..]); one read-back
 const char* poly_divide_batch(r0h_ctx* ctx, r0h_buf* polys, uint32_t n, const uint32_t* poly_idx, const uint32_t* points, uint32_t n_jobs, uint32_t* remainders_host);
+// rv32im.hip: the preflight rows of segment i are moved out of the machine (the session proves them while the guest runs on)
+void vm_take_trace(r0h_vm* vm, size_t i, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds);
+void vm_recycle_trace(r0h_vm* vm, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds);
 void ctx_retain(r0h_ctx* ctx);
 void ctx_release(r0h_ctx* ctx);
 // host Poseidon2 (transcript only): permutation over 24 Montgomery words with the context's table

@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
       uint8_t id[32];
       CHECK(r0h_system_state_digest(&st[0], id));
       char hex[65];
-      for (int i = 0; i < 32; i++) snprintf(hex + 2 * i, 3, "%02x", id[i]);
+      CHECK(r0h_image_id_to_hex(id, hex));  // the reference's IMAGE_ID.hex convention: eight {:08x} words
       image_ids[r] = hex;
     }
   }

@@ -53,13 +53,9 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
   if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); return 2; }
   uint8_t image_id[32];
   if (image_hex) {
-    bool ok = strlen(image_hex) == 64;
-    for (int i = 0; ok && i < 32; i++) {
-      unsigned v;
-      ok = sscanf(image_hex + 2 * i, "%2x", &v) == 1;
-      image_id[i] = (uint8_t)v;
-    }
-    if (!ok) { fprintf(stderr, "r0h_verify: --image-id wants 64 hex digits (verifier/src/main.rs:131-143)\n"); r0h_receipt_free(rc); return 2; }
+    // eight {:08x} words, each little-endian in the digest: the reference's IMAGE_ID.hex convention (r0h_image_id_from_hex)
+    err = r0h_image_id_from_hex(image_hex, image_id);
+    if (err) { fprintf(stderr, "r0h_verify: --image-id: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
   }
   const size_t n_seg = r0h_receipt_n_segments(rc);
   const bool bound = image_hex && !roots.empty();

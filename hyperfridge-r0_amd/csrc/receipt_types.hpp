@@ -16,7 +16,7 @@ struct r0h_receipt {
     uint32_t index = 0;
     std::string hashfn;
     bool has_claim = false;
-    r0h_receipt_claim claim;
+    r0h_receipt_claim claim{};
     uint8_t verifier_parameters[32] = {0};
   };
   std::vector<Segment> segments;

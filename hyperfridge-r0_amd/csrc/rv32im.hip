@@ -9,8 +9,11 @@
 // cases the specification tabulates (division by zero, signed overflow).  Everything risc0-specific is RECALLED in outline only and
 // written here as this library's own, documented choice -- a real guest ELF needs risc0's tables instead:
 //   * the ecall ABI (below) is NOT risc0's syscall table (halt / software / sha / bigint selected by t0);
-//   * the cycle model is one cycle per instruction plus a flat charge per page first touched (paged in) and per page dirtied (paged
-//     out) in a segment; risc0's rv32im-v2 charges differ and are not reproducible from the reference;
+//   * the cycle model is one cycle per instruction -- one per WORD moved for the two I/O ecalls, which re-execute like `rep movs`
+//     until their count is zero, so that a cycle has at most one memory access -- plus, per segment, a flat charge per page first
+//     touched / dirtied (page_in_cycles / page_out_cycles) and, with boundary_rows, one row per distinct register or memory word
+//     touched (what the trace circuit spends on each address's first and last value); risc0's rv32im-v2 charges differ and are
+//     not reproducible from the reference;
 //   * the state digest is risc0-binfmt's SystemState{pc, merkle_root} (csrc/claim.hip) with merkle_root = a SHA-256 binary Merkle
 //     tree over the 1 KiB pages of the 32-bit address space, all-zero subtrees folded (risc0's image id is also a page Merkle root;
 //     its exact tree shape and tags are not pinned here).
@@ -19,8 +22,10 @@
 //
 // ecall ABI (a7 = x17 selects; arguments a0.., result in a0):
 //   0 HALT        a0 = exit code                        -- ends the run (ExitCode::Halted(a0))
-//   1 READ_WORDS  a0 = destination, a1 = word count     -- the next words of the input stream (ExecutorEnv frames), zero past its end
-//   2 COMMIT      a0 = source, a1 = byte count          -- appends bytes to the journal (`env::commit`)
+//   1 READ_WORDS  a0 = destination, a1 = word count     -- the next words of the input stream (ExecutorEnv frames), zero past its end;
+//                                                          one word per cycle, a1 counts down to 0
+//   2 COMMIT      a0 = source, a1 = byte count          -- appends bytes to the journal (`env::commit`); one memory word per cycle,
+//                                                          a1 counts down to 0
 //   3 CYCLES                                            -- a0 = cycles executed so far (`env::cycle_count()`)
 //   4 PAUSE       a0 = exit code                        -- ends the run resumably (ExitCode::Paused(a0))
 #include <stdint.h>
@@ -28,46 +33,91 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <array>
-#include <iterator>
-#include <map>
 #include <memory>
-#include <set>
+#include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/r0hip.h"
 #include "internal.hpp"
 #include "receipt_types.hpp"
+#include "trace.hpp"
 
 namespace {
 constexpr uint32_t PAGE_BYTES = 1024, PAGE_WORDS = PAGE_BYTES / 4, PAGE_SHIFT = 10, N_PAGE_BITS = 32 - PAGE_SHIFT;  // 2^22 pages
+constexpr uint64_t MAX_JOURNAL_BYTES = (uint64_t)1 << 28, MAX_IO_WORDS = (uint64_t)1 << 26;
+constexpr size_t MAX_RESIDENT_PAGES = (size_t)1 << 21;  // 2 GiB of guest memory: a run that wants more is refused, not swapped
+
+struct Page {
+  uint32_t w[PAGE_WORDS];
+  uint32_t ts[PAGE_WORDS];  // timestamp of the last access in segment `epoch` (0 = not touched yet)
+  uint32_t epoch, in_epoch, out_epoch;  // segment (index + 1) for which ts / "paged in" / "dirtied" hold
+  uint32_t stale;           // 1: written since its leaf of the memory tree was last hashed (it is then on the vm's stale list)
+};
 
 struct Segment {
   r0h_vm_segment info;
   std::vector<r0h_preflight_row> rows;
+  std::vector<r0h_preflight_bound> bounds;
 };
+struct Run;
 }  // namespace
 
 struct r0h_vm {
   uint32_t x[32] = {0};
   uint32_t pc = 0;
-  std::map<uint32_t, std::vector<uint32_t>> pages;  // page index -> PAGE_WORDS words; absent = all zero
+  Page** table = nullptr;            // page index -> page; absent = all zero (a flat 2^22-entry table, lazily backed)
+  std::vector<uint32_t> page_list;   // the pages that exist, in creation order
+  // the memory Merkle tree, kept between segment boundaries: nodes of non-zero subtrees by (level << 32 | index); a boundary
+  // re-hashes only the pages written since the previous one and the paths above them (risc0 keeps its page table the same way)
+  std::unordered_map<uint64_t, std::array<uint8_t, 32>> tree;
+  std::vector<uint32_t> stale_pages;
+  void mark_stale(Page* p, uint32_t idx) {
+    if (!p->stale) { p->stale = 1; stale_pages.push_back(idx); }
+  }
   std::vector<uint32_t> input;
   size_t input_pos = 0;
   std::vector<uint8_t> journal;
-  uint64_t cycles = 0;  // user cycles (instructions) over the whole run
+  uint64_t cycles = 0;  // cycles (rows) over the whole run
   bool finished = false; // a run ended in HALT / PAUSE / the cycle limit: its segments are final
   std::vector<Segment> segments;
+  std::unique_ptr<Run> run;  // the run in progress (r0h_vm_run_segment)
+  // row buffers handed back by whoever took a segment's trace (vm_recycle_trace): the next segment writes into memory that is
+  // already mapped -- a fresh 72 MiB block costs about as much in page faults as the cycles that fill it
+  std::vector<std::vector<r0h_preflight_row>> spare_rows;
+  std::vector<std::vector<r0h_preflight_bound>> spare_bounds;
+  // an I/O ecall in progress: the count it started with (a1 counts down from there)
+  bool io_active = false;
+  uint32_t io_total = 0;
   // hashing caches
   uint8_t zero_level[N_PAGE_BITS + 1][32];
   bool zero_ready = false;
+
+  r0h_vm() { table = (Page**)calloc((size_t)1 << N_PAGE_BITS, sizeof(Page*)); }
+  ~r0h_vm();
+  r0h_vm(const r0h_vm&) = delete;
+  Page* find(uint32_t idx) const { return table ? table[idx] : nullptr; }
+  Page* get(uint32_t idx) {
+    Page* p = table[idx];
+    if (!p) {
+      if (page_list.size() >= MAX_RESIDENT_PAGES) throw std::runtime_error("the guest's memory exceeds 2 GiB of resident pages");
+      p = (Page*)calloc(1, sizeof(Page));
+      if (!p) throw std::bad_alloc();
+      table[idx] = p;
+      page_list.push_back(idx);
+      // a new page is all zero, as the tree already assumes: nothing to re-hash until it is written
+    }
+    return p;
+  }
 };
 
 namespace {
 using r0h::sha256;
 
-void page_hash(const std::vector<uint32_t>& w, uint8_t out[32]) { sha256(w.data(), PAGE_BYTES, out); }  // little-endian words = the bytes of memory
+void page_hash(const uint32_t* w, uint8_t out[32]) { sha256(w, PAGE_BYTES, out); }  // little-endian words = the bytes of memory
 void node_hash(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
   uint8_t cat[64];
   memcpy(cat, a, 32);
@@ -77,155 +127,201 @@ void node_hash(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
 void ensure_zero_levels(r0h_vm& vm) {
   if (vm.zero_ready) return;
   const std::vector<uint32_t> z(PAGE_WORDS, 0);
-  page_hash(z, vm.zero_level[0]);
+  page_hash(z.data(), vm.zero_level[0]);
   for (uint32_t l = 1; l <= N_PAGE_BITS; l++) node_hash(vm.zero_level[l - 1], vm.zero_level[l - 1], vm.zero_level[l]);
   vm.zero_ready = true;
 }
-// Merkle root over all 2^22 pages with all-zero subtrees taken from the table: cost ~ (non-zero pages) x 22 hashes
+// Merkle root over all 2^22 pages, all-zero subtrees taken from the table of zero levels.  Incremental: only the pages written
+// since the last call are hashed again, then the 22 nodes above each (shared parents once): cost ~ (pages written) x (17 + 2 x 22)
+// SHA-256 blocks per segment boundary instead of a pass over the whole image.
 void memory_root(r0h_vm& vm, uint8_t out[32]) {
   ensure_zero_levels(vm);
-  std::map<uint32_t, std::array<uint8_t, 32>> level;
-  for (const auto& kv : vm.pages) {
+  auto key = [](uint32_t level, uint32_t idx) { return (uint64_t)level << 32 | idx; };
+  std::vector<uint32_t> level(vm.stale_pages), up;
+  vm.stale_pages.clear();
+  std::sort(level.begin(), level.end());
+  for (uint32_t idx : level) {
+    Page* p = vm.table[idx];
+    p->stale = 0;
     bool nz = false;
-    for (uint32_t w : kv.second) nz |= w != 0;
-    if (!nz) continue;
-    std::array<uint8_t, 32> h;
-    page_hash(kv.second, h.data());
-    level[kv.first] = h;
+    for (uint32_t w : p->w) nz |= w != 0;
+    if (!nz) { vm.tree.erase(key(0, idx)); continue; }
+    page_hash(p->w, vm.tree[key(0, idx)].data());
   }
   for (uint32_t l = 0; l < N_PAGE_BITS; l++) {
-    std::map<uint32_t, std::array<uint8_t, 32>> up;
-    for (auto it = level.begin(); it != level.end();) {
-      const uint32_t parent = it->first >> 1;
-      const uint8_t *left = vm.zero_level[l], *right = vm.zero_level[l];
-      if (it->first & 1) { right = it->second.data(); ++it; }
-      else {
-        left = it->second.data();
-        auto nx = std::next(it);
-        if (nx != level.end() && nx->first == (it->first | 1)) { right = nx->second.data(); it = std::next(nx); }
-        else ++it;
-      }
+    up.clear();
+    for (size_t i = 0; i < level.size(); i++) {
+      const uint32_t parent = level[i] >> 1;
+      if (!up.empty() && up.back() == parent) continue;
+      up.push_back(parent);
+      auto a = vm.tree.find(key(l, parent << 1)), b = vm.tree.find(key(l, parent << 1 | 1));
+      if (a == vm.tree.end() && b == vm.tree.end()) { vm.tree.erase(key(l + 1, parent)); continue; }
+      const uint8_t* left = a == vm.tree.end() ? vm.zero_level[l] : a->second.data();
+      const uint8_t* right = b == vm.tree.end() ? vm.zero_level[l] : b->second.data();
       std::array<uint8_t, 32> h;
       node_hash(left, right, h.data());
-      up[parent] = h;
+      vm.tree[key(l + 1, parent)] = h;
     }
     level.swap(up);
   }
-  if (level.empty()) memcpy(out, vm.zero_level[N_PAGE_BITS], 32);
-  else memcpy(out, level.begin()->second.data(), 32);
+  auto top = vm.tree.find(key(N_PAGE_BITS, 0));
+  memcpy(out, top == vm.tree.end() ? vm.zero_level[N_PAGE_BITS] : top->second.data(), 32);
 }
 
 struct Run {
   r0h_vm& vm;
-  const r0h_vm_limits& lim;
+  const r0h_vm_limits lim;
   Segment cur;
-  std::set<uint32_t> touched, dirtied;  // pages of the current segment
-  uint64_t seg_budget;
+  uint32_t epoch = 0;                  // index of the current segment + 1
+  uint32_t n_in = 0, n_out = 0;        // pages first touched / dirtied in the current segment
+  uint32_t reg_ts[32], reg_first[32], reg_mask = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> touched;  // (word index, value found) of every word first touched in the segment
+  uint64_t seg_budget, executed = 0;
   const char* err = nullptr;
   r0h_preflight_row* row = nullptr;
+  int exit_kind = R0H_VM_LIMIT;
+  uint32_t exit_code = 0;
+  uint8_t root_now[32];                // memory root at the last segment boundary (the next segment starts from it)
+  bool have_root = false;
 
   Run(r0h_vm& v, const r0h_vm_limits& l) : vm(v), lim(l), seg_budget((uint64_t)1 << l.segment_po2) {}
 
-  uint64_t paging_cycles() const { return (uint64_t)touched.size() * lim.page_in_cycles + (uint64_t)dirtied.size() * lim.page_out_cycles; }
+  uint64_t paging_cycles() const { return (uint64_t)n_in * lim.page_in_cycles + (uint64_t)n_out * lim.page_out_cycles; }
+  uint64_t boundary_count() const { return lim.boundary_rows ? touched.size() + (uint64_t)__builtin_popcount(reg_mask) : 0; }
 
   void begin_segment() {
     cur = Segment();
     memset(&cur.info, 0, sizeof cur.info);
     cur.info.index = (uint32_t)vm.segments.size();
     cur.info.pre.pc = vm.pc;
-    memory_root(vm, cur.info.pre.merkle_root);
+    if (!have_root) { memory_root(vm, root_now); have_root = true; }
+    memcpy(cur.info.pre.merkle_root, root_now, 32);
+    epoch = cur.info.index + 1;
+    n_in = n_out = 0;
+    reg_mask = 0;
+    memset(reg_ts, 0, sizeof reg_ts);
     touched.clear();
-    dirtied.clear();
+    if (lim.keep_trace) {
+      if (!vm.spare_rows.empty()) { cur.rows.swap(vm.spare_rows.back()); vm.spare_rows.pop_back(); cur.rows.clear(); }
+      if (!vm.spare_bounds.empty()) { cur.bounds.swap(vm.spare_bounds.back()); vm.spare_bounds.pop_back(); cur.bounds.clear(); }
+      cur.rows.reserve((size_t)std::min<uint64_t>(seg_budget, (uint64_t)1 << 22));
+    }
   }
   void end_segment(uint32_t exit_system, uint32_t exit_user) {
     cur.info.post.pc = vm.pc;
-    memory_root(vm, cur.info.post.merkle_root);
-    cur.info.pages_in = (uint32_t)touched.size();
-    cur.info.pages_out = (uint32_t)dirtied.size();
+    memory_root(vm, root_now);
+    memcpy(cur.info.post.merkle_root, root_now, 32);
+    cur.info.pages_in = n_in;
+    cur.info.pages_out = n_out;
     cur.info.paging_cycles = paging_cycles();
+    cur.info.boundary_rows = (uint32_t)boundary_count();
     cur.info.exit_system = exit_system;
     cur.info.exit_user = exit_user;
+    if (lim.keep_trace) {  // one boundary row per address touched, in increasing address order (registers sit above memory)
+      std::sort(touched.begin(), touched.end());
+      cur.bounds.reserve(touched.size() + 32);
+      for (const auto& t : touched) {
+        const Page* p = vm.table[t.first >> 8];
+        cur.bounds.push_back(r0h_preflight_bound{t.first, t.second, p->w[t.first & 255], p->ts[t.first & 255]});
+      }
+      for (uint32_t i = 1; i < 32; i++)
+        if (reg_mask >> i & 1) cur.bounds.push_back(r0h_preflight_bound{R0H_REG_BASE + i, reg_first[i], vm.x[i], reg_ts[i]});
+    }
     vm.segments.push_back(std::move(cur));
   }
 
-  std::vector<uint32_t>& page(uint32_t addr, bool write) {
-    const uint32_t idx = addr >> PAGE_SHIFT;
-    touched.insert(idx);
-    if (write) dirtied.insert(idx);
-    auto it = vm.pages.find(idx);
-    if (it == vm.pages.end()) it = vm.pages.emplace(idx, std::vector<uint32_t>(PAGE_WORDS, 0)).first;
-    return it->second;
+  // ---- the accesses of a cycle, each with its timestamp: returns when the same register / word was last touched in this segment
+  uint32_t touch_reg(uint32_t i, uint32_t ts) {
+    const uint32_t prev = reg_ts[i];
+    if (!(reg_mask >> i & 1)) { reg_mask |= 1u << i; reg_first[i] = vm.x[i]; }
+    reg_ts[i] = ts;
+    return prev;
   }
-  uint32_t load_word(uint32_t addr) { return page(addr, false)[(addr & (PAGE_BYTES - 1)) >> 2]; }
-  void store_word(uint32_t addr, uint32_t v) { page(addr, true)[(addr & (PAGE_BYTES - 1)) >> 2] = v; }
-  void note_mem(uint32_t addr, uint32_t before, uint32_t after, uint32_t kind) {
-    if (!row) return;
-    row->mem_addr = addr & ~3u; row->mem_before = before; row->mem_after = after; row->mem_kind = kind;
+  Page* page(uint32_t addr, bool write) {
+    Page* p = vm.get(addr >> PAGE_SHIFT);
+    if (p->in_epoch != epoch) { p->in_epoch = epoch; n_in++; }
+    if (write) {
+      if (p->out_epoch != epoch) { p->out_epoch = epoch; n_out++; }
+      vm.mark_stale(p, addr >> PAGE_SHIFT);
+    }
+    return p;
+  }
+  uint32_t touch_word(Page* p, uint32_t addr, uint32_t ts) {
+    if (p->epoch != epoch) { p->epoch = epoch; memset(p->ts, 0, sizeof p->ts); }
+    const uint32_t k = (addr & (PAGE_BYTES - 1)) >> 2, prev = p->ts[k];
+    if (!prev) touched.emplace_back(addr >> 2, p->w[k]);
+    p->ts[k] = ts;
+    return prev;
+  }
+  // the cycle's one memory access (word-aligned address): value before, value after
+  void mem_access(uint32_t addr, bool write, uint32_t value, uint32_t* before) {
+    Page* p = page(addr, write);
+    const uint32_t k = (addr & (PAGE_BYTES - 1)) >> 2;
+    const uint32_t prev = touch_word(p, addr, r0h::trace::stamp((uint32_t)cur.info.user_cycles, 3));
+    *before = p->w[k];
+    if (write) p->w[k] = value;
+    if (row) {
+      row->mem_addr = addr; row->mem_before = *before; row->mem_after = write ? value : *before;
+      row->mem_kind = write ? R0H_MEM_WRITE : R0H_MEM_READ;
+      row->prev[3] = prev;
+    }
   }
   bool load(uint32_t addr, uint32_t width, bool sign, uint32_t* out) {
     if (addr & (width - 1)) { err = "misaligned load"; return false; }
-    const uint32_t w = load_word(addr & ~3u), sh = 8 * (addr & 3);
+    uint32_t w;
+    mem_access(addr & ~3u, false, 0, &w);
+    const uint32_t sh = 8 * (addr & 3);
     uint32_t v = width == 4 ? w : (w >> sh) & (width == 1 ? 0xffu : 0xffffu);
     if (sign && width == 1) v = (uint32_t)(int32_t)(int8_t)v;
     if (sign && width == 2) v = (uint32_t)(int32_t)(int16_t)v;
-    note_mem(addr, w, w, R0H_MEM_READ);
     *out = v;
     return true;
   }
   bool store(uint32_t addr, uint32_t width, uint32_t v) {
     if (addr & (width - 1)) { err = "misaligned store"; return false; }
-    const uint32_t old = load_word(addr & ~3u), sh = 8 * (addr & 3);
-    const uint32_t mask = width == 4 ? 0xffffffffu : (width == 1 ? 0xffu : 0xffffu) << sh;
-    const uint32_t nw = (old & ~mask) | ((v << sh) & mask);
-    store_word(addr & ~3u, nw);
-    note_mem(addr, old, nw, R0H_MEM_WRITE);
+    if (width == 4) { uint32_t old; mem_access(addr, true, v, &old); return true; }
+    // a narrow store rewrites part of the word: the new word depends on the old one, read in the same access
+    Page* p = page(addr & ~3u, true);
+    const uint32_t k = (addr & (PAGE_BYTES - 1)) >> 2, sh = 8 * (addr & 3);
+    const uint32_t mask = (width == 1 ? 0xffu : 0xffffu) << sh;
+    const uint32_t nw = (p->w[k] & ~mask) | ((v << sh) & mask);
+    uint32_t old;
+    mem_access(addr & ~3u, true, nw, &old);
     return true;
   }
 
-  // one instruction; returns false when the run ends (halt / pause / error)
-  bool step(int* exit_kind, uint32_t* exit_code) {
+  // one cycle; returns false when the run ends (halt / pause / error)
+  bool step() {
     r0h_vm& m = vm;
     if (m.pc & 3) { err = "misaligned pc"; return false; }
-    // segment boundary: the next instruction and the pages it may bring in and write back must still fit.  An ordinary
-    // instruction touches its own page and one more (in and out); an I/O ecall touches every page of its buffer, so its span
-    // is priced before it runs (the word at pc is peeked without being charged to this segment yet).
-    uint64_t worst = (uint64_t)lim.page_in_cycles * 2 + lim.page_out_cycles;
-    bool io = false;
-    {
-      auto it = m.pages.find(m.pc >> PAGE_SHIFT);
-      const uint32_t peek = it == m.pages.end() ? 0u : it->second[(m.pc & (PAGE_BYTES - 1)) >> 2];
-      if (peek == 0x00000073u && (m.x[17] == 1 || m.x[17] == 2) && m.x[11] != 0) {
-        const uint64_t bytes = m.x[17] == 1 ? (uint64_t)m.x[11] * 4 : (uint64_t)m.x[11];
-        const uint64_t span = (((uint64_t)m.x[10] + bytes - 1) >> PAGE_SHIFT) - (m.x[10] >> PAGE_SHIFT) + 1;
-        worst = lim.page_in_cycles + span * ((uint64_t)lim.page_in_cycles + (m.x[17] == 1 ? lim.page_out_cycles : 0));
-        io = true;
-      }
-    }
-    if (cur.info.user_cycles + 1 + paging_cycles() + worst > seg_budget) {
+    // segment boundary: the next cycle, the pages it may bring in and write back (its own and one more) and the boundary rows of
+    // what it may touch for the first time (three registers, one word, the fetched word) must still fit
+    const uint64_t worst = (uint64_t)lim.page_in_cycles * 2 + lim.page_out_cycles + (lim.boundary_rows ? 5 : 0);
+    if (cur.info.user_cycles + 1 + paging_cycles() + boundary_count() + worst > seg_budget) {
       if (cur.info.user_cycles != 0) {
         end_segment(2, 0);  // SystemSplit
         begin_segment();
       }
-      if (1 + worst > seg_budget) {  // not even alone in a fresh segment
-        err = io ? "an I/O ecall spans more pages than one segment can pay for: transfer in smaller pieces or raise segment_po2"
-                 : "segment limit too small for a single instruction and its pages";
-        return false;
-      }
+      if (1 + worst > seg_budget) { err = "segment limit too small for a single instruction and its pages"; return false; }
     }
-    const uint32_t insn = load_word(m.pc);
+    const uint32_t cyc = (uint32_t)cur.info.user_cycles;
+    Page* fp = page(m.pc, false);
+    const uint32_t insn = fp->w[(m.pc & (PAGE_BYTES - 1)) >> 2];
+    const uint32_t fetch_prev = touch_word(fp, m.pc, r0h::trace::stamp(cyc, 4));
     const uint32_t op = insn & 0x7f, rd = (insn >> 7) & 31, f3 = (insn >> 12) & 7, rs1 = (insn >> 15) & 31, rs2 = (insn >> 20) & 31, f7 = insn >> 25;
     const uint32_t a = m.x[rs1], b = m.x[rs2];
     const int32_t imm_i = (int32_t)insn >> 20;
     const int32_t imm_s = ((int32_t)(insn & 0xfe000000) >> 20) | (int32_t)((insn >> 7) & 31);
     const int32_t imm_b = ((int32_t)(insn & 0x80000000) >> 19) | (int32_t)((insn & 0x80) << 4) | (int32_t)((insn >> 20) & 0x7e0) | (int32_t)((insn >> 7) & 0x1e);
     const int32_t imm_j = ((int32_t)(insn & 0x80000000) >> 11) | (int32_t)(insn & 0xff000) | (int32_t)((insn >> 9) & 0x800) | (int32_t)((insn >> 20) & 0x7fe);
-    uint32_t next = m.pc + 4, wr = 0;
+    uint32_t next = m.pc + 4, wr = 0, wr_reg = rd;
     bool has_wr = false;
-    r0h_preflight_row local;
+    const uint32_t p0 = rs1 ? touch_reg(rs1, r0h::trace::stamp(cyc, 0)) : 0, p1 = rs2 ? touch_reg(rs2, r0h::trace::stamp(cyc, 1)) : 0;
     if (lim.keep_trace) {
-      memset(&local, 0, sizeof local);
-      local.cycle = cur.info.user_cycles; local.pc = m.pc; local.insn = insn; local.rs1_value = a; local.rs2_value = b;
-      row = &local;
+      cur.rows.emplace_back();  // value-initialised: all zero
+      row = &cur.rows.back();
+      row->cycle = cyc; row->pc = m.pc; row->insn = insn; row->rs1_value = a; row->rs2_value = b;
+      row->prev[0] = p0; row->prev[1] = p1; row->prev[4] = fetch_prev;
     } else {
       row = nullptr;
     }
@@ -328,40 +424,110 @@ struct Run {
         if (insn != 0x00000073u) { err = insn == 0x00100073u ? "ebreak" : "illegal instruction"; return false; }
         const uint32_t fn = m.x[17], a0 = m.x[10], a1 = m.x[11];
         switch (fn) {
-          case 0: *exit_kind = R0H_VM_HALTED; *exit_code = a0; running = false; break;
-          case 4: *exit_kind = R0H_VM_PAUSED; *exit_code = a0; running = false; break;
+          case 0: exit_kind = R0H_VM_HALTED; exit_code = a0; running = false; break;
+          case 4: exit_kind = R0H_VM_PAUSED; exit_code = a0; running = false; break;
           case 1:
-            if (a0 & 3) { err = "READ_WORDS: misaligned destination"; return false; }
-            if ((uint64_t)a1 * 4 > ((uint64_t)1 << 28)) { err = "READ_WORDS: count too large"; return false; }
-            for (uint32_t i = 0; i < a1; i++) store_word(a0 + 4 * i, m.input_pos < m.input.size() ? m.input[m.input_pos++] : 0u);
-            break;
-          case 2:
-            if ((uint64_t)a1 > ((uint64_t)1 << 28)) { err = "COMMIT: count too large"; return false; }
-            for (uint32_t i = 0; i < a1; i++) {
-              const uint32_t w = load_word((a0 + i) & ~3u);
-              m.journal.push_back((uint8_t)(w >> (8 * ((a0 + i) & 3))));
+          case 2: {
+            // one word per cycle; the ecall re-executes until a1 is 0 (io_total: the count the transfer started with)
+            if (fn == 1 && (a0 & 3)) { err = "READ_WORDS: misaligned destination"; return false; }
+            if (a1 == 0) { m.io_active = false; break; }
+            if (!m.io_active || a1 > m.io_total) {
+              if (fn == 1 && a1 > MAX_IO_WORDS) { err = "READ_WORDS: count too large"; return false; }
+              if (fn == 2 && (uint64_t)a1 > MAX_JOURNAL_BYTES) { err = "COMMIT: count too large"; return false; }
+              m.io_active = true;
+              m.io_total = a1;
             }
+            const uint32_t off = m.io_total - a1;
+            uint32_t left;
+            if (fn == 1) {
+              uint32_t old;
+              mem_access(a0 + 4 * off, true, m.input_pos < m.input.size() ? m.input[m.input_pos] : 0u, &old);
+              if (m.input_pos < m.input.size()) m.input_pos++;
+              left = a1 - 1;
+            } else {
+              if (m.journal.size() + 4 > MAX_JOURNAL_BYTES) { err = "COMMIT: the journal exceeds 2^28 bytes"; return false; }
+              const uint32_t at = a0 + off, take = std::min(4 - (at & 3), a1);
+              uint32_t w;
+              mem_access(at & ~3u, false, 0, &w);
+              for (uint32_t i = 0; i < take; i++) m.journal.push_back((uint8_t)(w >> (8 * ((at & 3) + i))));
+              left = a1 - take;
+            }
+            wr_reg = 11; set(left);
+            if (left) next = m.pc;
+            else m.io_active = false;
             break;
-          case 3: m.x[10] = (uint32_t)m.cycles; if (row) { row->rd = 10; row->rd_after = m.x[10]; } break;
+          }
+          case 3: wr_reg = 10; set((uint32_t)m.cycles); break;
           default: err = "unknown ecall function"; return false;
         }
         break;
       }
       default: err = "illegal instruction"; return false;
     }
-    if (has_wr && rd != 0) m.x[rd] = wr;
-    if (row) {
-      if (has_wr) { row->rd = rd; row->rd_after = rd ? wr : 0; }
-      row->next_pc = next;
-      cur.rows.push_back(local);
+    if (has_wr && wr_reg != 0) {
+      const uint32_t p2 = touch_reg(wr_reg, r0h::trace::stamp(cyc, 2));
+      if (row) { row->rd = wr_reg; row->rd_before = m.x[wr_reg]; row->rd_after = wr; row->prev[2] = p2; }
+      m.x[wr_reg] = wr;
     }
+    if (row) row->next_pc = next;
     m.pc = next;
     m.cycles++;
     cur.info.user_cycles++;
     return running;
   }
+
+  // runs until one more segment is complete (or the run ends); returns an error string or nullptr
+  const char* run_segment(bool* finished) {
+    const size_t before = vm.segments.size();
+    *finished = false;
+    while (vm.segments.size() == before) {
+      if (lim.max_cycles && executed >= lim.max_cycles) { end_segment(2, 2); *finished = true; return nullptr; }  // SessionLimit
+      const bool running = step();
+      if (err) return r0h::make_error("guest trap at pc %#x after %llu cycles: %s", vm.pc, (unsigned long long)vm.cycles, err);
+      executed++;
+      if (!running) {
+        end_segment(exit_kind == R0H_VM_HALTED ? 0 : 1, exit_code);  // Halted(code) / Paused(code)
+        *finished = true;
+        return nullptr;
+      }
+    }
+    return nullptr;
+  }
 };
 }  // namespace
+
+r0h_vm::~r0h_vm() {
+  if (!table) return;
+  for (uint32_t idx : page_list) free(table[idx]);
+  free(table);
+}
+
+namespace r0h {
+namespace trace {
+const Tables& trace_tables() {
+  static const Tables T = [] {
+    Tables t;
+    memset(&t, 0, sizeof t);
+    for (uint32_t i = 1; i < 32; i++) t.inv_small[i] = inv(enc(i));
+    for (int c = 0; c < 4; c++)
+      for (uint32_t op = 0; op < 128; op++) t.inv_op[c][op] = op == opcode_class(c) ? 0u : inv(sub(enc(op), enc(opcode_class(c))));
+    return t;
+  }();
+  return T;
+}
+static const char* const COLUMN_NAMES[] = {
+    "live", "bnd", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi",
+    "bit0", "bit1", "bit2", "bit3", "bit4", "bit5", "bit6", "bit7", "bit8", "bit9", "bit10", "bit11", "bit12", "bit13", "bit14", "bit15",
+    "bit16", "bit17", "bit18", "bit19", "bit20", "bit21", "bit22", "bit23", "bit24", "bit25", "bit26", "bit27", "bit28", "bit29", "bit30", "bit31",
+    "is_jal", "is_jalr", "is_branch", "is_ecall", "inv_jal", "inv_jalr", "inv_branch", "inv_ecall",
+    "z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0",
+    "z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1",
+    "act2", "addr2", "inv_rd", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2",
+    "mem_kind", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "tw3",
+    "addr4", "p4", "tw4"};
+static_assert(sizeof COLUMN_NAMES / sizeof COLUMN_NAMES[0] == DIG0, "column names out of step with the enum");
+}  // namespace trace
+}  // namespace r0h
 
 using namespace r0h;
 
@@ -370,7 +536,9 @@ extern "C" {
 const char* r0h_vm_new(r0h_vm** out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(out, "r0h_vm_new: NULL argument");
-  *out = new r0h_vm;
+  std::unique_ptr<r0h_vm> vm(new r0h_vm);
+  R0H_REQUIRE(vm->table, "r0h_vm_new: out of memory");
+  *out = vm.release();
   return nullptr;
   R0H_GUARD_END
 }
@@ -385,9 +553,9 @@ const char* r0h_vm_load(r0h_vm* vm, uint32_t addr, const uint32_t* words, size_t
   R0H_REQUIRE((addr & 3) == 0 && (uint64_t)addr + 4 * (uint64_t)n <= ((uint64_t)1 << 32), "r0h_vm_load: [%#x, +%zu words) is misaligned or leaves the address space", addr, n);
   for (size_t i = 0; i < n; i++) {
     const uint32_t a = addr + 4 * (uint32_t)i;
-    auto it = vm->pages.find(a >> PAGE_SHIFT);
-    if (it == vm->pages.end()) it = vm->pages.emplace(a >> PAGE_SHIFT, std::vector<uint32_t>(PAGE_WORDS, 0)).first;
-    it->second[(a & (PAGE_BYTES - 1)) >> 2] = words[i];
+    Page* p = vm->get(a >> PAGE_SHIFT);
+    p->w[(a & (PAGE_BYTES - 1)) >> 2] = words[i];
+    vm->mark_stale(p, a >> PAGE_SHIFT);
   }
   return nullptr;
   R0H_GUARD_END
@@ -416,10 +584,13 @@ const char* r0h_vm_load_elf(r0h_vm* vm, const uint8_t* elf, size_t n) {
     // [filesz, memsz) is .bss: memory nothing has touched reads as zero already, so only what an earlier segment put there is
     // cleared -- a header may claim hundreds of megabytes, none of which need exist
     const uint64_t z0 = (uint64_t)vaddr + 4 * (uint64_t)words.size(), z1 = (uint64_t)vaddr + memsz;
-    for (auto it = vm->pages.lower_bound((uint32_t)(z0 >> PAGE_SHIFT)); it != vm->pages.end() && ((uint64_t)it->first << PAGE_SHIFT) < z1; ++it) {
-      const uint64_t base = (uint64_t)it->first << PAGE_SHIFT;
+    for (uint32_t idx : vm->page_list) {
+      const uint64_t base = (uint64_t)idx << PAGE_SHIFT;
+      if (base + PAGE_BYTES <= z0 || base >= z1) continue;
+      Page* p = vm->table[idx];
       for (uint32_t w = 0; w < PAGE_WORDS; w++)
-        if (base + 4 * w >= z0 && base + 4 * w < z1) it->second[w] = 0;
+        if (base + 4 * w >= z0 && base + 4 * w < z1) p->w[w] = 0;
+      vm->mark_stale(p, idx);
     }
   }
   vm->pc = entry;
@@ -451,39 +622,63 @@ const char* r0h_vm_read(const r0h_vm* vm, uint32_t addr, uint32_t* words, size_t
   R0H_REQUIRE(vm && words && (addr & 3) == 0, "r0h_vm_read: NULL argument or misaligned address");
   for (size_t i = 0; i < n; i++) {
     const uint32_t a = addr + 4 * (uint32_t)i;
-    auto it = vm->pages.find(a >> PAGE_SHIFT);
-    words[i] = it == vm->pages.end() ? 0u : it->second[(a & (PAGE_BYTES - 1)) >> 2];
+    const Page* p = vm->find(a >> PAGE_SHIFT);
+    words[i] = p ? p->w[(a & (PAGE_BYTES - 1)) >> 2] : 0u;
   }
   return nullptr;
 }
 
-const char* r0h_vm_run(r0h_vm* vm, const r0h_vm_limits* limits, int* exit_kind, uint32_t* exit_code) {
+const char* r0h_vm_run_segment(r0h_vm* vm, const r0h_vm_limits* limits, int* finished_out, int* exit_kind, uint32_t* exit_code) {
   R0H_GUARD_BEGIN
-  R0H_REQUIRE(vm && limits && exit_kind && exit_code, "r0h_vm_run: NULL argument");
+  R0H_REQUIRE(vm && limits && finished_out, "r0h_vm_run_segment: NULL argument");
   R0H_REQUIRE(limits->segment_po2 >= 6 && limits->segment_po2 <= 24, "r0h_vm_run: segment_po2 %u outside [6, 24]", limits->segment_po2);
   R0H_REQUIRE(!vm->finished, "r0h_vm_run: this machine has already run to its end (one run per r0h_vm: load a new one)");
-  vm->finished = true;
-  Run run(*vm, *limits);
-  run.begin_segment();
-  *exit_kind = R0H_VM_LIMIT;
-  *exit_code = 0;
-  uint64_t executed = 0;
-  bool running = true;
-  while (running) {
-    if (limits->max_cycles && executed >= limits->max_cycles) break;
-    running = run.step(exit_kind, exit_code);
-    if (run.err) {
-      const uint32_t at = vm->pc;
-      return make_error("guest trap at pc %#x after %llu cycles: %s", at, (unsigned long long)vm->cycles, run.err);
-    }
-    executed++;
+  if (!vm->run) {
+    vm->run.reset(new Run(*vm, *limits));
+    vm->run->begin_segment();
   }
-  // ExitCode of the last segment: Halted(code) / Paused(code) / SessionLimit
-  if (*exit_kind == R0H_VM_HALTED) run.end_segment(0, *exit_code);
-  else if (*exit_kind == R0H_VM_PAUSED) run.end_segment(1, *exit_code);
-  else run.end_segment(2, 2);
+  bool finished = false;
+  const char* err = vm->run->run_segment(&finished);
+  if (err || finished) vm->finished = true;
+  if (err) { vm->run.reset(); return err; }
+  *finished_out = finished ? 1 : 0;
+  if (finished) {
+    if (exit_kind) *exit_kind = vm->run->exit_kind;
+    if (exit_code) *exit_code = vm->run->exit_code;
+    vm->run.reset();
+  }
   return nullptr;
   R0H_GUARD_END
+}
+
+const char* r0h_vm_run(r0h_vm* vm, const r0h_vm_limits* limits, int* exit_kind, uint32_t* exit_code) {
+  R0H_REQUIRE(vm && limits && exit_kind && exit_code, "r0h_vm_run: NULL argument");
+  *exit_kind = R0H_VM_LIMIT;
+  *exit_code = 0;
+  for (int finished = 0; !finished;) R0H_TRY(r0h_vm_run_segment(vm, limits, &finished, exit_kind, exit_code));
+  return nullptr;
+}
+
+}  // extern "C"
+namespace r0h {
+// the rows of segment i change hands (session.hip hands them to the prover while the guest runs on)
+void vm_take_trace(r0h_vm* vm, size_t i, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds) {
+  rows.swap(vm->segments[i].rows);
+  bounds.swap(vm->segments[i].bounds);
+}
+// ... and come back empty-handed but with their memory, for a later segment to fill (call from the thread that runs the machine)
+void vm_recycle_trace(r0h_vm* vm, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds) {
+  if (rows.capacity()) { vm->spare_rows.emplace_back(); vm->spare_rows.back().swap(rows); }
+  if (bounds.capacity()) { vm->spare_bounds.emplace_back(); vm->spare_bounds.back().swap(bounds); }
+}
+}  // namespace r0h
+extern "C" {
+
+const char* r0h_vm_release_trace(r0h_vm* vm, size_t i) {
+  R0H_REQUIRE(vm && i < vm->segments.size(), "r0h_vm_release_trace: no such segment");
+  std::vector<r0h_preflight_row>().swap(vm->segments[i].rows);
+  std::vector<r0h_preflight_bound>().swap(vm->segments[i].bounds);
+  return nullptr;
 }
 
 size_t r0h_vm_n_segments(const r0h_vm* vm) { return vm ? vm->segments.size() : 0; }
@@ -502,54 +697,55 @@ const char* r0h_vm_preflight(const r0h_vm* vm, size_t i, const r0h_preflight_row
   *n = vm->segments[i].rows.size();
   return nullptr;
 }
-// The DATA group of the trace circuit (tools/gen_circuit.py trace: R0H_TRACE_COLUMNS columns of 2^po2 rows, column-major,
-// Montgomery words) from the preflight rows of segment i, and its three public inputs (first pc, pc after the last row, number of
-// rows).  Row r of the witness is cycle r of the segment; rows past the end are blank.  32-bit words enter as 16-bit halves where
-// the circuit only carries them, and reduced mod p where it does arithmetic on them (pc, addresses).
-const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint32_t* data_out, uint32_t globals_out[3]) {
+const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_bound** rows, size_t* n) {
+  R0H_REQUIRE(vm && rows && n, "r0h_vm_boundary: NULL argument");
+  R0H_REQUIRE(i < vm->segments.size(), "r0h_vm_boundary: segment %zu of %zu", i, vm->segments.size());
+  *rows = vm->segments[i].bounds.data();
+  *n = vm->segments[i].bounds.size();
+  return nullptr;
+}
+const char* r0h_trace_column_name(uint32_t column) {
+  static char digit_names[60][8];
+  static bool ready = false;
+  if (column < trace::DIG0) return trace::COLUMN_NAMES[column];
+  if (column >= trace::N_COLS) return nullptr;
+  if (!ready) {
+    for (int k = 0; k < 60; k++) snprintf(digit_names[k], sizeof digit_names[k], "d%d_%d", k / 12, k % 12);
+    ready = true;
+  }
+  return digit_names[column - trace::DIG0];
+}
+
+// The DATA group of the trace circuit on the host (the reference tests compare r0h_trace_witgen's device kernel with): cycles first,
+// then the boundary rows, blank rows to the end -- csrc/trace.hpp holds the expansion both sides compile.
+const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint32_t* data_out, uint32_t globals_out[R0H_TRACE_GLOBALS]) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(vm && data_out && globals_out, "r0h_vm_trace_witness: NULL argument");
   R0H_REQUIRE(i < vm->segments.size(), "r0h_vm_trace_witness: segment %zu of %zu", i, vm->segments.size());
   const std::vector<r0h_preflight_row>& rows = vm->segments[i].rows;
+  const std::vector<r0h_preflight_bound>& bounds = vm->segments[i].bounds;
   R0H_REQUIRE(!rows.empty(), "r0h_vm_trace_witness: segment %zu has no preflight rows (run with keep_trace)", i);
-  R0H_REQUIRE(po2 <= R0H_MAX_PO2 && rows.size() <= ((size_t)1 << po2), "r0h_vm_trace_witness: %zu rows do not fit 2^%u", rows.size(), po2);
+  R0H_REQUIRE(po2 <= R0H_TRACE_MAX_PO2 && rows.size() + bounds.size() <= ((size_t)1 << po2), "r0h_vm_trace_witness: %zu cycles and %zu boundary rows do not fit 2^%u",
+              rows.size(), bounds.size(), po2);
   const size_t n = (size_t)1 << po2;
+  const trace::Tables& T = trace::trace_tables();
   memset(data_out, 0, (size_t)R0H_TRACE_COLUMNS * n * 4);  // the Montgomery form of 0 is 0
-  auto put = [&](uint32_t col, size_t r, uint32_t v) { data_out[(size_t)col * n + r] = enc(v % P); };
-  for (size_t r = 0; r < rows.size(); r++) {
-    const r0h_preflight_row& w = rows[r];
-    put(0, r, 1);
-    put(1, r, (uint32_t)r);
-    put(2, r, w.pc);
-    put(3, r, w.next_pc);
-    put(4, r, w.next_pc == w.pc + 4 ? 1u : 0u);
-    put(5, r, w.insn & 0xffffu); put(6, r, w.insn >> 16);
-    put(7, r, w.rs1_value & 0xffffu); put(8, r, w.rs1_value >> 16);
-    put(9, r, w.rs2_value & 0xffffu); put(10, r, w.rs2_value >> 16);
-    put(11, r, w.rd);
-    put(12, r, w.rd_after & 0xffffu); put(13, r, w.rd_after >> 16);
-    put(14, r, w.mem_kind);
-    put(15, r, w.mem_addr);
-    put(16, r, w.mem_before & 0xffffu); put(17, r, w.mem_before >> 16);
-    put(18, r, w.mem_after & 0xffffu); put(19, r, w.mem_after >> 16);
-    for (uint32_t k = 0; k < 32; k++) put(20 + k, r, (w.insn >> k) & 1u);
-  }
-  // opcode classes that may leave the sequential path, pinned both ways by an inverse: flag = 1 iff the opcode is the class's
-  // (blank rows past the end carry opcode 0 and therefore the inverses of -code)
-  const uint32_t codes[3] = {0x6f, 0x67, 0x63};
-  uint32_t inv_of[3][128];
-  for (int c = 0; c < 3; c++)
-    for (uint32_t op = 0; op < 128; op++) inv_of[c][op] = op == codes[c] ? 0u : inv(sub(enc(op), enc(codes[c])));
   for (size_t r = 0; r < n; r++) {
-    const uint32_t op = r < rows.size() ? rows[r].insn & 0x7fu : 0u;
-    for (int c = 0; c < 3; c++) {
-      data_out[(size_t)(52 + c) * n + r] = op == codes[c] ? ONE : 0u;
-      data_out[(size_t)(55 + c) * n + r] = inv_of[c][op];
+    auto put = [&](uint32_t col, uint32_t v) { data_out[(size_t)col * n + r] = enc(v); };
+    auto raw = [&](uint32_t col, uint32_t w) { data_out[(size_t)col * n + r] = w; };
+    if (r < rows.size()) {
+      R0H_REQUIRE(rows[r].pc < P && rows[r].next_pc < P, "r0h_vm_trace_witness: pc %#x is not below p: the trace circuit carries a pc as one field element", rows[r].pc);
+      trace::live_row(rows[r], T, put, raw);
+    } else if (r < rows.size() + bounds.size()) {
+      const size_t j = r - rows.size();
+      trace::bound_row(bounds[j], j ? bounds[j - 1].addr : 0xffffffffu, T, put, raw);
+    } else {
+      trace::blank_row(T, put, raw);
     }
   }
-  globals_out[0] = enc(rows.front().pc % P);
-  globals_out[1] = enc(rows.back().next_pc % P);
-  globals_out[2] = enc((uint32_t)(rows.size() % P));
+  globals_out[8] = enc(rows.front().pc);
+  globals_out[9] = enc(rows.back().next_pc);
+  globals_out[10] = enc((uint32_t)rows.size());
   return nullptr;
   R0H_GUARD_END
 }
@@ -569,7 +765,7 @@ const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* 
   out->post = s.post;
   out->exit_system = s.exit_system;
   out->exit_user = s.exit_user;
-  if (i + 1 == vm->segments.size() && s.exit_system <= 1) R0H_TRY(r0h_output_digest(vm->journal.data(), vm->journal.size(), nullptr, out->output_digest));
+  if (vm->finished && i + 1 == vm->segments.size() && s.exit_system <= 1) R0H_TRY(r0h_output_digest(vm->journal.data(), vm->journal.size(), nullptr, out->output_digest));
   return nullptr;
 }
 

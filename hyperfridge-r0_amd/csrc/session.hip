@@ -5,13 +5,25 @@
 // What each stage is here: the executor is csrc/rv32im.hip (RV32IM by the specification; this library's ecall ABI and cycle model,
 // see there); `prove_segment` is the device-resident sequencer (csrc/prover.hip) at the trace size the segment needs; the claim of
 // every segment (system states from the run, exit code, the journal's output digest on the last one) is bound to its seal through
-// the public inputs (csrc/claim.hip).  What it is NOT: the witness is the circuit blob's synthetic column program with the claim
-// planted -- it is not derived from the preflight trace, because the rv32im step functions (risc0-circuit-rv32im-sys) cannot be
-// reproduced here (hard part 2).  The seal therefore proves "a satisfying trace of the loaded circuit exists whose
-// public inputs name this claim", not "this program ran": the row a9 gap, stated wherever this entry point is described.
+// the public inputs (csrc/claim.hip).
+//
+// With the trace circuit (circuits/trace.r0c, ProtocolInfo "R0HIP_TRACE:v2__") the seal of a segment attests THAT segment: the
+// executor keeps one compact row per cycle plus one per address touched, the device expands them into the DATA group
+// (csrc/trace.hip: 72 bytes per cycle cross PCIe, not the 576 bytes of an expanded row), and the proof is over those columns --
+// contiguity, control flow and memory consistency as include/r0hip.h lists them (what an instruction computes is risc0's rv32im
+// circuit and stays unconstrained).  The guest runs ahead on its own host thread; the calling thread proves segment k while
+// segment k + 1 executes.  With any other circuit the witness is the blob's synthetic column program with the claim
+// planted: the seal then proves "a satisfying trace of the loaded circuit exists whose public inputs name this claim", not
+// "this program ran".
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "circuit.hpp"
@@ -19,16 +31,67 @@
 
 using namespace r0h;
 
+namespace {
+using Clock = std::chrono::steady_clock;
+double seconds(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+struct CodeCommits {  // one committed CODE group per trace size met in the run
+  std::map<uint32_t, r0h_code_commit*> by_po2;
+  ~CodeCommits() { for (auto& kv : by_po2) r0h_code_commit_free(kv.second); }
+  const char* get(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, r0h_buf* data_scratch, r0h_code_commit** out) {
+    auto it = by_po2.find(po2);
+    if (it == by_po2.end()) {
+      // the fixed CODE columns come from the blob's column program (the DATA it also fills is scratch here)
+      const size_t n = (size_t)1 << po2;
+      r0h_buf* code = nullptr;
+      R0H_TRY(buf_alloc_pooled(ctx, (size_t)c->group_size[R0H_GROUP_CODE] * n * 4, &code));
+      const char* err = r0h_witgen(ctx, c, po2, 0, code, data_scratch, nullptr);
+      r0h_code_commit* cc = nullptr;
+      if (!err) err = r0h_code_commit_new(ctx, code, c->group_size[R0H_GROUP_CODE], po2, &cc);
+      r0h_buf_free(code);
+      if (err) return err;
+      it = by_po2.emplace(po2, cc).first;
+    }
+    *out = it->second;
+    return nullptr;
+  }
+};
+
+struct Produced {  // a segment as the executor thread hands it over
+  r0h_vm_segment info;
+  r0h_receipt_claim claim;
+  std::vector<r0h_preflight_row> rows;
+  std::vector<r0h_preflight_bound> bounds;
+};
+
+uint32_t trace_size(uint64_t rows) {
+  uint32_t po2 = 9;  // the sequencer's smallest trace
+  while (((uint64_t)1 << po2) < rows) po2++;
+  return po2;
+}
+}  // namespace
+
 extern "C" {
+
+const char* r0h_last_session_stats(r0h_ctx* ctx, r0h_session_stats* out) {
+  R0H_REQUIRE(ctx && out, "r0h_last_session_stats: NULL argument");
+  *out = ctx->session;
+  return nullptr;
+}
 
 const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words, size_t n_input, uint32_t segment_po2,
                           uint64_t max_cycles, r0h_receipt** receipt_out, uint8_t image_id_out[32], uint64_t* cycles_out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && c && elf && receipt_out && (input_words || !n_input), "r0h_prove_elf: NULL argument");
-  R0H_REQUIRE(segment_po2 >= 9 && segment_po2 <= R0H_MAX_PO2, "r0h_prove_elf: segment_po2 %u outside [9, %u]", segment_po2, R0H_MAX_PO2);
-  R0H_REQUIRE(c->has_column_program, "r0h_prove_elf: the circuit has no column program to plant a claim into");
+  const bool trace_mode = !memcmp(c->info, "R0HIP_TRACE:v2__", 16);
+  R0H_REQUIRE(segment_po2 >= 9 && segment_po2 <= (trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2), "r0h_prove_elf: segment_po2 %u outside [9, %u]", segment_po2,
+              (unsigned)(trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2));
+  R0H_REQUIRE(c->has_column_program, "r0h_prove_elf: the circuit has no column program (CODE columns, accumulation)");
   R0H_REQUIRE(c->n_global >= 8, "r0h_prove_elf: the circuit exposes %u public inputs, a claim needs 8", c->n_global);
-  // 1. execute and segment (no trace kept: the synthetic witness does not read it)
+  if (trace_mode) R0H_REQUIRE(c->n_global == R0H_TRACE_GLOBALS && c->group_size[R0H_GROUP_DATA] == R0H_TRACE_COLUMNS, "r0h_prove_elf: this trace circuit is not the one the library was built for");
+  if (!max_cycles) max_cycles = R0H_DEFAULT_SESSION_LIMIT;  // a guest that never halts must not hang the host (risc0: session limit)
+  const Clock::time_point t_begin = Clock::now();
+  r0h_session_stats stats = {0, 0, 0, 0, 0, 0};
   r0h_vm* vm = nullptr;
   R0H_TRY(r0h_vm_new(&vm));
   struct VmGuard { r0h_vm* v; ~VmGuard() { r0h_vm_free(v); } } guard{vm};
@@ -38,49 +101,149 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
   memset(&lim, 0, sizeof lim);
   lim.segment_po2 = segment_po2;
   lim.max_cycles = max_cycles;
-  int exit_kind = 0;
+  lim.keep_trace = lim.boundary_rows = trace_mode ? 1 : 0;
+
+  // ---- the executor runs ahead on its own thread; at most two finished segments wait (a 2^20-cycle segment holds 72 MiB of rows)
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::unique_ptr<Produced>> queue;
+  std::vector<std::unique_ptr<Produced>> returned;  // proved segments on their way back: the executor refills their row buffers
+  bool producer_done = false, stop = false;
+  const char* producer_err = nullptr;
+  int exit_kind = R0H_VM_LIMIT;
   uint32_t exit_code = 0;
-  R0H_TRY(r0h_vm_run(vm, &lim, &exit_kind, &exit_code));
+  double executor_s = 0;
+  std::thread producer([&] {
+    const char* err = nullptr;
+    try {
+      for (int finished = 0; !finished && !err;) {
+        std::vector<std::unique_ptr<Produced>> back;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || queue.size() < 2; });
+          if (stop) break;
+          back.swap(returned);
+        }
+        for (auto& b : back) vm_recycle_trace(vm, b->rows, b->bounds);
+        const Clock::time_point t0 = Clock::now();
+        err = r0h_vm_run_segment(vm, &lim, &finished, &exit_kind, &exit_code);
+        executor_s += seconds(t0, Clock::now());
+        if (err) break;
+        std::unique_ptr<Produced> p(new Produced());
+        const size_t i = r0h_vm_n_segments(vm) - 1;
+        err = r0h_vm_segment_info(vm, i, &p->info);
+        if (!err) err = r0h_vm_segment_claim(vm, i, &p->claim);
+        if (err) break;
+        if (trace_mode) vm_take_trace(vm, i, p->rows, p->bounds);
+        std::lock_guard<std::mutex> lk(mu);
+        queue.push_back(std::move(p));
+        cv.notify_all();
+      }
+    } catch (const std::exception& ex) {
+      err = make_error("exception in the executor: %s", ex.what());
+    } catch (...) {
+      err = make_error("unknown exception in the executor");
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    producer_err = err;
+    producer_done = true;
+    cv.notify_all();
+  });
+  // the row buffers are recycled, so there are three or four of them in a run: each is page-locked the first time it is seen
+  // (hipHostRegister) and the 72 MiB of a segment then cross PCIe by DMA at the link's rate instead of through a staging copy
+  struct Pins {
+    std::map<const void*, size_t> seen;
+    void pin(const void* p, size_t bytes) {
+      if (!p || !bytes) return;
+      auto it = seen.find(p);
+      if (it != seen.end() && it->second >= bytes) return;
+      if (it != seen.end()) { (void)hipHostUnregister(const_cast<void*>(p)); seen.erase(it); }
+      if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) seen[p] = bytes;
+      else (void)hipGetLastError();  // pageable memory still works, only slower
+    }
+    ~Pins() { for (auto& kv : seen) (void)hipHostUnregister(const_cast<void*>(kv.first)); }
+  } pins;
+  struct Join {  // whatever path leaves this function: the executor thread is told to stop and joined first
+    std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
+    ~Join() {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv.notify_all();
+      if (t.joinable()) t.join();
+    }
+  } join{producer, mu, cv, stop};
+
+  // ---- prove every segment for its claim, as it arrives
+  r0h_receipt* rc = nullptr;
+  R0H_TRY(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, nullptr, 0, &rc));
+  std::unique_ptr<r0h_receipt, const char* (*)(r0h_receipt*)> rc_guard(rc, r0h_receipt_free);
+  CodeCommits commits;
+  std::vector<uint32_t> seal((size_t)1 << 20), global(c->n_global);
+  r0h_system_state first_pre;
+  memset(&first_pre, 0, sizeof first_pre);
+  for (size_t i = 0;; i++) {
+    std::unique_ptr<Produced> seg;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !queue.empty() || producer_done; });
+      if (queue.empty()) {
+        if (producer_err) { const char* e = producer_err; producer_err = nullptr; return e; }
+        break;
+      }
+      seg = std::move(queue.front());
+      queue.pop_front();
+      cv.notify_all();
+    }
+    if (i == 0) first_pre = seg->info.pre;
+    const uint64_t rows_needed = trace_mode ? seg->rows.size() + seg->bounds.size() : seg->info.user_cycles + seg->info.paging_cycles;
+    const uint32_t po2 = trace_size(rows_needed);
+    uint8_t cd[32];
+    claim_digest(seg->claim, cd);
+    std::fill(global.begin(), global.end(), 0u);
+    claim_globals(cd, global.data());
+    const size_t n = (size_t)1 << po2;
+    r0h_buf* data = nullptr;
+    R0H_TRY(buf_alloc_pooled(ctx, (size_t)c->group_size[R0H_GROUP_DATA] * n * 4, &data));
+    struct Free { r0h_buf* b; ~Free() { r0h_buf_free(b); } } data_guard{data};
+    r0h_code_commit* cc = nullptr;
+    R0H_TRY(commits.get(ctx, c, po2, data, &cc));
+    const Clock::time_point t0 = Clock::now();
+    size_t words = 0;
+    if (trace_mode) {
+      pins.pin(seg->rows.data(), seg->rows.capacity() * sizeof(r0h_preflight_row));
+      R0H_TRY(r0h_trace_witgen(ctx, seg->rows.data(), seg->rows.size(), seg->bounds.data(), seg->bounds.size(), po2, data, global.data()));
+    } else {
+      // synthetic column program with the claim planted (CODE is regenerated into a scratch block: only DATA is used)
+      r0h_buf* code = nullptr;
+      R0H_TRY(buf_alloc_pooled(ctx, (size_t)c->group_size[R0H_GROUP_CODE] * n * 4, &code));
+      const char* err = r0h_witgen_public(ctx, c, po2, 0x5E55 + i, global.data(), code, data);
+      r0h_buf_free(code);
+      if (err) return err;
+    }
+    const Clock::time_point t1 = Clock::now();
+    R0H_TRY(r0h_prove_segment_committed(ctx, c, po2, cc, data, global.data(), seal.data(), seal.size(), &words));
+    const Clock::time_point t2 = Clock::now();
+    stats.witgen_ms += 1e3 * seconds(t0, t1);
+    stats.prove_ms += 1e3 * seconds(t1, t2);
+    stats.segments++;
+    R0H_TRY(r0h_receipt_add_segment_claim(rc, seal.data(), words, (uint32_t)i, &seg->claim, nullptr));
+    if (trace_mode) {  // the row buffers go back to the executor
+      std::lock_guard<std::mutex> lk(mu);
+      returned.push_back(std::move(seg));
+    }
+  }
+  producer.join();  // finished: the machine is this thread's again
   R0H_REQUIRE(exit_kind != R0H_VM_LIMIT, "r0h_prove_elf: the guest did not halt within %llu cycles (session limit)", (unsigned long long)max_cycles);
   R0H_REQUIRE(exit_code == 0, "r0h_prove_elf: the guest exited with code %u", exit_code);  // `prove` is an Err for a failed guest
   if (cycles_out) *cycles_out = r0h_vm_cycles(vm);
   const uint8_t* journal; size_t journal_len;
   R0H_TRY(r0h_vm_journal(vm, &journal, &journal_len));
-  // 2. prove every segment for its claim
-  r0h_receipt* rc = nullptr;
-  R0H_TRY(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, journal, journal_len, &rc));
-  std::unique_ptr<r0h_receipt, const char* (*)(r0h_receipt*)> rc_guard(rc, r0h_receipt_free);
-  const size_t n_seg = r0h_vm_n_segments(vm);
-  std::vector<uint32_t> seal((size_t)1 << 20), global(c->n_global);
-  for (size_t i = 0; i < n_seg; i++) {
-    r0h_vm_segment info;
-    r0h_receipt_claim claim;
-    R0H_TRY(r0h_vm_segment_info(vm, i, &info));
-    R0H_TRY(r0h_vm_segment_claim(vm, i, &claim));
-    uint32_t po2 = 9;  // the smallest trace that holds the segment's cycles
-    while (((uint64_t)1 << po2) < info.user_cycles + info.paging_cycles) po2++;
-    uint8_t cd[32];
-    claim_digest(claim, cd);
-    std::fill(global.begin(), global.end(), 0u);
-    claim_globals(cd, global.data());
-    const size_t n = (size_t)1 << po2;
-    r0h_buf *code = nullptr, *data = nullptr;
-    R0H_TRY(buf_alloc_pooled(ctx, (size_t)c->group_size[R0H_GROUP_CODE] * n * 4, &code));
-    const char* err = buf_alloc_pooled(ctx, (size_t)c->group_size[R0H_GROUP_DATA] * n * 4, &data);
-    size_t words = 0;
-    if (!err) err = r0h_witgen_public(ctx, c, po2, 0x5E55 + i, global.data(), code, data);
-    if (!err) err = r0h_prove_segment(ctx, c, po2, code, data, global.data(), seal.data(), seal.size(), &words);
-    r0h_buf_free(code);
-    if (data) r0h_buf_free(data);
-    if (err) return err;
-    R0H_TRY(r0h_receipt_add_segment_claim(rc, seal.data(), words, (uint32_t)i, &claim, nullptr));
-  }
-  // 3. the image id the verifier is given: digest of the state the run started from
-  if (image_id_out) {
-    r0h_vm_segment first;
-    R0H_TRY(r0h_vm_segment_info(vm, 0, &first));
-    system_state_digest(first.pre, image_id_out);
-  }
+  rc->journal.assign(journal, journal + journal_len);
+  // the image id the verifier is given: digest of the state the run started from
+  if (image_id_out) system_state_digest(first_pre, image_id_out);
+  stats.cycles = r0h_vm_cycles(vm);
+  stats.executor_s = executor_s;
+  stats.wall_s = seconds(t_begin, Clock::now());
+  ctx->session = stats;
   *receipt_out = rc_guard.release();
   return nullptr;
   R0H_GUARD_END

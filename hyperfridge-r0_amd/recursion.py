@@ -162,11 +162,14 @@ def torch_transport(device=None):
     def send(words, dst):
         n = torch.tensor([int(words.size)], dtype=torch.int64, device=dev)
         dist.send(n, dst)
-        dist.send(torch.from_numpy(words.view(np.int32).copy()).to(dev), dst)
+        if words.size:  # an EMPTY message is its length word alone: no zero-byte point-to-point transfer (both sides skip it)
+            dist.send(torch.from_numpy(words.view(np.int32).copy()).to(dev), dst)
 
     def recv(src):
         n = torch.zeros(1, dtype=torch.int64, device=dev)
         dist.recv(n, src)
+        if int(n.item()) == 0:
+            return np.zeros(0, dtype=np.uint32)
         buf = torch.empty(int(n.item()), dtype=torch.int32, device=dev)
         dist.recv(buf, src)
         return buf.cpu().numpy().view(np.uint32)

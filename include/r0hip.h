@@ -282,7 +282,8 @@ const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out);
  * receipt/composite.rs does it: every seal verifies against the control root of its trace size (control_roots: n_roots records of
  * 9 words [po2, root[8]], from r0h_code_root), its public inputs name the segment's claim, the segments chain (index, SystemSplit,
  * post-state == next pre-state), the last claim's output commits to SHA-256(journal.bytes) and exits Halted(0)/Paused(0), and the
- * first pre-state's digest is image_id (32 bytes; NULL skips that last comparison).  Pure host code.  Returns NULL when the check
+ * first pre-state's digest is image_id (32 bytes; with NULL the outcome is at best R0H_RECEIPT_V_UNBOUND, never OK).  A seal of the
+ * trace circuit must also carry its claim's first and last pc as public inputs 8 and 9.  Pure host code.  Returns NULL when the check
  * ran: *verdict_out is R0H_RECEIPT_V_*; *segment_out (optional) the segment at fault; *seal_verdict_out (optional) the R0H_VERIFY_*
  * code when the verdict is R0H_RECEIPT_V_SEAL. */
 #define R0H_RECEIPT_V_OK 0
@@ -297,9 +298,15 @@ const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out);
 #define R0H_RECEIPT_V_EXIT_CODE 9
 #define R0H_RECEIPT_V_NO_BINDING 10
 #define R0H_RECEIPT_V_HASHFN 11
+#define R0H_RECEIPT_V_UNBOUND 12 /* everything else holds, but image_id was NULL: the receipt is not tied to a program */
 const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots,
                                size_t n_roots, const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out);
 const char* r0h_receipt_verify_reason(int verdict); /* static string, do not free */
+/* The image id as text, the reference's way (host/src/main.rs:445-449, verifier/src/main.rs:131-143, host/out/IMAGE_ID.hex): eight
+ * u32 words printed `{:08x}`, each stored little-endian in the 32-byte digest (`Digest::from([u32; 8])`) -- NOT the digest's bytes
+ * in order.  Strict: exactly 64 hex digits. */
+const char* r0h_image_id_from_hex(const char* hex, uint8_t image_id_out[32]);
+const char* r0h_image_id_to_hex(const uint8_t image_id[32], char hex_out[65]);
 
 /* ---- EBICS pre-processing: what data/checkResponse.sh does with xmllint / openssl / zlib-flate / unzip
  * before `host` starts (host/src/main.rs:143-151), as pure host code.  r0h_ebics_parse cuts the guest's four XML inputs out of a
@@ -351,31 +358,46 @@ const char* r0h_zlib_inflate(const uint8_t* in, size_t n, uint8_t** out, size_t*
 /* ---- RV32IM executor, segmenter and preflight trace (csrc/rv32im.hip): the part of `prover.prove(env, elf)`
  * that runs before prove_segment.  Pure host code.  Instruction semantics are the RISC-V specification's; the ecall ABI, the cycle
  * model and the page Merkle root are this library's own documented choices (risc0's are recalled in outline only: see the source).
- * ecall (a7): 0 HALT(a0) | 1 READ_WORDS(a0 = dst, a1 = n) | 2 COMMIT(a0 = src, a1 = n bytes) | 3 CYCLES -> a0 | 4 PAUSE(a0). ---- */
+ * ecall (a7): 0 HALT(a0) | 1 READ_WORDS(a0 = dst, a1 = n) | 2 COMMIT(a0 = src, a1 = n bytes) | 3 CYCLES -> a0 | 4 PAUSE(a0).
+ * The two I/O ecalls move ONE word per cycle, the way `rep movs` does: the instruction re-executes (next pc = pc) with a1 counting
+ * down until it is 0, so that every cycle has at most one memory access -- what the trace circuit's row has room for -- and a
+ * transfer of any length can be cut between two segments.  a1 is 0 afterwards; a0 is left as it was. ---- */
 typedef struct r0h_vm r0h_vm;
 typedef struct {
-  uint32_t segment_po2;     /* a segment holds at most 2^segment_po2 cycles (instructions + paging) */
+  uint32_t segment_po2;     /* a segment holds at most 2^segment_po2 rows (cycles + paging + boundary rows) */
   uint32_t page_in_cycles;  /* charged once per 1 KiB page first touched in a segment */
   uint32_t page_out_cycles; /* charged once per page written in a segment */
-  uint32_t keep_trace;      /* record one r0h_preflight_row per instruction */
-  uint64_t max_cycles;      /* stop (R0H_VM_LIMIT, ExitCode::SessionLimit) after this many instructions; 0 = no limit */
+  uint32_t keep_trace;      /* record one r0h_preflight_row per cycle and the boundary rows of every segment */
+  uint64_t max_cycles;      /* stop (R0H_VM_LIMIT, ExitCode::SessionLimit) after this many cycles; 0 = no limit */
+  uint32_t boundary_rows;   /* charge one row per distinct register / memory word touched in a segment: the rows the trace
+                             * circuit spends on the first and last value of each (set by r0h_prove_elf for a trace circuit) */
+  uint32_t reserved;
 } r0h_vm_limits;
 typedef struct {
-  uint32_t index, exit_system, exit_user, pages_in, pages_out, reserved;
+  uint32_t index, exit_system, exit_user, pages_in, pages_out, boundary_rows;
   uint64_t user_cycles, paging_cycles;
   r0h_system_state pre, post; /* pc + Merkle root of memory before the first and after the last instruction of the segment */
 } r0h_vm_segment;
 #define R0H_MEM_NONE 0
 #define R0H_MEM_READ 1
 #define R0H_MEM_WRITE 2
-/* what witness generation replays, one row per cycle: the instruction, its operands and result, and its memory transaction */
+/* What witness generation replays, one row per cycle (18 words): the instruction, its register operands and result, its memory
+ * transaction, and -- for the memory-consistency argument of the trace circuit -- when each of the five things the cycle touches
+ * was last touched in this segment.  Access k of cycle c carries the timestamp 5 c + k + 1 (k = 0 x[rs1] read, 1 x[rs2] read,
+ * 2 x[rd] write, 3 the memory word, 4 the instruction fetch); prev[k] is the timestamp of the previous access to the same
+ * register / word in this segment, 0 when this is the first.  rs1 / rs2 are instruction bits 15..19 / 20..24 whatever the format. */
 typedef struct {
-  uint64_t cycle;  /* within the segment */
+  uint32_t cycle;  /* within the segment */
   uint32_t pc, insn, next_pc;
   uint32_t rs1_value, rs2_value;
-  uint32_t rd, rd_after;                           /* rd = 0: no register written */
+  uint32_t rd, rd_before, rd_after;                    /* rd = 0: no register written */
   uint32_t mem_kind, mem_addr, mem_before, mem_after; /* word-aligned address, the word before and after */
+  uint32_t prev[5];
 } r0h_preflight_row;
+/* One per register / memory word a segment touched, in increasing address order: the value the segment found there, the value it
+ * left, and the timestamp of its last access.  addr: word index (byte address / 4) for memory, R0H_REG_BASE + i for x[i]. */
+#define R0H_REG_BASE 0x40000000u
+typedef struct { uint32_t addr, first_value, last_value, last_ts; } r0h_preflight_bound;
 #define R0H_VM_HALTED 0
 #define R0H_VM_PAUSED 1
 #define R0H_VM_LIMIT 2
@@ -392,32 +414,66 @@ const char* r0h_vm_read(const r0h_vm* vm, uint32_t addr, uint32_t* words, size_t
 /* runs to HALT / PAUSE / max_cycles, cutting segments on the way; a guest trap (illegal instruction, misaligned access, unknown
  * ecall) is an error string, as a guest panic is an Err from `prove` (host/src/main.rs:327-330) */
 const char* r0h_vm_run(r0h_vm* vm, const r0h_vm_limits* limits, int* exit_kind_out, uint32_t* exit_code_out);
+/* the same run one segment at a time (a prover takes each segment as it is cut, while the guest runs on): returns after the next
+ * segment is complete; *finished_out = 1 with the last one (then exit_kind / exit_code are set).  The limits of the first call hold
+ * for the whole run.  r0h_vm_release_trace drops the rows of a segment that has been taken (its r0h_vm_segment stays). */
+const char* r0h_vm_run_segment(r0h_vm* vm, const r0h_vm_limits* limits, int* finished_out, int* exit_kind_out, uint32_t* exit_code_out);
+const char* r0h_vm_release_trace(r0h_vm* vm, size_t i);
 size_t r0h_vm_n_segments(const r0h_vm* vm);
 uint64_t r0h_vm_cycles(const r0h_vm* vm);
 const char* r0h_vm_segment_info(const r0h_vm* vm, size_t i, r0h_vm_segment* out);
 const char* r0h_vm_preflight(const r0h_vm* vm, size_t i, const r0h_preflight_row** rows, size_t* n);
-/* Witness of the trace circuit (circuits/trace.r0c, tools/gen_circuit.py): the DATA group IS the preflight trace of segment i --
- * R0H_TRACE_COLUMNS columns of 2^po2 rows, column-major, Montgomery words, blank past the last row: the 20 fields of
- * r0h_preflight_row (32-bit words as halves), the instruction word bit by bit, three opcode-class flags and their inverses -- and
- * the three public inputs (first pc, pc after the last row, number of rows).  The circuit constrains that the rows form one
- * contiguous run (each live row starts where its predecessor went, one cycle later; reads leave memory unchanged; padding only at
- * the end) whose control flow follows the instruction words: a step leaves pc + 4 only at a JAL / JALR / branch word, JAL goes to
- * pc + imm_J, a branch to pc + 4 or pc + imm_B.  Branch conditions, JALR targets, register and memory contents are NOT
- * constrained -- that is the rv32im circuit, which cannot be reproduced here. */
-#define R0H_TRACE_COLUMNS 58
-const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint32_t* data_out, uint32_t globals_out[3]);
+const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_bound** rows, size_t* n);
+/* ---- the trace circuit (circuits/trace.r0c, tools/gen_circuit.py): a circuit whose DATA group IS the preflight trace of a segment.
+ * R0H_TRACE_COLUMNS columns of 2^po2 rows, column-major, Montgomery words: first the cycles (one row each), then the boundary rows
+ * (one per register / word touched), then blank rows.  Per cycle: pc, next pc, the instruction word bit by bit, opcode-class flags,
+ * and five accesses -- x[rs1], x[rs2], x[rd], the memory word, the fetched word -- each as (address, value, timestamp of the
+ * previous access, own timestamp).  What the circuit constrains:
+ *   - the cycles form one contiguous run from the public first pc to the public last pc in the public number of cycles;
+ *   - control flow follows the instruction words: a step leaves pc + 4 only at a JAL / JALR / branch / ecall word, JAL goes to
+ *     pc + imm_J, a branch to pc + 4 or pc + imm_B, an ecall to pc or pc + 4;
+ *   - MEMORY CONSISTENCY over registers and memory as one address space (offline memory checking): every access reads the tuple
+ *     (address, value, timestamp) the previous access to that address wrote and writes a new one with a larger timestamp; the
+ *     boundary rows write each address's first tuple (timestamp 0) and read its last; the multiset of tuples read equals the
+ *     multiset written, checked as a grand product over r0h_prefix_products in the ACCUM group; boundary addresses strictly
+ *     increase, so an address has ONE history.  Hence a register or word read returns what was last written to it, the
+ *     instruction word at a pc is the word in memory, x0 reads as zero, rs1 / rs2 / rd are the registers the word names.
+ * What it does NOT constrain: what an instruction computes (ALU results, branch conditions, load/store addresses, JALR targets:
+ * risc0's rv32im circuit, not reproducible here), and that the first values of the boundary rows are the pre-state's memory
+ * (risc0 pages memory in through in-circuit Merkle proofs).  Public inputs: 8 words naming the segment's ReceiptClaim
+ * (r0h_claim_globals), first pc, pc after the last cycle, number of cycles.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
+#define R0H_TRACE_COLUMNS 144
+#define R0H_TRACE_GLOBALS 11
+#define R0H_TRACE_MAX_PO2 21
+const char* r0h_trace_column_name(uint32_t column); /* static string; NULL past the last column */
+/* host reference of the witness (what tests compare the device kernel with): data_out = R0H_TRACE_COLUMNS * 2^po2 words;
+ * globals_out[8..11) = first pc, pc after the last cycle, cycles (globals_out[0..8) are left to the caller: the claim) */
+const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint32_t* data_out, uint32_t globals_out[R0H_TRACE_GLOBALS]);
+/* the same on the device: the compact rows (72 B per cycle, 16 B per boundary row) are uploaded and one thread per row expands
+ * them into the column-major Montgomery DATA group in `data` (R0H_TRACE_COLUMNS * 2^po2 words).  Stream-ordered; the host arrays
+ * may be released when the call returns. */
+const char* r0h_trace_witgen(r0h_ctx* ctx, const r0h_preflight_row* rows, size_t n_rows, const r0h_preflight_bound* bounds,
+                             size_t n_bounds, uint32_t po2, r0h_buf* data, uint32_t globals_out[R0H_TRACE_GLOBALS]);
 const char* r0h_vm_journal(const r0h_vm* vm, const uint8_t** bytes, size_t* n);
 /* the ReceiptClaim of segment i: system states and exit code from the run, Output{journal} on the last segment */
 const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* out);
 
 /* ---- `default_prover().prove(env, elf)` (host/src/main.rs:420-423) in one call: execute the ELF on the word stream of `env`,
- * cut the run into segments of at most 2^segment_po2 cycles, prove each at the smallest trace size that holds it, return the
+ * cut the run into segments of at most 2^segment_po2 rows, prove each at the smallest trace size that holds it, return the
  * composite receipt with every segment's claim bound to its seal, plus the image id `receipt.verify` is given.  A guest that
- * traps, exits non-zero or exceeds max_cycles (0 = unlimited) is an error, as it is an Err from `prove`.  The witness of every
- * segment is the circuit's synthetic column program with the claim planted, NOT the execution trace (csrc/session.hip). ---- */
+ * traps, exits non-zero or exceeds max_cycles is an error, as it is an Err from `prove`; max_cycles = 0 selects
+ * R0H_DEFAULT_SESSION_LIMIT (risc0's executor has a session limit as well).
+ * With the trace circuit (circuits/trace.r0c) every seal attests the segment it stands for: the executor keeps the preflight
+ * rows, r0h_trace_witgen expands them on the device, the public inputs carry the claim, the first and last pc and the cycle count,
+ * and the guest runs ahead on its own thread while the device proves.  With any other circuit the witness is that circuit's
+ * synthetic column program with the claim planted (the seal then proves only that a satisfying trace naming the claim exists). ---- */
+#define R0H_DEFAULT_SESSION_LIMIT ((uint64_t)1 << 32)
 const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words,
                           size_t n_input, uint32_t segment_po2, uint64_t max_cycles, r0h_receipt** receipt_out,
                           uint8_t image_id_out[32], uint64_t* cycles_out);
+/* per-stage timing of the last r0h_prove_elf on this context (for tools/bench_session.py): names are static strings */
+typedef struct { uint32_t segments; uint64_t cycles; double executor_s, witgen_ms, prove_ms, wall_s; } r0h_session_stats;
+const char* r0h_last_session_stats(r0h_ctx* ctx, r0h_session_stats* out);
 
 /* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
  * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */

@@ -22,6 +22,10 @@
  *   INFO    (7): optional, 4 words = the circuit's 16-byte ProtocolInfo tag committed into the transcript (risc0 `CIRCUIT_INFO`)
  *   ACCUM   (6): n_acc, (first_code_col, a_data_col, b_data_col): extension column j (ACCUM columns 4j..4j+3) is the
  *                running product of (mix[8j..8j+4) + a + mix[8j+4..8j+8) * b) from row 0
+ *   ACCUM_FP (8): [instead of ACCUM: the memory-consistency argument of the trace circuit] n_acc, then 13 words per accumulator:
+ *                n_f (1..3) and three (addr, lo, hi, t) quadruples of DATA columns; extension column j is the running product
+ *                from row 0 of prod_{f < n_f} (alpha - addr_f - b1 lo_f - b2 hi_f - b3 t_f) with alpha = mix[0..4),
+ *                b1 = mix[4..8), b2 = mix[8..12), b3 = mix[12..16) shared by all accumulators (n_mix = 16)
  */
 #ifndef R0HIP_CIRCUIT_H
 #define R0HIP_CIRCUIT_H
@@ -33,6 +37,7 @@
 #define R0H_SEC_WITGEN 5
 #define R0H_SEC_ACCUM 6
 #define R0H_SEC_INFO 7
+#define R0H_SEC_ACCUM_FP 8
 #define R0H_OP_CONST 0
 #define R0H_OP_GET 2
 #define R0H_OP_GET_GLOBAL 3

@@ -18,7 +18,7 @@
 #include <string.h>
 
 #define BLOB_MAGIC 0x31433052u
-enum { SEC_GROUPS = 1, SEC_TAPS = 2, SEC_GLOBALS = 3, SEC_POLY = 4, SEC_WITGEN = 5, SEC_ACCUM = 6, SEC_INFO = 7 };
+enum { SEC_GROUPS = 1, SEC_TAPS = 2, SEC_GLOBALS = 3, SEC_POLY = 4, SEC_WITGEN = 5, SEC_ACCUM = 6, SEC_INFO = 7, SEC_ACCUM_FP = 8 };
 
 uint32_t orc_circuit_group_size(const orc_circuit_t* c, uint32_t g) { return c->group_size[g]; }
 uint32_t orc_circuit_n_taps(const orc_circuit_t* c) { return c->n_taps; }
@@ -29,7 +29,7 @@ uint32_t orc_circuit_n_combos(const orc_circuit_t* c) { return c->n_combos; }
 void orc_circuit_free(orc_circuit_t* c) {
   if (!c) return;
   free(c->taps); free(c->regs); free(c->combo_begin); free(c->combo_backs); free(c->steps);
-  free(c->code_cols); free(c->data_cols); free(c->acc_cols); free(c->global_cols); free(c);
+  free(c->code_cols); free(c->data_cols); free(c->acc_cols); free(c->acc_fp); free(c->global_cols); free(c);
 }
 
 static void derive_regs_and_combos(orc_circuit_t* c) {
@@ -106,6 +106,12 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
         c->acc_cols = (orc_acc_col_t*)malloc(sizeof(orc_acc_col_t) * (c->n_acc ? c->n_acc : 1));
         memcpy(c->acc_cols, p + 1, sizeof(orc_acc_col_t) * c->n_acc);
         break;
+      case SEC_ACCUM_FP:
+        if (len < 1 || len != 1 + 13 * (size_t)p[0]) goto bad;
+        c->n_acc_fp = p[0];
+        c->acc_fp = (orc_acc_fp_t*)malloc(sizeof(orc_acc_fp_t) * (c->n_acc_fp ? c->n_acc_fp : 1));
+        memcpy(c->acc_fp, p + 1, sizeof(orc_acc_fp_t) * c->n_acc_fp);
+        break;
       case SEC_INFO:
         if (len >= 4) memcpy(c->info, p, 16);
         break;
@@ -119,10 +125,18 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
     else c->n_fp_vars++;
   }
   /* WITGEN/ACCUM (the synthetic column program) are optional: circuits imported from risc0 tables omit both */
-  if ((c->code_cols || c->acc_cols) &&
-      (c->n_code != c->group_size[ORC_GROUP_CODE] || c->n_data != c->group_size[ORC_GROUP_DATA] ||
-       4 * c->n_acc != c->group_size[ORC_GROUP_ACCUM] || c->n_mix != 8 * c->n_acc))
+  if ((c->code_cols || c->acc_cols || c->acc_fp) && (c->n_code != c->group_size[ORC_GROUP_CODE] || c->n_data != c->group_size[ORC_GROUP_DATA])) goto bad;
+  if (c->acc_fp) {  /* the trace circuit's memory-consistency accumulators: alpha, b1, b2, b3 shared */
+    if (c->acc_cols || 4 * c->n_acc_fp != c->group_size[ORC_GROUP_ACCUM] || c->n_mix != 16) goto bad;
+    for (uint32_t j = 0; j < c->n_acc_fp; j++) {
+      if (c->acc_fp[j].n_f < 1 || c->acc_fp[j].n_f > 3) goto bad;
+      for (int f = 0; f < 3; f++)
+        for (int q = 0; q < 4; q++)
+          if (c->acc_fp[j].col[f][q] >= c->n_data) goto bad;
+    }
+  } else if ((c->code_cols || c->acc_cols) && (4 * c->n_acc != c->group_size[ORC_GROUP_ACCUM] || c->n_mix != 8 * c->n_acc)) {
     goto bad;
+  }
   derive_regs_and_combos(c);
   return c;
 bad:
@@ -208,6 +222,30 @@ void orc_accum(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const
   (void)code;
   size_t n = (size_t)1 << po2;
   fp4_t* tmp = (fp4_t*)malloc(sizeof(fp4_t) * n);
+  for (uint32_t j = 0; j < c->n_acc_fp; j++) {
+    /* running product over the rows of prod_f (alpha - addr_f - b1 lo_f - b2 hi_f - b3 t_f): the tuples one side of the
+     * memory argument reads (or writes) in a row */
+    const orc_acc_fp_t* a = &c->acc_fp[j];
+    fp4_t m[4];
+    memcpy(m, mix, 64);
+#pragma omp parallel for
+    for (size_t r = 0; r < n; r++) {
+      fp4_t prod = fp4_one();
+      for (uint32_t f = 0; f < a->n_f; f++) {
+        const fp_t addr = data[(size_t)a->col[f][0] * n + r], lo = data[(size_t)a->col[f][1] * n + r];
+        const fp_t hi = data[(size_t)a->col[f][2] * n + r], t = data[(size_t)a->col[f][3] * n + r];
+        fp4_t term = fp4_sub(fp4_sub(fp4_sub(m[0], fp4_scale(m[1], lo)), fp4_scale(m[2], hi)), fp4_scale(m[3], t));
+        term = fp4_sub(term, fp4_from_fp(addr));
+        prod = fp4_mul(prod, term);
+      }
+      tmp[r] = prod;
+    }
+    orc_prefix_products((uint32_t*)tmp, (uint32_t)n);
+    for (int k = 0; k < 4; k++) {
+      fp_t* dst = accum + ((size_t)4 * j + k) * n;
+      for (size_t r = 0; r < n; r++) dst[r] = tmp[r].e[k];
+    }
+  }
   for (uint32_t j = 0; j < c->n_acc; j++) {
     fp4_t m0, m1;
     memcpy(&m0, mix + 8 * j, 16); memcpy(&m1, mix + 8 * j + 4, 16);

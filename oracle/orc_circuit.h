@@ -10,6 +10,7 @@ typedef struct { uint32_t op, a, b, c; } orc_step_t;
 typedef struct { uint32_t kind, param; } orc_code_col_t;
 typedef struct { uint32_t kind, a, b, c, e; } orc_data_col_t;
 typedef struct { uint32_t first, a, b; } orc_acc_col_t;
+typedef struct { uint32_t n_f; uint32_t col[3][4]; } orc_acc_fp_t; /* running product of up to three tuple fingerprints (blob section 8) */
 
 struct orc_circuit {
   uint32_t group_size[3];
@@ -23,6 +24,7 @@ struct orc_circuit {
   uint32_t n_code; orc_code_col_t* code_cols;
   uint32_t n_data; orc_data_col_t* data_cols;
   uint32_t n_acc; orc_acc_col_t* acc_cols;
+  uint32_t n_acc_fp; orc_acc_fp_t* acc_fp;
   uint8_t info[16]; /* circuit ProtocolInfo tag (risc0 `CIRCUIT_INFO`), 16 bytes */
 };
 

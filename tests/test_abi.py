@@ -168,7 +168,7 @@ def test_rust_bindings_are_generated_from_the_header_and_name_the_same_symbols()
     declared = set(re.findall(r"pub struct (r0h_\w+)", rs))
     assert set(re.findall(r"\b(r0h_\w+)\b", " ".join(a + (r or "") for _, a, r in fns))) - {n for n, _, _ in fns} <= declared
     assert "pub struct r0h_system_state { pub pc: u32, pub merkle_root: [u8; 32] }" in rs
-    assert "pub struct r0h_vm_limits { pub segment_po2: u32, pub page_in_cycles: u32, pub page_out_cycles: u32, pub keep_trace: u32, pub max_cycles: u64 }" in rs
+    assert "pub struct r0h_vm_limits { pub segment_po2: u32, pub page_in_cycles: u32, pub page_out_cycles: u32, pub keep_trace: u32, pub max_cycles: u64, pub boundary_rows: u32, pub reserved: u32 }" in rs
     assert "pub struct r0h_ctx { _private: [u8; 0] }" in rs and "pub struct r0h_vm { _private: [u8; 0] }" in rs
     # INTEGRATION.md points at the generated file instead of carrying its own (partial) copy
     assert "bindings/r0hip_sys.rs" in open(os.path.join(ROOT, "INTEGRATION.md")).read()

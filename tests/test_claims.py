@@ -153,3 +153,27 @@ def test_receipt_verification_rejects_what_the_reference_verifier_exists_to_reje
     # a circuit that cannot name a claim
     tiny = np.fromfile(circuit_path("tiny"), dtype=np.uint32)
     assert r0.Receipt.new(s["journal"], s["seals"], s["claims"]).verify(tiny, roots, img)[0] == 10
+    # a claim missing in the MIDDLE is reported as missing at that segment, before any claim is looked at (the chain check
+    # used to read it first)
+    holed = json.loads(r0.Receipt.new(s["journal"], s["seals"], s["claims"]).to_json())
+    holed["inner"]["Composite"]["segments"][1]["claim"] = None
+    assert r0.Receipt.parse(json.dumps(holed)).verify(blob, roots, img)[:3] == (4, "a segment carries no claim", 1)
+    # no image id, no acceptance: `receipt.verify(image_id)` always names the program
+    v = r0.Receipt.new(s["journal"], s["seals"], s["claims"]).verify(blob, roots, None)
+    assert v[0] == 12 and "no image id" in v[1]
+
+
+def test_image_id_text_follows_the_reference_fixture():
+    """host/out/IMAGE_ID.hex (reference-held data): eight `{:08x}` u32 words (host/src/main.rs:445-449), read back word by word with
+    `u32::from_str_radix` (verifier/src/main.rs:131-143) into `Digest::from([u32; 8])`, which keeps each word little-endian -- so every
+    4-byte group of the digest is the reverse of its 8 digits."""
+    import os
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "reference_IMAGE_ID.hex")).read().strip()
+    assert len(text) == 64
+    words = [int(text[8 * i:8 * i + 8], 16) for i in range(8)]
+    want = b"".join(w.to_bytes(4, "little") for w in words)
+    got = r0.image_id_from_hex(text)
+    assert got == want and got[:4] == bytes.fromhex(text[:8])[::-1] and r0.image_id_to_hex(got) == text
+    for bad in (text[:-1], text + "0", " " + text[1:], "-" + text[1:], text[:10] + "g" + text[11:]):  # strict: no signs, blanks or short reads
+        with pytest.raises(r0.R0HipError, match="hex"):
+            r0.image_id_from_hex(bad)

@@ -112,3 +112,48 @@ def test_bench_py_gpus_n_starts_its_own_ranks():
 def test_bench_py_reports_a_failed_rank_with_a_non_zero_exit():
     out, lines = _bench("--gpus", "3", "--steps", "2", "--warmup", "0", "--rehearse-without-gpu", "10", "--fail-rank", "2")
     assert out.returncode != 0 and lines == [] and "rank(s) failed" in out.stderr
+
+
+@pytest.mark.parametrize("how", ["SIGTERM", "SIGKILL"])
+def test_no_rank_outlives_a_parent_that_is_killed(how):
+    """ADVICE r2: atexit alone does not run when the parent of the self-started ranks gets SIGTERM (a harness time limit) or SIGKILL;
+    the ranks would sit in a barrier holding their GPUs.  The parent now forwards SIGTERM / SIGINT / SIGHUP to its ranks, and every
+    rank arms PR_SET_PDEATHSIG before touching torch, which covers SIGKILL.  Rehearsed without a GPU: three ranks with long steps."""
+    import signal
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    parent = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "200", "--warmup", "0", "--rehearse-without-gpu", "500"],
+                              cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def ranks():
+        out = subprocess.run(["ps", "-eo", "pid,ppid,args"], capture_output=True, text=True).stdout.splitlines()
+        return [int(ln.split()[0]) for ln in out if len(ln.split()) > 2 and ln.split()[1] == str(parent.pid) and "bench.py" in ln]
+
+    deadline = time.time() + 60
+    kids = []
+    while time.time() < deadline and len(kids) < 3:
+        time.sleep(0.2)
+        kids = ranks()
+    assert len(kids) == 3, kids
+    time.sleep(1.0)  # let them get into their steps (and past prctl)
+    parent.send_signal(getattr(signal, how))
+    parent.wait(timeout=30)
+    deadline = time.time() + 20
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except OSError:
+            return False
+        try:  # a zombie waiting for init to reap it is dead for our purposes
+            return open("/proc/%d/stat" % pid).read().split(")")[1].split()[0] != "Z"
+        except OSError:
+            return False
+
+    while time.time() < deadline and any(alive(k) for k in kids):
+        time.sleep(0.2)
+    left = [k for k in kids if alive(k)]
+    for k in left:
+        os.kill(k, signal.SIGKILL)  # exactly the processes this test started
+    assert left == [], "ranks that outlived their parent: %s" % left

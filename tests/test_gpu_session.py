@@ -5,8 +5,9 @@ against the image id -- and every seal is checked by the CPU oracle's verifier, 
 
 The guest is a STAND-IN, hand-assembled here (the reference ships no ELF; its guest needs the Rust toolchain): it reads the input
 stream, folds it into a checksum and commits a serde-framed JSON string carrying it, the way hyperfridge's guest commits its
-statement summary.  The witness of a segment is the circuit's synthetic column program with the claim planted (csrc/session.hip),
-so what this test pins is the plumbing and the bindings between the stages, not the rv32im circuit."""
+statement summary.  With a synthetic circuit the witness of a segment is that circuit's column program with the claim planted
+(first test: the plumbing and the bindings between the stages); with the trace circuit the witness IS the segment's execution,
+expanded on the device from the compact preflight rows (second test)."""
 import json
 import os
 import struct
@@ -115,38 +116,77 @@ def test_response_to_verified_receipt(hal, orc, tmp_path):
     tiny.free()
 
 
-def test_every_segment_of_the_guest_run_proves_as_a_trace(hal, orc):
-    """The same run -- the stand-in guest over the input stream made from the reference's EBICS response -- cut into 2^11-cycle
-    segments with the preflight trace kept: each segment's rows go through the trace circuit (csrc/rv32im.hip
-    r0h_vm_trace_witness, circuits/trace.r0c) on the device.  The seals chain like the run does: a segment's public first pc is
-    its predecessor's public last pc, the cycle counts add up, and the CPU oracle's verifier accepts every one."""
+def test_prove_elf_with_the_trace_circuit_proves_the_run_it_executed(hal, orc):
+    """`prove(env, elf)` with circuits/trace.r0c: every seal of the receipt is a proof over THAT segment's cycles.  The run is the
+    stand-in guest over the input stream made from the reference's EBICS response, cut into 2^11-row segments.  Checked here:
+    the receipt verifies against the image id (seals bound to the control roots, claims named by the seals, first / last pc of
+    every seal equal to its claim's, states chaining, journal digest); every seal is accepted by the CPU oracle's verifier; the
+    device's witness of every segment equals the host reference word for word, and the oracle proving from the host reference gives
+    the receipt's seal word for word -- so what r0h_prove_elf proved is the execution an independent run of the executor records."""
     eb = r0.Ebics(rd("response.xml"))
     tx = rd("test.xml-TransactionKeyDecrypt.bin")
     frames = eb.env_inputs(rd("pub_bank.pem"), "-----BEGIN PRIVATE KEY-----…", tx, "CH4308307000289537312", "host:main", rd("test.xml-Witness.hex", "r"),
                            rd("pub_witness.pem"), "verbose")
     stream = np.concatenate([[frames.size], frames]).astype(np.uint32)
-    elf, _, _ = stand_in_guest_elf()
+    elf, template, off = stand_in_guest_elf()
+    blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
+    c = orc.circuit(blob)
+    gc = hal.load_circuit(blob, entry.code_object_path("trace"))
+    po2 = 11
+    receipt, image_id, cycles = hal.prove_elf(gc, elf, stream, segment_po2=po2)
+    stats = hal.last_session_stats()
+    # the same run, executed again with the limits r0h_prove_elf uses
     vm = r0.Vm()
     vm.load_elf(elf)
     vm.set_input(stream)
-    assert vm.run(segment_po2=11, keep_trace=True) == (0, 0)
-    segs = vm.segments()
-    assert len(segs) >= 4
-    blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
-    c = orc.circuit(blob)
-    gc = hal.load_circuit(blob)
-    po2 = 11
-    code, synthetic, _ = hal.witgen(gc, po2, 0)
-    synthetic.free()
-    root = hal.code_root(gc, po2, code)
-    dev = hal.alloc(r0.TRACE_COLUMNS << po2)
-    publics = []
-    for k, s in enumerate(segs):
-        data, glob = vm.trace_witness(k, po2)
-        dev.upload(data)
-        seal = hal.prove_segment(gc, po2, code, dev, glob)
-        assert c.verify(seal, code_root=root) == (0, "ok"), k
-        publics.append([orc.dec(int(g)) for g in glob])
-        assert publics[-1] == [s.pre.pc, s.post.pc, s.user_cycles]
-    assert all(publics[k][1] == publics[k + 1][0] for k in range(len(segs) - 1)) and sum(p[2] for p in publics) == vm.cycles
-    code.free(); dev.free(); gc.free()
+    assert vm.run(segment_po2=po2, keep_trace=True, boundary_rows=True) == (0, 0)
+    segs, claims = vm.segments(), vm.claims()
+    assert cycles == vm.cycles and image_id == segs[0].pre.digest() and receipt.journal == vm.journal
+    seals = receipt.seals()
+    assert len(seals) == len(segs) >= 6 and stats["segments"] == len(segs) and stats["cycles"] == cycles
+    want_json = template[:off] + b"%08x" % checksum(frames) + template[off + 8:]
+    assert r0.journal_commitment(receipt.journal) == want_json
+    roots, ocodes = {}, {}
+    for k, (index, seal) in enumerate(seals):
+        s = segs[k]
+        size = r0.verify_seal(blob, seal)[2]
+        assert index == k and size <= po2 and s.user_cycles + s.boundary_rows <= 1 << size
+        if size not in roots:
+            cc = hal.code_commit(gc, size)
+            roots[size], ocodes[size] = cc.root(), c.witgen(size, 0)[0]
+            cc.free()
+        assert c.verify(seal, code_root=roots[size]) == (0, "ok"), k
+        publics = [orc.dec(int(g)) for g in seal[8:11]]
+        assert publics == [s.pre.pc, s.post.pc, s.user_cycles] and np.array_equal(seal[:8], claims[k].globals())
+        rows, bounds = vm.preflight_arrays(k)
+        data, glob = vm.trace_witness(k, size, claim_globals=claims[k].globals())
+        dev, dglob = hal.trace_witgen(rows, bounds, size, claim_globals=claims[k].globals())
+        assert np.array_equal(dev.to_host(), data) and np.array_equal(dglob, glob)
+        dev.free()
+        if k in (0, len(seals) // 2, len(seals) - 1):
+            assert np.array_equal(seal, c.prove(size, ocodes[size], data, glob)), k
+    assert all(segs[k].post.pc == segs[k + 1].pre.pc for k in range(len(segs) - 1)) and sum(s.user_cycles for s in segs) == cycles
+    back = r0.Receipt.parse(receipt.to_json())
+    assert back.verify(blob, roots, image_id)[:2] == (0, "ok")
+    assert back.verify(blob, roots, None)[0] == 12 and back.verify(blob, roots, bytes(32))[0] == 8
+    # a seal proved for a claim whose pc is not the one the run starts from: the seal is valid and names that claim, the states
+    # chain -- and it is refused because public input 8 (the pc the circuit pins the first cycle to) is not the claim's
+    k = 0
+    forged = r0.ReceiptClaim.make(r0.SystemState.make(segs[k].pre.pc + 4, bytes(segs[k].pre.merkle_root)), segs[k].post, claims[k].exit_system, claims[k].exit_user, None)
+    rows, bounds = vm.preflight_arrays(k)
+    size = r0.verify_seal(blob, seals[k][1])[2]
+    dev, glob = hal.trace_witgen(rows, bounds, size, claim_globals=forged.globals())
+    cc = hal.code_commit(gc, size)
+    seal = hal.prove_segment(gc, size, cc, dev, glob)
+    assert c.verify(seal, code_root=roots[size]) == (0, "ok")
+    rc2 = r0.Receipt.new(receipt.journal, [seal] + [s for _, s in seals[1:]], [forged] + claims[1:])
+    assert rc2.verify(blob, roots, forged.pre.digest())[:3] == (5, "a seal's public inputs do not name its claim", 0)
+    dev.free(); cc.free()
+    # a guest that fails or never halts is an error, not a receipt
+    with pytest.raises(r0.R0HipError, match="did not halt"):
+        hal.prove_elf(gc, elf, stream, segment_po2=po2, max_cycles=100)
+    bad_elf = bytearray(elf)
+    bad_elf[52 + 64 + 8] ^= 0xFF
+    with pytest.raises(r0.R0HipError, match="guest trap|exited with code"):
+        hal.prove_elf(gc, bytes(bad_elf), stream, segment_po2=po2)
+    gc.free()

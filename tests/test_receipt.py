@@ -101,7 +101,7 @@ def test_verify_cli_binds_the_journal_and_the_program(tmp_path, orc):
         code, data, glob = c.witgen(po2, 40 + k, globals_in=cl.globals())
         seals.append(c.prove(po2, code, data, glob))
     root = c.code_root(code, po2)
-    args = ["--image-id", image_id.hex(), "--control-root", "%d:%s" % (po2, ",".join(str(int(w)) for w in root))]
+    args = ["--image-id", r0.image_id_to_hex(image_id), "--control-root", "%d:%s" % (po2, ",".join(str(int(w)) for w in root))]
     path = tmp_path / "receipt.json"
     path.write_text(r0.Receipt.new(journal, seals, claims).to_json())
     out = subprocess.run([VERIFY, "--receipt", str(path), circuit_path("small")] + args, capture_output=True, text=True)

@@ -296,36 +296,47 @@ def test_segmenter_cuts_a_run_and_the_claims_chain_like_a_receipts(orc):
     assert rc.verify(blob, roots, other.segments()[0].pre.digest())[0] == 8  # another program's image id
 
 
-def test_an_io_ecall_is_priced_for_every_page_of_its_buffer():
-    """Found by tools/fuzz: a READ_WORDS or COMMIT touches every page of its buffer inside ONE instruction, so the segmenter has to
-    price the whole span before the ecall runs -- cut the segment first if it does not fit behind what is already there, and refuse a
-    transfer no segment of that size could pay for -- instead of assuming one page in and out per instruction."""
+def test_an_io_ecall_moves_one_word_per_cycle_and_can_be_cut_anywhere():
+    """tools/fuzz (round 2) found that a READ_WORDS or COMMIT which touches every page of its buffer inside ONE cycle cannot be
+    priced like an ordinary instruction.  Since round 3 the two I/O ecalls re-execute once per word (a1 counts down to 0, the pc
+    stays put until then), so a cycle has one memory access, pays for at most its own pages, and a transfer of any length is cut
+    between two segments like any other stretch of the run; the journal and the memory come out the same."""
     buf = 0x40000
     def prog(n_words):
         return flat([ADDI(T0, T0, 1)] * 40, LI(A0, buf), LI(A1, n_words), ADDI(A7, 0, 1), ECALL,   # 40 cheap cycles, then READ_WORDS(buf, n)
-                    LI(A0, buf), LI(A1, 4 * n_words), ADDI(A7, 0, 2), ECALL,                         # COMMIT(buf, 4 n)
+                    LI(A0, buf + 1), LI(A1, 4 * n_words - 2), ADDI(A7, 0, 2), ECALL,                 # COMMIT(buf + 1, 4 n - 2): unaligned at both ends
                     ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
-    def run(n_words, po2, cin, cout):
+    def run(n_words, po2, cin, cout, **kw):
         vm = r0.Vm()
         vm.load(0x400, prog(n_words))
         vm.set_pc(0x400)
         vm.set_input(list(range(1, n_words + 1)))
-        return vm, vm.run(segment_po2=po2, page_in_cycles=cin, page_out_cycles=cout)
-    # 20 pages of 1 KiB: 20 * (8 + 8) = 320 cycles of paging for the read alone; a 2^9-cycle segment takes it only at its start
-    vm, (kind, code) = run(20 * 256, 9, 8, 8)
-    segs = vm.segments()
-    assert (kind, code) == (0, 0) and len(segs) >= 2 and vm.journal == struct.pack("<%dI" % (20 * 256), *range(1, 20 * 256 + 1))
-    for s in segs:
-        assert s.user_cycles + s.paging_cycles <= 1 << 9, (s.index, s.user_cycles, s.paging_cycles)
-    # the same transfer with dearer pages fits no segment of that size: reported, not silently over budget
-    with pytest.raises(r0.R0HipError, match="spans more pages"):
-        run(20 * 256, 9, 30, 30)
-    # and a count in the millions does not grind through memory first (the fuzzer's input: 33 M words)
+        return vm, vm.run(segment_po2=po2, page_in_cycles=cin, page_out_cycles=cout, **kw)
+    n = 20 * 256  # 20 pages of 1 KiB
+    want = struct.pack("<%dI" % n, *range(1, n + 1))[1:-1]
+    for cin, cout in ((8, 8), (30, 30)):
+        vm, (kind, code) = run(n, 9, cin, cout)
+        segs = vm.segments()
+        assert (kind, code) == (0, 0) and len(segs) >= 20 and vm.journal == want and vm.read(buf, n).tolist() == list(range(1, n + 1))
+        assert vm.reg(A1) == 0 and vm.cycles == 40 + 2 + 2 + 1 + n + 2 + 2 + 1 + n + 3  # one cycle per word moved (COMMIT: per word touched, n of them here)
+        for s in segs:
+            assert s.user_cycles + s.paging_cycles <= 1 << 9, (s.index, s.user_cycles, s.paging_cycles)
+    # the rows of such a transfer: the ecall word at one pc, one memory word each, a1 written every time
+    vm, _ = run(6, 20, 0, 0, keep_trace=True)
+    io = [w for w in vm.preflight(0) if w.insn == ECALL and w.mem_kind == r0.MEM_WRITE]
+    assert len(io) == 6 and len({w.pc for w in io}) == 1 and [w.next_pc - w.pc for w in io] == [0] * 5 + [4]
+    assert [w.mem_addr for w in io] == [buf + 4 * k for k in range(6)] and [(w.rd, w.rd_after) for w in io] == [(A1, 5 - k) for k in range(6)]
+    # a count in the millions (the fuzzer's input: 33 M words) costs cycles, not memory up front: the session limit ends it
     vm = r0.Vm()
     vm.load(0x1000, flat(LI(2, 0x02001000), ADDI(A1, 2, 4), ADDI(A7, 0, 1), ADDI(A0, 2, 0), ECALL))
     vm.set_pc(0x1000)
-    with pytest.raises(r0.R0HipError, match="spans more pages"):
-        vm.run(segment_po2=10, page_in_cycles=16, page_out_cycles=16)
+    assert vm.run(segment_po2=10, page_in_cycles=16, page_out_cycles=16, max_cycles=5000)[0] == r0.Vm.LIMIT and vm.cycles == 5000
+    # a count no transfer may have is refused before anything moves
+    vm = r0.Vm()
+    vm.load(0x1000, flat(LI(A1, 0x7FFFFFF0), LI(A0, 0x2000), ADDI(A7, 0, 1), ECALL))
+    vm.set_pc(0x1000)
+    with pytest.raises(r0.R0HipError, match="count too large"):
+        vm.run()
 
 
 def test_elf_loader():

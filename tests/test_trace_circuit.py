@@ -1,10 +1,15 @@
-"""The trace circuit (tools/gen_circuit.py trace, circuits/trace.r0c): a circuit whose DATA group IS the executor's preflight
-trace (r0h_vm_trace_witness) -- the one place where what the prover commits to comes from an execution rather than from a
-synthetic column program.  It constrains that the rows form one contiguous run from the public
-first pc to the public last pc in the public number of cycles, and that control flow follows the instruction words (a step
-leaves pc + 4 only at JAL / JALR / branch words; JAL and branches go where their immediates say).  Register and memory contents,
-branch conditions and JALR targets are risc0's rv32im circuit's business (its tap table and constraint polynomial cannot be
-reproduced here) and are not constrained.  The non-gpu tests prove with the oracle; both verifiers check."""
+"""The trace circuit (tools/gen_circuit.py trace, circuits/trace.r0c): a circuit whose DATA group IS the executor's preflight trace
+-- what the prover commits to comes from an execution, not from a synthetic column program.
+It constrains that the cycles form one contiguous run from the public first pc to the public last pc in the public number of
+cycles, that control flow follows the instruction words, and MEMORY CONSISTENCY over registers and memory as one address space
+(offline memory checking: a grand product over r0h_prefix_products in ACCUM, timestamps ordered through radix-4 digits in DATA):
+what is read from a register or a word -- an instruction word included -- is what was last written there.  What an instruction
+computes is risc0's rv32im circuit's business (its tap table and constraint polynomial cannot be reproduced here) and is not
+constrained.  The non-gpu tests prove with the oracle; both verifiers check.  The expansion of the compact rows into columns is
+restated here in numpy, independently of csrc/trace.hpp, and compared with the host reference and with the device kernel."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -12,100 +17,257 @@ import hyperfridge_r0_amd as r0
 from conftest import circuit_path
 from test_rv32im import _guest
 
-import os
-import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 from gen_circuit import TRACE_COLUMNS  # noqa: E402
 
 COL = {name: i for i, name in enumerate(TRACE_COLUMNS)}
 P = 2013265921
+REG = r0.REG_BASE
+F = dict(cycle=0, pc=1, insn=2, next_pc=3, rs1=4, rs2=5, rd=6, rd_before=7, rd_after=8, mem_kind=9, mem_addr=10, mem_before=11, mem_after=12, prev=13)
 
 
-def _run(n_loop=60):
+def _run(n_loop=60, po2=20):
     prog, base = _guest(n_loop), 0x400
     vm = r0.Vm()
     vm.load(base, prog)
     vm.set_pc(base)
     vm.set_input([7, 0x01020304])
-    assert vm.run(segment_po2=20, keep_trace=True) == (0, 0)
+    assert vm.run(segment_po2=po2, keep_trace=True, boundary_rows=True) == (0, 0)
     return vm, base
+
+
+def expand(rows, bounds, po2):
+    """The DATA group as canonical integers, [column, row], from the compact rows: the specification of include/r0hip.h
+    (r0h_preflight_row, r0h_preflight_bound, the trace-circuit paragraph) written out with numpy."""
+    n, nr, nb = 1 << po2, len(rows), len(bounds)
+    m = np.zeros((len(TRACE_COLUMNS), n), dtype=np.int64)
+    inv = lambda v: pow(int(v) % P, P - 2, P)
+    r = rows.astype(np.int64)
+    L = slice(0, nr)
+    insn, cyc = r[:, F["insn"]], r[:, F["cycle"]]
+    m[COL["live"], L] = 1
+    m[COL["cycle"], L] = cyc
+    m[COL["pc"], L] = r[:, F["pc"]]
+    m[COL["next_pc"], L] = r[:, F["next_pc"]]
+    m[COL["is_seq"], L] = r[:, F["next_pc"]] == ((r[:, F["pc"]] + 4) & 0xFFFFFFFF)
+    m[COL["insn_lo"], L] = insn & 0xFFFF
+    m[COL["insn_hi"], L] = insn >> 16
+    for k in range(32):
+        m[COL["bit%d" % k], L] = (insn >> k) & 1
+    op = np.zeros(n, dtype=np.int64)
+    op[L] = insn & 0x7F
+    for name, code in (("jal", 0x6F), ("jalr", 0x67), ("branch", 0x63), ("ecall", 0x73)):
+        m[COL["is_" + name]] = (op == code) & (np.arange(n) < nr)
+        table = np.array([0 if o == code else inv(o - code) for o in range(128)], dtype=np.int64)
+        m[COL["inv_" + name]] = table[op]  # every row: a blank row carries opcode 0
+    small = np.array([0] + [inv(i) for i in range(1, 32)], dtype=np.int64)
+    for k, (z, iv, act, addr, lo, hi, p, tw, shift, val) in enumerate((("z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0", 15, "rs1"),
+                                                                      ("z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1", 20, "rs2"))):
+        idx = (insn >> shift) & 31
+        m[COL[z]] = 1
+        m[COL[z], L] = idx == 0
+        m[COL[iv], L] = small[idx]
+        on = idx != 0
+        m[COL[act], L] = on
+        m[COL[lo], L] = r[:, F[val]] & 0xFFFF
+        m[COL[hi], L] = r[:, F[val]] >> 16
+        m[COL[addr], L] = np.where(on, REG + idx, 0)
+        m[COL[p], L] = np.where(on, r[:, F["prev"] + k], 0)
+        m[COL[tw], L] = np.where(on, 5 * cyc + k + 1, 0)
+    m[COL["inv_rd"], L] = small[(insn >> 7) & 31]
+    wr = r[:, F["rd"]] != 0
+    m[COL["act2"], L] = wr
+    m[COL["addr2"], L] = np.where(wr, REG + r[:, F["rd"]], 0)
+    for name, f in (("old", "rd_before"), ("new", "rd_after")):
+        m[COL[name + "_lo"], L] = np.where(wr, r[:, F[f]] & 0xFFFF, 0)
+        m[COL[name + "_hi"], L] = np.where(wr, r[:, F[f]] >> 16, 0)
+    m[COL["p2"], L] = np.where(wr, r[:, F["prev"] + 2], 0)
+    m[COL["tw2"], L] = np.where(wr, 5 * cyc + 3, 0)
+    mem = r[:, F["mem_kind"]] != 0
+    m[COL["mem_kind"], L] = r[:, F["mem_kind"]]
+    m[COL["addr3"], L] = np.where(mem, r[:, F["mem_addr"]] >> 2, 0)
+    for name, f in (("before", "mem_before"), ("after", "mem_after")):
+        m[COL[name + "_lo"], L] = np.where(mem, r[:, F[f]] & 0xFFFF, 0)
+        m[COL[name + "_hi"], L] = np.where(mem, r[:, F[f]] >> 16, 0)
+    m[COL["p3"], L] = np.where(mem, r[:, F["prev"] + 3], 0)
+    m[COL["tw3"], L] = np.where(mem, 5 * cyc + 4, 0)
+    m[COL["addr4"], L] = r[:, F["pc"]] >> 2
+    m[COL["p4"], L] = r[:, F["prev"] + 4]
+    m[COL["tw4"], L] = 5 * cyc + 5
+    for k in range(5):
+        diff = np.where(m[COL["tw%d" % k], L] > 0, m[COL["tw%d" % k], L] - m[COL["p%d" % k], L] - 1, 0)
+        assert (diff >= 0).all() and (diff < 1 << 24).all()
+        for i in range(12):
+            m[COL["d%d_%d" % (k, i)], L] = (diff >> (2 * i)) & 3
+    if nb:
+        bb = bounds.astype(np.int64)
+        B = slice(nr, nr + nb)
+        m[COL["bnd"], B] = 1
+        m[COL["addr3"], B] = bb[:, 0]
+        m[COL["after_lo"], B], m[COL["after_hi"], B] = bb[:, 1] & 0xFFFF, bb[:, 1] >> 16     # written: the value found, timestamp 0
+        m[COL["before_lo"], B], m[COL["before_hi"], B] = bb[:, 2] & 0xFFFF, bb[:, 2] >> 16   # read: the value left, at its last timestamp
+        m[COL["p3"], B] = bb[:, 3]
+        gap = np.concatenate([[0], bb[1:, 0] - bb[:-1, 0] - 1])
+        assert (gap >= 0).all()
+        for i in range(12):
+            m[COL["d3_%d" % i], B] = (gap >> (2 * i)) & 3
+        for i in range(4):
+            m[COL["d2_%d" % i], B] = (gap >> (2 * (12 + i))) & 3
+    return m
+
+
+def montgomery(m):
+    return ((m.astype(object) << 32) % P).astype(np.uint32)
+
+
+def test_column_list_is_the_one_the_library_fills():
+    assert r0.trace_column_names() == TRACE_COLUMNS and len(TRACE_COLUMNS) == r0.TRACE_COLUMNS
 
 
 def test_the_witness_is_the_preflight_trace(orc):
     vm, base = _run()
-    rows = vm.preflight(0)
+    rows, bounds = vm.preflight_arrays(0)
     n, po2 = len(rows), 10
-    assert 256 < n <= 1 << po2
+    assert 256 < n and n + len(bounds) <= 1 << po2 and len(bounds) == vm.segments()[0].boundary_rows
     data, glob = vm.trace_witness(0, po2)
-    m = np.array([orc.dec(int(w)) for w in data], dtype=np.uint64).reshape(r0.TRACE_COLUMNS, 1 << po2)
-    assert [orc.dec(int(g)) for g in glob] == [base, rows[-1].next_pc, n]
-    assert m[COL["live"]].tolist() == [1] * n + [0] * ((1 << po2) - n)
-    assert not m[:COL["inv_jal"], n:].any()  # blank past the end, but for the inverses that pin opcode 0 to "no jump"
-    for k, code in enumerate((0x6F, 0x67, 0x63)):
-        assert (m[COL["inv_jal"] + k, n] * (P - code)) % P == 1
-    for r in (0, 1, n // 2, n - 1):
-        w = rows[r]
-        assert (m[COL["pc"], r], m[COL["next_pc"], r], m[COL["cycle"], r]) == (w.pc, w.next_pc, r)
-        assert m[COL["insn_lo"], r] | m[COL["insn_hi"], r] << 16 == w.insn and m[COL["rd_after_lo"], r] | m[COL["rd_after_hi"], r] << 16 == w.rd_after
-        assert m[COL["mem_kind"], r] == w.mem_kind and m[COL["mem_after_lo"], r] | m[COL["mem_after_hi"], r] << 16 == w.mem_after
+    want = expand(rows, bounds, po2)
+    got = data.reshape(r0.TRACE_COLUMNS, 1 << po2)
+    assert np.array_equal(got, montgomery(want)), [TRACE_COLUMNS[c] for c in np.nonzero((got != montgomery(want)).any(axis=1))[0]]
+    assert [orc.dec(int(g)) for g in glob] == [0] * 8 + [base, int(rows[-1, F["next_pc"]]), n]
+    # the rows themselves: timestamps name the previous access, boundary rows are each address once, in order, with what was found and left
+    last, value = {}, {}
+    for w in vm.preflight(0):
+        i1, i2 = (w.insn >> 15) & 31, (w.insn >> 20) & 31
+        acc = [(REG + i1, w.rs1_value, w.rs1_value) if i1 else None, (REG + i2, w.rs2_value, w.rs2_value) if i2 else None,
+               (REG + w.rd, w.rd_before, w.rd_after) if w.rd else None, (w.mem_addr >> 2, w.mem_before, w.mem_after) if w.mem_kind else None,
+               (w.pc >> 2, w.insn, w.insn)]
+        for k, a in enumerate(acc):
+            if a is None:
+                continue
+            addr, before, after = a
+            assert w.prev[k] == last.get(addr, 0), (w.cycle, k)
+            if addr in value:
+                assert value[addr][1] == before, (w.cycle, k, hex(addr))  # what is read is what was last written
+            else:
+                value[addr] = [before, before]
+            value[addr][1] = after
+            last[addr] = 5 * w.cycle + k + 1
+    bl = vm.boundary(0)
+    assert [b.addr for b in bl] == sorted(value) and all((b.first_value, b.last_value, b.last_ts) == (value[b.addr][0], value[b.addr][1], last[b.addr]) for b in bl)
     with pytest.raises(r0.R0HipError, match="do not fit"):
         vm.trace_witness(0, 8)
 
 
-def test_an_execution_proves_and_an_altered_one_does_not(orc):
-    vm, base = _run()
-    n, po2 = len(vm.preflight(0)), 10
-    N = 1 << po2
-    data, glob = vm.trace_witness(0, po2)
+def _prover(orc, po2):
     blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
     c = orc.circuit(blob)
     code, _, _ = c.witgen(po2, 0)  # the fixed CODE columns (first / last row, row index): the program's control root comes from them
     root = c.code_root(code, po2)
-    seal = c.prove(po2, code, data, glob)
-    assert c.verify(seal, code_root=root) == (0, "ok")
-    assert r0.verify_seal(blob, seal, code_root=root)[:2] == (0, "ok")
-    enc = orc.enc
 
     def rejected(d, g):
         s = c.prove(po2, code, d, g)
         got = c.verify(s, code_root=root)
         assert got == r0.verify_seal(blob, s, code_root=root)[:2]
         return got[0] == 4  # the constraint identity at z fails
+    return blob, c, code, root, rejected
 
-    def edit(col, row, value):
+
+def test_an_execution_proves_and_an_altered_one_does_not(orc):
+    vm, base = _run()
+    rows = vm.preflight(0)
+    n, po2 = len(rows), 10
+    N = 1 << po2
+    data, glob = vm.trace_witness(0, po2)
+    blob, c, code, root, rejected = _prover(orc, po2)
+    seal = c.prove(po2, code, data, glob)
+    assert c.verify(seal, code_root=root) == (0, "ok")
+    assert r0.verify_seal(blob, seal, code_root=root)[:2] == (0, "ok")
+    enc = orc.enc
+
+    def edit(*changes):
         d = data.copy()
-        d[COL[col] * N + row] = enc(value)
+        for col, row, value in changes:
+            d[COL[col] * N + row] = enc(value % P)
         return d
 
     mid = n // 2
-    assert rejected(edit("pc", mid, 0x5000), glob)                    # a row that starts somewhere its predecessor did not go
-    assert rejected(edit("next_pc", mid, 0x5000), glob)               # ... or goes somewhere the next one does not start
-    assert rejected(edit("cycle", mid, mid + 1), glob)                # a skipped cycle
-    assert rejected(edit("live", mid, 0), glob)                       # a hole in the run
-    assert rejected(edit("live", n, 1), glob)                         # a row smuggled in after the end
-    assert rejected(edit("mem_kind", mid, 3), glob)                   # not none / read / write
-    rd = next(r for r, w in enumerate(vm.preflight(0)) if w.mem_kind == r0.MEM_READ)
-    assert rejected(edit("mem_after_lo", rd, (vm.preflight(0)[rd].mem_after & 0xffff) ^ 1), glob)  # a read that changes the word
-    for k, wrong in ((0, base + 4), (1, 0x5000), (2, n - 1)):         # public inputs that do not describe this run
+    assert rejected(edit(("pc", mid, 0x5000)), glob)                   # a row that starts somewhere its predecessor did not go
+    assert rejected(edit(("next_pc", mid, 0x5000)), glob)              # ... or goes somewhere the next one does not start
+    assert rejected(edit(("cycle", mid, mid + 1)), glob)               # a skipped cycle
+    assert rejected(edit(("live", mid, 0)), glob)                      # a hole in the run
+    assert rejected(edit(("live", N - 1, 1)), glob)                    # a row smuggled in after the end
+    assert rejected(edit(("mem_kind", mid, 3)), glob)                  # not none / read / write
+    rd = next(r for r, w in enumerate(rows) if w.mem_kind == r0.MEM_READ)
+    assert rejected(edit(("after_lo", rd, (rows[rd].mem_after & 0xffff) ^ 1)), glob)  # a read that changes the word
+    for k, wrong in ((8, base + 4), (9, 0x5000), (10, n - 1)):         # public inputs that do not describe this run
         g = glob.copy()
         g[k] = enc(wrong)
         assert rejected(data, g)
+    g = glob.copy()
+    g[0] = enc(1)                                                      # the claim words are bound by the transcript, not by a constraint:
+    s = c.prove(po2, code, data, g)                                    # another claim, another (valid) seal ...
+    assert c.verify(s, code_root=root) == (0, "ok") and not np.array_equal(s[:11], seal[:11])
+    s[0] = seal[0]                                                     # ... which does not pass for this one
+    assert c.verify(s, code_root=root)[0] != 0
     # control flow follows the instruction words
-    rows = vm.preflight(0)
     br = next(r for r, w in enumerate(rows) if (w.insn & 0x7f) == 0x63 and w.next_pc != w.pc + 4)   # a taken branch
-    assert rejected(edit("is_branch", br, 0), glob)                   # ... cannot pass as an ordinary instruction
-    assert rejected(edit("bit0", br, 0), glob)                        # ... nor can its word be changed under it (halves and opcode pin the bits)
-    d2 = edit("next_pc", br, rows[br].pc + 8)                         # ... nor can it go anywhere but pc + 4 or pc + imm_B,
-    d2[COL["pc"] * N + br + 1] = enc(rows[br].pc + 8)                 #     even if the next row plays along
-    assert rejected(d2, glob)
+    assert rejected(edit(("is_branch", br, 0)), glob)                  # ... cannot pass as an ordinary instruction
+    assert rejected(edit(("bit0", br, 0)), glob)                       # ... nor can its word be changed under it (halves and opcode pin the bits)
+    assert rejected(edit(("next_pc", br, rows[br].pc + 8), ("pc", br + 1, rows[br].pc + 8), ("addr4", br + 1, (rows[br].pc + 8) >> 2)), glob)  # nor go elsewhere
     alu = next(r for r, w in enumerate(rows) if (w.insn & 0x7f) == 0x13 and r > 4)
-    d3 = edit("next_pc", alu, rows[alu].pc + 8)                       # an ALU instruction that skips the next one
-    d3[COL["is_seq"] * N + alu] = enc(0)
-    d3[COL["pc"] * N + alu + 1] = enc(rows[alu].pc + 8)
-    assert rejected(d3, glob)
-    assert rejected(edit("is_jal", alu, 1), glob)                     # ... and cannot be flagged as a jump to get away with it
-    # what the circuit does not see, by design: what an instruction computes
-    assert not rejected(edit("rd_after_lo", alu, 0x1234), glob)
+    assert rejected(edit(("next_pc", alu, rows[alu].pc + 8), ("is_seq", alu, 0), ("pc", alu + 1, rows[alu].pc + 8)), glob)  # an ALU instruction that skips the next one
+    assert rejected(edit(("is_jal", alu, 1)), glob)                    # ... and cannot be flagged as a jump to get away with it
+    io = next(r for r, w in enumerate(rows) if w.insn == 0x73 and w.next_pc == w.pc)  # an I/O ecall repeating: to pc or pc + 4, nowhere else
+    assert rejected(edit(("next_pc", io, rows[io].pc + 8), ("pc", io + 1, rows[io].pc + 8)), glob)
+
+    # ---- memory consistency: registers, memory and instruction words
+    def next_read(reg, after):
+        return next(r for r in range(after + 1, n) if ((rows[r].insn >> 15) & 31) == reg or ((rows[r].insn >> 20) & 31) == reg)
+
+    w_row = next(r for r, w in enumerate(rows) if w.rd and r > 8 and any(((q.insn >> 15) & 31) == w.rd for q in rows[r + 1:r + 30]))
+    reg = rows[w_row].rd
+    r_row = next_read(reg, w_row)
+    slot = "rs1" if ((rows[r_row].insn >> 15) & 31) == reg else "rs2"
+    v = getattr(rows[r_row], slot + "_value")
+    assert rejected(edit((slot + "_lo", r_row, (v & 0xffff) ^ 1)), glob)           # a register that changes between its write and the next read
+    assert rejected(edit(("new_lo", w_row, (rows[w_row].rd_after & 0xffff) ^ 1)), glob)   # ... from either side
+    assert rejected(edit(("old_hi", w_row, (rows[w_row].rd_before >> 16) ^ 1)), glob)     # a write that misstates what it overwrote
+    st = next(r for r, w in enumerate(rows) if w.mem_kind == r0.MEM_WRITE and r > 20)
+    assert rejected(edit(("after_lo", st, (rows[st].mem_after & 0xffff) ^ 4)), glob)      # a store whose word is not what is found there later (its boundary row)
+    assert rejected(edit(("before_lo", rd, (rows[rd].mem_before & 0xffff) ^ 1), ("after_lo", rd, (rows[rd].mem_after & 0xffff) ^ 1)), glob)  # a load that sees another word
+    assert rejected(edit(("insn_lo", mid, rows[mid].insn & 0xffff ^ 0x1000), ("bit12", mid, 1 - ((rows[mid].insn >> 12) & 1))), glob)  # an instruction word that is not the one in memory
+    assert rejected(edit(("addr0", r_row if slot == "rs1" else next_read(reg, r_row), REG + 31)), glob)  # reading another register than the word names
+    assert rejected(edit(("p4", mid, rows[mid].prev[4] + 1)), glob)                # a made-up previous timestamp
+    assert rejected(edit(("tw4", mid, 5 * mid + 6)), glob)                         # ... or own timestamp
+    x0 = next(r for r, w in enumerate(rows) if ((w.insn >> 15) & 31) == 0 and (w.insn & 0x7f) == 0x13)
+    assert rejected(edit(("rs1_lo", x0, 5)), glob)                                 # x0 reads as zero
+    assert rejected(edit(("z1", x0, 0), ("act0", x0, 1)), glob)                    # ... and cannot be declared a register access
+    bounds = vm.boundary(0)
+    b0 = n + 3
+    assert rejected(edit(("after_lo", b0, (bounds[3].first_value & 0xffff) ^ 1)), glob)  # the first value of an address is what its first access finds
+    assert rejected(edit(("p3", b0, bounds[3].last_ts + 5)), glob)
+    assert rejected(edit(("addr3", b0, bounds[2].addr)), glob)                     # an address twice among the boundary rows (two histories)
+    assert rejected(edit(("bnd", b0, 0)), glob)                                    # a boundary row dropped
+    # what the circuit does not see, by design: what an instruction computes.  A consistent lie -- the value an instruction writes
+    # changed together with every later sight of it, up to the register's next write or its boundary row -- is accepted: the
+    # statement proved is "memory is consistent", not "the ALU computed this" (risc0's rv32im circuit)
+    lie = (rows[w_row].rd_after & 0xffff) ^ 1
+    chain = [("new_lo", w_row, lie)]
+    r = w_row
+    while True:  # every later sight of that register value up to its next write
+        nxt = [q for q in range(r + 1, n) if ((rows[q].insn >> 15) & 31) == reg or ((rows[q].insn >> 20) & 31) == reg or rows[q].rd == reg]
+        if not nxt:
+            chain.append(("before_lo", n + [b.addr for b in bounds].index(REG + reg), lie))
+            break
+        r = nxt[0]
+        if ((rows[r].insn >> 15) & 31) == reg:
+            chain.append(("rs1_lo", r, lie))
+        if ((rows[r].insn >> 20) & 31) == reg:
+            chain.append(("rs2_lo", r, lie))
+        if rows[r].rd == reg:
+            chain.append(("old_lo", r, lie))
+            break
+    assert not rejected(edit(*chain), glob)
 
 
 def test_jumps_and_branches_of_every_kind_satisfy_the_control_flow_constraints(orc):
@@ -125,7 +287,7 @@ def test_jumps_and_branches_of_every_kind_satisfy_the_control_flow_constraints(o
     vm.load(0x1000, prog)
     vm.set_pc(0x1000)
     try:
-        vm.run(segment_po2=20, keep_trace=True, max_cycles=200)
+        vm.run(segment_po2=20, keep_trace=True, boundary_rows=True, max_cycles=200)
     except r0.R0HipError:
         pass  # wherever it ends, the rows so far are a run
     rows = vm.preflight(0)
@@ -140,30 +302,69 @@ def test_jumps_and_branches_of_every_kind_satisfy_the_control_flow_constraints(o
     assert c.verify(seal, code_root=c.code_root(code, po2)) == (0, "ok")
 
 
+def test_every_segment_of_a_cut_run_proves_and_the_boundary_values_chain(orc):
+    """A run cut into several segments: each proves on its own; what a segment leaves in an address is what the next one that
+    touches it finds (the boundary rows' first / last values) -- the link the circuit itself does not make (include/r0hip.h)."""
+    vm, base = _run(700, po2=10)
+    segs = vm.segments()
+    assert len(segs) >= 4
+    blob, c, code, root, _ = _prover(orc, 10)
+    left = {}
+    for k, s in enumerate(segs):
+        assert s.user_cycles + s.boundary_rows <= 1 << 10 and s.boundary_rows == len(vm.boundary(k))
+        data, glob = vm.trace_witness(k, 10, claim_globals=vm.claims()[k].globals())
+        seal = c.prove(10, code, data, glob)
+        assert c.verify(seal, code_root=root) == (0, "ok"), k
+        assert [orc.dec(int(g)) for g in glob[8:]] == [s.pre.pc, s.post.pc, s.user_cycles]
+        for b in vm.boundary(k):
+            if b.addr in left:
+                assert left[b.addr] == b.first_value, (k, hex(b.addr))
+            left[b.addr] = b.last_value
+    assert sum(s.user_cycles for s in segs) == vm.cycles
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_loop,po2", [(60, 10), (9000, 16)])
-def test_the_device_proves_an_execution_trace_word_for_word_like_the_cpu_port(hal, orc, n_loop, po2):
-    """The same on the GPU: CODE columns generated on the device, DATA uploaded from the executor's trace, the seal equal to the
-    CPU port's and accepted by both verifiers bound to the control root; a row that breaks the run is rejected."""
+@pytest.mark.parametrize("n_loop,po2", [(60, 10), (9000, 17)])
+def test_the_device_expands_and_proves_an_execution_trace_word_for_word_like_the_cpu_side(hal, orc, n_loop, po2):
+    """The same on the GPU: the compact rows are uploaded and expanded by the device kernel (r0h_trace_witgen) -- the DATA group
+    equals the host reference's and the numpy restatement's word for word; CODE columns generated on the device; the seal equal to
+    the CPU port's and accepted by both verifiers bound to the control root; a row that breaks the run is rejected."""
     vm, base = _run(n_loop)
-    n = len(vm.preflight(0))
-    assert (1 << (po2 - 2)) < n <= (1 << po2)
+    rows, bounds = vm.preflight_arrays(0)
+    n = len(rows)
+    assert (1 << (po2 - 2)) < n + len(bounds) <= (1 << po2)
     data, glob = vm.trace_witness(0, po2)
     blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
     c = orc.circuit(blob)
     gc = hal.load_circuit(blob)  # eval_check compiled in-process (hipRTC)
     code, synthetic, _ = hal.witgen(gc, po2, 0)
     synthetic.free()
-    dev = hal.copy_from(data)
-    seal = hal.prove_segment(gc, po2, code, dev, glob)
-    root = hal.code_root(gc, po2, code)
+    dev, dglob = hal.trace_witgen(rows, bounds, po2)
+    assert np.array_equal(dglob, glob)
+    got = dev.to_host()
+    assert np.array_equal(got, data)
+    if po2 <= 12:
+        assert np.array_equal(got.reshape(r0.TRACE_COLUMNS, -1), montgomery(expand(rows, bounds, po2)))
+    cc = hal.code_commit(gc, po2, code)
+    seal = hal.prove_segment(gc, po2, cc, dev, glob)
+    root = cc.root()
     assert c.verify(seal, code_root=root) == (0, "ok") and r0.verify_seal(blob, seal, code_root=root)[:2] == (0, "ok")
     ocode, _, _ = c.witgen(po2, 0)
     assert np.array_equal(ocode, code.to_host())
     assert np.array_equal(seal, c.prove(po2, ocode, data, glob))
-    bad = data.copy()
-    bad[COL["pc"] * (1 << po2) + n // 2] = orc.enc(0x5000)
-    dev.upload(bad)
-    seal = hal.prove_segment(gc, po2, code, dev, glob)
+    # a register value that changes between a write and the next read: rejected by both verifiers
+    bad = rows.copy()
+    k = next(r for r in range(20, n) if (bad[r, F["insn"]] >> 15) & 31)
+    bad[k, F["rs1"]] ^= 1
+    dev2, _ = hal.trace_witgen(bad, bounds, po2)
+    seal = hal.prove_segment(gc, po2, cc, dev2, glob)
     assert c.verify(seal, code_root=root)[0] == 4 and r0.verify_seal(blob, seal, code_root=root)[0] == 4
-    code.free(); dev.free(); gc.free()
+    bad = rows.copy()
+    bad[n // 2, F["pc"]] = 0x5000
+    dev2.free()
+    dev2, _ = hal.trace_witgen(bad, bounds, po2)
+    seal = hal.prove_segment(gc, po2, cc, dev2, glob)
+    assert c.verify(seal, code_root=root)[0] == 4 and r0.verify_seal(blob, seal, code_root=root)[0] == 4
+    with pytest.raises(r0.R0HipError, match="do not fit"):
+        hal.trace_witgen(rows, bounds, 9 if po2 > 10 else 8)
+    cc.free(); code.free(); dev.free(); dev2.free(); gc.free()

@@ -38,6 +38,7 @@ def main():
         raise SystemExit(bench.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     import bench
+    bench.die_with_parent()  # a rank started by spawn_ranks ends with its parent, whatever ends the parent
     bench.guard_stdout()  # stdout carries the one result line; what gloo / RCCL print to stdout themselves goes to stderr
 
     import numpy as np

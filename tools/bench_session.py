@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""`prove(env, elf)` end to end with the trace circuit, timed: the executor (host thread), the device expansion of the compact
+preflight rows (r0h_trace_witgen, upload included) and the proof of every segment are all inside the timed region -- one JSON line.
+
+The guest is hand-assembled (the reference ships no ELF): by default the memory-traffic loop of tests/test_rv32im.py (_guest),
+sized by --cycles; with --guest rsa the guest-shaped program of tools/guest_rsa.py (SHA-256 + RSA-2048 signature check on the
+reference's own inputs), when that file exists.  What is reported: segments per second of the whole pipeline, the executor's rate,
+host milliseconds per segment (executor thread; it overlaps the device), device-side milliseconds per segment for witness
+generation and proof.  The receipt is verified against the image id before the line is printed.
+usage: python tools/bench_session.py [--po2 20] [--cycles 8000000] [--guest loop|rsa] [--repeat 2]"""
+import argparse
+import json
+import os
+import struct
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+
+def elf_of(words, base, data=b"", data_addr=0):
+    code = struct.pack("<%dI" % len(words), *words)
+    n_ph = 2 if data else 1
+    ehdr = b"\x7fELF" + bytes([1, 1, 1, 0]) + bytes(8) + struct.pack("<HHIIIIIHHHHHH", 2, 243, 1, base, 52, 0, 0, 52, 32, n_ph, 0, 0, 0)
+    o1 = 52 + 32 * n_ph
+    ph = struct.pack("<IIIIIIII", 1, o1, base, base, len(code), len(code), 5, 4)
+    if data:
+        data = data + bytes(-len(data) % 4)
+        ph += struct.pack("<IIIIIIII", 1, o1 + len(code), data_addr, data_addr, len(data), len(data), 6, 4)
+    return ehdr + ph + code + data
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--po2", type=int, default=20)
+    ap.add_argument("--cycles", type=int, default=8_000_000)
+    ap.add_argument("--guest", default="loop")
+    ap.add_argument("--repeat", type=int, default=2, help="runs; the last one is reported (the first pays for code objects, pools, CODE commitments)")
+    ap.add_argument("--oracle-check", type=int, default=1, help="verify this many seals with the CPU oracle's verifier as well")
+    args = ap.parse_args()
+    import __graft_entry__ as entry
+    entry.ensure_built()
+    import hyperfridge_r0_amd as r0
+    if args.guest == "rsa":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import guest_rsa
+        elf, stream, what = guest_rsa.elf_and_input()
+    else:
+        from test_rv32im import ADDI, A0, A1, A7, B, ECALL, I, LI, R, S, S0, T0, T1, T2, flat
+        buf, scratch, n_loop = 0x10000, 0x20000, max(1, (args.cycles - 40) // 7)
+        # reads two input words, then n_loop times: store the counter at scratch + ((t1 & 0x7fc) << 4) (a 32 KiB window, 32 pages), count
+        prog = flat(LI(A0, buf), ADDI(A1, 0, 2), ADDI(A7, 0, 1), ECALL, LI(S0, scratch), LI(T2, n_loop), ADDI(T1, 0, 0),
+                    I(0x7FC, T1, 7, T0, 0x13), I(4, T0, 1, T0, 0x13), R(0, S0, T0, 0, T0), S(0, T1, T0, 2), ADDI(T1, T1, 4), ADDI(T2, T2, -1), B(-24, 0, T2, 1),
+                    LI(A0, buf), I(0, A0, 2, T0, 0x03), R(0, T1, T0, 0, T0), S(0, T0, A0, 2), ADDI(A1, 0, 8), ADDI(A7, 0, 2), ECALL,
+                    ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
+        elf, stream = elf_of(prog, 0x400), [7, 0x01020304]
+        what = "store loop over a 32 KiB window (7 instructions per iteration, one store), about %d cycles" % args.cycles
+    blob = np.fromfile(entry.circuit_blob_path("trace"), dtype=np.uint32)
+    hal = r0.Hal(0)
+    gc = hal.load_circuit(blob, entry.code_object_path("trace"))
+    for _ in range(max(1, args.repeat)):
+        t0 = time.perf_counter()
+        receipt, image_id, cycles = hal.prove_elf(gc, elf, stream, segment_po2=args.po2)
+        wall = time.perf_counter() - t0
+        st = hal.last_session_stats()
+    seals = receipt.seals()
+    roots = {}
+    for _, seal in seals:
+        size = r0.verify_seal(blob, seal)[2]
+        if size not in roots:
+            cc = hal.code_commit(gc, size)
+            roots[size] = cc.root()
+            cc.free()
+    verdict = receipt.verify(blob, roots, image_id)
+    assert verdict[:2] == (0, "ok"), verdict
+    if args.oracle_check:
+        import orc_binding
+        oc = orc_binding.load().circuit(blob)
+        for _, seal in seals[:args.oracle_check]:
+            assert oc.verify(seal, code_root=roots[r0.verify_seal(blob, seal)[2]]) == (0, "ok")
+    n = st["segments"]
+    line = {"metric": "segments/s of prove(env, elf) with the trace circuit: executor + device witgen + proof, all inside the timed region",
+            "value": round(n / wall, 4), "unit": "segments/s", "n_gpus": 1, "segment_po2": args.po2, "segments": n, "cycles": cycles,
+            "wall_s": round(wall, 4), "guest": what,
+            "executor": {"host_s": round(st["executor_s"], 4), "MHz_with_trace_kept": round(cycles / st["executor_s"] / 1e6, 2), "host_ms_per_segment": round(1e3 * st["executor_s"] / n, 3),
+                         "note": "own host thread, overlaps the device work of the previous segment"},
+            "device": {"witgen_ms_per_segment": round(st["witgen_ms"] / n, 3), "prove_ms_per_segment": round(st["prove_ms"] / n, 3),
+                       "note": "witgen = upload of 72 B/cycle + 16 B/boundary row and the expansion kernel; prove = r0h_prove_segment_committed (CODE committed once per trace size)"},
+            "circuit": "trace.r0c W=(%d accum, %d code, %d data)" % tuple(gc.group_size), "seal_words": int(seals[0][1].size),
+            "receipt_verified": True, "data": "synthetic guest; no guest ELF exists in the reference (needs the Rust toolchain)"}
+    print(json.dumps(line))
+    gc.free()
+    hal.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,19 +76,20 @@ static void walk_ebics(r0h_ebics* e) {
 static void run_vm(r0h_vm* vm) {
   uint32_t input[8] = {1, 2, 3, 4, 5, 6, 7, 8};
   drop(r0h_vm_set_input(vm, input, 8));
-  r0h_vm_limits lim = {10, 16, 16, 1, 20000};
+  r0h_vm_limits lim = {10, 16, 16, 1, 20000, 1, 0};  // trace kept, boundary rows charged: the r0h_prove_elf configuration
   int kind = 0; uint32_t code = 0;
   drop(r0h_vm_run(vm, &lim, &kind, &code));
   for (size_t i = 0; i < r0h_vm_n_segments(vm); i++) {
-    r0h_vm_segment seg; r0h_receipt_claim cl; const r0h_preflight_row* rows; size_t n;
+    r0h_vm_segment seg; r0h_receipt_claim cl; const r0h_preflight_row* rows; size_t n; const r0h_preflight_bound* bounds; size_t nb;
     drop(r0h_vm_segment_info(vm, i, &seg));
     drop(r0h_vm_preflight(vm, i, &rows, &n));
+    drop(r0h_vm_boundary(vm, i, &bounds, &nb));
     drop(r0h_vm_segment_claim(vm, i, &cl));
     if (i == 0 && n > 0) {  // the trace circuit's witness from these rows
       uint32_t po2 = 4;
-      while (((size_t)1 << po2) < n) po2++;
+      while (((size_t)1 << po2) < n + nb) po2++;
       std::vector<uint32_t> w((size_t)R0H_TRACE_COLUMNS << po2);
-      uint32_t g[3];
+      uint32_t g[R0H_TRACE_GLOBALS];
       drop(r0h_vm_trace_witness(vm, i, po2, w.data(), g));
       drop(r0h_vm_trace_witness(vm, i, po2 - 1, w.data(), g));  // too small: an error, not an overrun
     }

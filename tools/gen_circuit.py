@@ -13,7 +13,7 @@ Shapes:
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
   recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
-  trace  W=(4, 4, 58)                       columns = the executor's preflight rows + instruction bits; one contiguous run, control flow per the words
+  trace  W=(16, 4, 144)                     columns = the executor's preflight rows; one contiguous run, control flow per the words, memory consistency
 """
 import argparse
 import struct
@@ -246,23 +246,39 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
     return words, info
 
 
-# ---- the trace circuit: columns ARE the executor's preflight rows (include/r0hip.h: r0h_preflight_row) --------------------------
+# ---- the trace circuit: columns ARE the executor's preflight rows (include/r0hip.h: r0h_preflight_row / r0h_preflight_bound;
+# csrc/trace.hpp holds the same column list and the expansion of a row into it) ---------------------------------------------------
 # Not the rv32im circuit (risc0's constrains every instruction's semantics; that tap table and polynomial are not reproducible
-# here): this one constrains that the rows form ONE contiguous run whose control flow follows the instruction words -- it leaves
-# the sequential path only at JAL / JALR / branch words, and JAL and branches go where their immediates say.  Public inputs:
-# first pc, pc after the last row, number of rows.  Its witness comes from an execution (r0h_vm_trace_witness), not from a column program.
-TRACE_COLUMNS = (["live", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi", "rs1_lo", "rs1_hi", "rs2_lo", "rs2_hi", "rd", "rd_after_lo",
-                  "rd_after_hi", "mem_kind", "mem_addr", "mem_before_lo", "mem_before_hi", "mem_after_lo", "mem_after_hi"]
-                 + ["bit%d" % k for k in range(32)]                                   # the instruction word, bit by bit
-                 + ["is_jal", "is_jalr", "is_branch", "inv_jal", "inv_jalr", "inv_branch"])  # opcode classes and the inverses that pin them
+# here).  This one constrains
+#   * that the cycles form ONE contiguous run from the public first pc to the public last pc in the public number of cycles;
+#   * that control flow follows the instruction words (it leaves the sequential path only at JAL / JALR / branch / ecall words, JAL
+#     and branches go where their immediates say, an ecall to pc or pc + 4);
+#   * MEMORY CONSISTENCY over registers and memory as one address space, by offline memory checking: each of a cycle's five
+#     accesses (x[rs1], x[rs2], x[rd], the memory word, the fetched word) reads the tuple (address, value, timestamp) that the
+#     previous access to the address wrote and writes a new one with a larger timestamp (the difference is range-checked through
+#     radix-4 digits); boundary rows, one per address in strictly increasing order, write the first tuple (timestamp 0) and read
+#     the last.  Multiset equality of tuples read and written is a grand product in ACCUM (four running products over fingerprints
+#     alpha - addr - b1 lo - b2 hi - b3 t with alpha, b1..b3 drawn after DATA is committed), compared on the last row.
+# Public inputs: 8 words naming the segment's ReceiptClaim, first pc, pc after the last cycle, number of cycles.
+TRACE_COLUMNS = (["live", "bnd", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi"]
+                 + ["bit%d" % k for k in range(32)]                                                   # the instruction word, bit by bit
+                 + ["is_jal", "is_jalr", "is_branch", "is_ecall", "inv_jal", "inv_jalr", "inv_branch", "inv_ecall"]  # opcode classes, pinned by inverses
+                 + ["z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0"]                   # access 0: x[rs1] read
+                 + ["z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1"]                   # access 1: x[rs2] read
+                 + ["act2", "addr2", "inv_rd", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2"]  # access 2: x[rd] write
+                 + ["mem_kind", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "tw3"]  # access 3: memory word / boundary row
+                 + ["addr4", "p4", "tw4"]                                                             # access 4: instruction fetch
+                 + ["d%d_%d" % (k, i) for k in range(5) for i in range(12)])                          # radix-4 digits of (own - previous - 1)
+TRACE_GLOBALS = 11   # claim words 0..7, first pc, pc after the last cycle, cycles
+REG_BASE = 1 << 30
+SEC_ACCUM_FP = 8
 
 
 def generate_trace():
     col = {name: i for i, name in enumerate(TRACE_COLUMNS)}
-    n_data, n_code, n_acc, n_global = len(TRACE_COLUMNS), 4, 1, 3
+    n_data, n_code, n_acc, n_global = len(TRACE_COLUMNS), 4, 4, TRACE_GLOBALS
     code_cols = [(0, 0), (1, 0), (2, 0), (3, 3)]  # first-row indicator, last-row indicator, row index, one seeded column
-    data_cols = [(0, 0, 0, 0, 0)] * n_data        # all free: the witness is the caller's
-    acc_cols = [(0, col["pc"], col["cycle"])]     # one running product over (pc, cycle), gated like the synthetic ones
+    data_cols = [(0, 0, 0, 0, 0)] * n_data        # all free: the witness is the execution's
     b = Builder()
     for g, size in ((G_ACCUM, 4 * n_acc), (G_CODE, n_code), (G_DATA, n_data)):
         for c in range(size):
@@ -271,32 +287,16 @@ def generate_trace():
     def d(name, back=0):
         return b.get(G_DATA, col[name], back)
 
-    one, two, four = b.const(1), b.const(2), b.const(4)
+    one, two, three, four, five = (b.const(v) for v in (1, 2, 3, 4, 5))
+    half = b.const((P + 1) // 2)
     first, last = b.get(G_CODE, 0, 0), b.get(G_CODE, 1, 0)
     not_first = b.sub(one, first)
-    live, prev_live = d("live"), d("live", 1)
+    live, prev_live, bnd, prev_bnd = d("live"), d("live", 1), d("bnd"), d("bnd", 1)
+    not_live = b.sub(one, live)
     cons = []  # (fp var that must vanish on every row, degree)
-    cons.append((b.mul(live, b.sub(live, one)), 2))                                                     # live is a bit
-    cons.append((b.mul(d("is_seq"), b.sub(d("is_seq"), one)), 2))                                       # is_seq is a bit
-    cons.append((b.mul(b.mul(live, d("is_seq")), b.sub(d("next_pc"), b.add(d("pc"), four))), 3))        # sequential rows step by 4
-    gate = b.mul(not_first, live)                                                                       # a live row that has a predecessor
-    cons.append((b.mul(gate, b.sub(d("pc"), d("next_pc", 1))), 3))                                      # ... starts where that one went
-    cons.append((b.mul(gate, b.sub(d("cycle"), b.add(d("cycle", 1), one))), 3))                         # ... one cycle later
-    cons.append((b.mul(gate, b.sub(one, prev_live)), 3))                                                # ... and follows a live row (padding only at the end)
-    mk = d("mem_kind")
-    cons.append((b.mul(b.mul(mk, b.sub(mk, one)), b.sub(mk, two)), 3))                                  # none / read / write
-    rd_only = b.mul(mk, b.sub(two, mk))                                                                 # 1 on reads, 0 otherwise
-    cons.append((b.mul(rd_only, b.sub(d("mem_after_lo"), d("mem_before_lo"))), 3))                      # a read leaves the word as it was
-    cons.append((b.mul(rd_only, b.sub(d("mem_after_hi"), d("mem_before_hi"))), 3))
-    for name in ("pc", "next_pc", "cycle", "mem_kind"):                                                 # padding rows are blank
-        cons.append((b.mul(b.sub(one, live), d(name)), 2))
-    # --- control flow from the instruction word.  The word is decomposed into bits; the opcode classes that may leave the
-    # sequential path are flags pinned BOTH ways (flag * (op - code) = 0 and (op - code) * inv = 1 - flag: flag = 1 iff the opcode
-    # is that code); a live row may be non-sequential only under a flag, JAL goes to pc + imm_J, a branch to pc + 4 or pc + imm_B.
-    # (Branch conditions, JALR targets and everything the ALU does are the rv32im circuit's business and are not constrained.)
-    bits = [d("bit%d" % k) for k in range(32)]
-    for bk in bits:
-        cons.append((b.mul(bk, b.sub(bk, one)), 2))
+
+    def bit(v):
+        cons.append((b.mul(v, b.sub(v, one)), 2))
 
     def lin(terms):  # sum of coeff * var, coeff an integer (negative allowed)
         acc = None
@@ -305,66 +305,164 @@ def generate_trace():
             acc = t if acc is None else b.add(acc, t)
         return acc
 
+    # --- the run: live rows first, then boundary rows, then blank rows
+    bit(live)
+    bit(bnd)
+    cons.append((b.mul(live, bnd), 2))
+    bit(d("is_seq"))
+    cons.append((b.mul(b.mul(live, d("is_seq")), b.sub(d("next_pc"), b.add(d("pc"), four))), 3))        # sequential rows step by 4
+    gate = b.mul(not_first, live)                                                                       # a live row that has a predecessor
+    cons.append((b.mul(gate, b.sub(d("pc"), d("next_pc", 1))), 3))                                      # ... starts where that one went
+    cons.append((b.mul(gate, b.sub(d("cycle"), b.add(d("cycle", 1), one))), 3))                         # ... one cycle later
+    cons.append((b.mul(gate, b.sub(one, prev_live)), 3))                                                # ... and follows a live row
+    cons.append((b.mul(b.mul(not_first, bnd), b.sub(one, b.add(prev_live, prev_bnd))), 3))              # a boundary row follows a live or a boundary row
+    for name in ("pc", "next_pc", "cycle", "mem_kind", "act2"):                                         # rows that are not cycles carry none of these
+        cons.append((b.mul(not_live, d(name)), 2))
+    # --- the instruction word, its opcode class, control flow
+    bits = [d("bit%d" % k) for k in range(32)]
+    for bk in bits:
+        bit(bk)
     cons.append((b.sub(d("insn_lo"), lin([(1 << k, bits[k]) for k in range(16)])), 1))
     cons.append((b.sub(d("insn_hi"), lin([(1 << k, bits[16 + k]) for k in range(16)])), 1))
     op = lin([(1 << k, bits[k]) for k in range(7)])
-    flags = []
-    for name, code in (("jal", 0x6F), ("jalr", 0x67), ("branch", 0x63)):
+    flags = {}
+    for name, code in (("jal", 0x6F), ("jalr", 0x67), ("branch", 0x63), ("ecall", 0x73)):
         f, inv_ = d("is_" + name), d("inv_" + name)
         diff = b.sub(op, b.const(code))
-        cons.append((b.mul(f, b.sub(f, one)), 2))
-        cons.append((b.mul(f, diff), 2))
-        cons.append((b.sub(b.mul(diff, inv_), b.sub(one, f)), 2))
-        flags.append(f)
-    jumpy = b.add(b.add(flags[0], flags[1]), flags[2])
+        bit(f)
+        cons.append((b.mul(f, diff), 2))                                # flag = 1 only at this opcode ...
+        cons.append((b.sub(b.mul(diff, inv_), b.sub(one, f)), 2))       # ... and 0 only elsewhere
+        flags[name] = f
+    jumpy = b.add(b.add(flags["jal"], flags["jalr"]), b.add(flags["branch"], flags["ecall"]))
     cons.append((b.mul(b.mul(live, b.sub(one, d("is_seq"))), b.sub(one, jumpy)), 3))
     step = b.sub(d("next_pc"), d("pc"))
     imm_j = lin([(-(1 << 20), bits[31])] + [(1 << k, bits[k]) for k in range(12, 20)] + [(1 << 11, bits[20])] + [(1 << (k - 20), bits[k]) for k in range(21, 31)])
     imm_b = lin([(-(1 << 12), bits[31]), (1 << 11, bits[7])] + [(1 << (k - 20), bits[k]) for k in range(25, 31)] + [(1 << (k - 7), bits[k]) for k in range(8, 12)])
-    cons.append((b.mul(flags[0], b.sub(step, imm_j)), 2))
-    cons.append((b.mul(b.mul(flags[2], b.sub(step, four)), b.sub(step, imm_b)), 3))
-    # public inputs: the run starts at pc0 in cycle 0; the row after the last live one (or the last row itself) pins the end
+    cons.append((b.mul(flags["jal"], b.sub(step, imm_j)), 2))
+    cons.append((b.mul(b.mul(flags["branch"], b.sub(step, four)), b.sub(step, imm_b)), 3))
+    cons.append((b.mul(b.mul(flags["ecall"], step), b.sub(step, four)), 3))                             # an I/O ecall repeats (pc) or completes (pc + 4)
+    # --- the five accesses.  Timestamp of access k of a cycle: 5 cycle + k + 1.  An access that does not happen leaves its read
+    # tuple equal to its written tuple (they cancel in the grand product); one that happens writes its own timestamp, larger than
+    # the one it read: own - previous - 1 is a sum of twelve radix-4 digits.
+    digit = [[d("d%d_%d" % (k, i)) for i in range(12)] for k in range(5)]
+    for k in range(5):
+        for dg in digit[k]:
+            cons.append((b.mul(b.mul(dg, b.sub(dg, one)), b.mul(b.sub(dg, two), b.sub(dg, three))), 4))
+
+    def stamp(k):
+        return b.add(b.mul(five, d("cycle")), b.const(k + 1))
+
+    def ordered(act, k, deg):  # act * (tw_k - p_k - 1 - digits_k) = 0
+        cons.append((b.mul(act, b.sub(b.sub(d("tw%d" % k), b.add(d("p%d" % k), one)), lin([(4 ** i, digit[k][i]) for i in range(12)]))), deg + 1))
+
+    reg_base = b.const(REG_BASE)
+    for k, (z, inv_, act, lo_bit) in enumerate((("z1", "inv1", "act0", 15), ("z2", "inv2", "act1", 20))):
+        idx = lin([(1 << i, bits[lo_bit + i]) for i in range(5)])
+        cons.append((b.mul(d(z), idx), 2))                                                             # z = 1 iff the index is 0 ...
+        cons.append((b.sub(b.mul(idx, d(inv_)), b.sub(one, d(z))), 2))
+        cons.append((b.sub(d(act), b.mul(live, b.sub(one, d(z)))), 2))                                 # x0 is not memory: no access
+        for half_ in ("lo", "hi"):
+            cons.append((b.mul(d(z), d("rs%d_%s" % (k + 1, half_))), 2))                               # ... and reads as zero
+        cons.append((b.mul(d(act), b.sub(d("addr%d" % k), b.add(reg_base, idx))), 2))                  # the register the word names
+        cons.append((b.mul(d(act), b.sub(d("tw%d" % k), stamp(k))), 2))
+        cons.append((b.mul(b.sub(one, d(act)), b.sub(d("tw%d" % k), d("p%d" % k))), 2))
+        ordered(d(act), k, 1)
+    act2 = d("act2")
+    bit(act2)
+    idx_rd = lin([(1 << i, bits[7 + i]) for i in range(5)])
+    plain = b.mul(act2, b.sub(one, flags["ecall"]))                                                     # a register write of an ordinary instruction
+    cons.append((b.mul(plain, b.sub(d("addr2"), b.add(reg_base, idx_rd))), 3))                          # ... goes to the register the word names,
+    cons.append((b.mul(plain, b.sub(b.mul(idx_rd, d("inv_rd")), one)), 4))                              # ... which is not x0
+    sys_wr = b.mul(act2, flags["ecall"])                                                                # an ecall writes a0 or a1
+    cons.append((b.mul(b.mul(sys_wr, b.sub(d("addr2"), b.const(REG_BASE + 10))), b.sub(d("addr2"), b.const(REG_BASE + 11))), 4))
+    cons.append((b.mul(act2, b.sub(d("tw2"), stamp(2))), 2))
+    not_act2 = b.sub(one, act2)
+    for a_, c_ in (("tw2", "p2"), ("new_lo", "old_lo"), ("new_hi", "old_hi")):
+        cons.append((b.mul(not_act2, b.sub(d(a_), d(c_))), 2))
+    ordered(act2, 2, 1)
+    mk = d("mem_kind")
+    cons.append((b.mul(b.mul(mk, b.sub(mk, one)), b.sub(mk, two)), 3))                                  # none / read / write
+    mem_act = b.mul(half, b.mul(mk, b.sub(three, mk)))                                                  # 1 on reads and writes
+    is_write = b.mul(half, b.mul(mk, b.sub(mk, one)))                                                   # 1 on writes
+    keeps = b.sub(one, b.add(is_write, bnd))                                                            # the word stays as it was unless written (or a boundary row)
+    cons.append((b.mul(keeps, b.sub(d("after_lo"), d("before_lo"))), 3))
+    cons.append((b.mul(keeps, b.sub(d("after_hi"), d("before_hi"))), 3))
+    cons.append((b.mul(mem_act, b.sub(d("tw3"), stamp(3))), 3))
+    cons.append((b.mul(b.sub(one, b.add(mem_act, bnd)), b.sub(d("tw3"), d("p3"))), 3))
+    cons.append((b.mul(bnd, d("tw3")), 2))                                                              # a boundary row writes the first tuple: timestamp 0
+    ordered(mem_act, 3, 2)
+    # boundary rows in strictly increasing address order: one history per address (16 digits: access 3's twelve, access 2's first four)
+    gap = b.sub(b.sub(d("addr3"), b.add(d("addr3", 1), one)), lin([(4 ** i, digit[3][i]) for i in range(12)] + [(4 ** (12 + i), digit[2][i]) for i in range(4)]))
+    cons.append((b.mul(b.mul(bnd, prev_bnd), gap), 3))
+    cons.append((b.mul(live, b.sub(d("pc"), b.mul(four, d("addr4")))), 2))                              # the fetch reads the word at pc
+    cons.append((b.mul(live, b.sub(d("tw4"), stamp(4))), 2))
+    cons.append((b.mul(not_live, b.sub(d("tw4"), d("p4"))), 2))
+    ordered(live, 4, 1)
+    # --- public inputs: the run starts at pc0 in cycle 0; the row after the last cycle (or the last row itself) pins the end
+    G0 = 8
     cons.append((b.mul(first, b.sub(live, one)), 2))
-    cons.append((b.mul(first, b.sub(d("pc"), b.glob(0, 0))), 2))
+    cons.append((b.mul(first, b.sub(d("pc"), b.glob(0, G0))), 2))
     cons.append((b.mul(first, d("cycle")), 2))
-    ended = b.mul(not_first, b.sub(prev_live, live))                                                    # 1 on the first padding row
-    cons.append((b.mul(ended, b.sub(d("next_pc", 1), b.glob(0, 1))), 3))
-    cons.append((b.mul(ended, b.sub(b.add(d("cycle", 1), one), b.glob(0, 2))), 3))
+    ended = b.mul(not_first, b.sub(prev_live, live))                                                    # 1 on the first row that is not a cycle
+    cons.append((b.mul(ended, b.sub(d("next_pc", 1), b.glob(0, G0 + 1))), 3))
+    cons.append((b.mul(ended, b.sub(b.add(d("cycle", 1), one), b.glob(0, G0 + 2))), 3))
     full = b.mul(last, live)                                                                            # a trace that fills every row
-    cons.append((b.mul(full, b.sub(d("next_pc"), b.glob(0, 1))), 3))
-    cons.append((b.mul(full, b.sub(b.add(d("cycle"), one), b.glob(0, 2))), 3))
-    # the accumulator, exactly as in generate()
-    a, bb = d("pc"), d("cycle")
-    m0 = [b.glob(1, i) for i in range(4)]
-    m1 = [b.glob(1, 4 + i) for i in range(4)]
-    term = [b.add(m0[i], b.mul(m1[i], bb)) for i in range(4)]
-    term[0] = b.add(term[0], a)
-    prev = [b.get(G_ACCUM, i, 1) for i in range(4)]
-    sel = [b.mul(not_first, prev[i]) for i in range(4)]
-    sel[0] = b.add(sel[0], first)
-    want = fp4_mul_sym(b, term, sel)
-    cons.extend((b.sub(b.get(G_ACCUM, i, 0), want[i]), 3) for i in range(4))
+    cons.append((b.mul(full, b.sub(d("next_pc"), b.glob(0, G0 + 1))), 3))
+    cons.append((b.mul(full, b.sub(b.add(d("cycle"), one), b.glob(0, G0 + 2))), 3))
+    # --- the grand products: RS_A, RS_B over the tuples read, WS_A, WS_B over the tuples written
+    alpha = [b.glob(1, i) for i in range(4)]
+    beta = [[b.glob(1, 4 * (j + 1) + i) for i in range(4)] for j in range(3)]
+
+    def fingerprint(addr, lo, hi, t):  # alpha - addr - b1 lo - b2 hi - b3 t as four base-field expressions
+        out = []
+        for i in range(4):
+            e = b.sub(alpha[i], b.add(b.add(b.mul(beta[0][i], d(lo)), b.mul(beta[1][i], d(hi))), b.mul(beta[2][i], d(t))))
+            out.append(b.sub(e, d(addr)) if i == 0 else e)
+        return out
+
+    products = [  # (ACCUM column block, the fingerprints it multiplies) -- mirrored in the SEC_ACCUM_FP records below
+        [("addr0", "rs1_lo", "rs1_hi", "p0"), ("addr1", "rs2_lo", "rs2_hi", "p1"), ("addr2", "old_lo", "old_hi", "p2")],
+        [("addr3", "before_lo", "before_hi", "p3"), ("addr4", "insn_lo", "insn_hi", "p4")],
+        [("addr0", "rs1_lo", "rs1_hi", "tw0"), ("addr1", "rs2_lo", "rs2_hi", "tw1"), ("addr2", "new_lo", "new_hi", "tw2")],
+        [("addr3", "after_lo", "after_hi", "tw3"), ("addr4", "insn_lo", "insn_hi", "tw4")],
+    ]
+    for j, tuples in enumerate(products):
+        prev = [b.get(G_ACCUM, 4 * j + i, 1) for i in range(4)]
+        want = [b.mul(not_first, prev[i]) for i in range(4)]
+        want[0] = b.add(want[0], first)
+        for t in tuples:
+            want = fp4_mul_sym(b, want, fingerprint(*t))
+        cons.extend((b.sub(b.get(G_ACCUM, 4 * j + i, 0), want[i]), 2 + len(tuples)) for i in range(4))
+    acc = [[b.get(G_ACCUM, 4 * j + i, 0) for i in range(4)] for j in range(4)]
+    reads, writes = fp4_mul_sym(b, acc[0], acc[1]), fp4_mul_sym(b, acc[2], acc[3])
+    cons.extend((b.mul(last, b.sub(reads[i], writes[i])), 3) for i in range(4))                          # every tuple read was written, once
     assert max(deg for _, deg in cons) <= 5
     x = b.true()
     for v, _ in cons:
         x = b.and_eqz(x, v)
     taps = sorted(b.taps)
     tap_index = {t: i for i, t in enumerate(taps)}
-    steps = [(op, tap_index[(a_[1], a_[2], a_[3])] if op == OP_GET else a_, b_, c_) for op, a_, b_, c_ in b.steps]
+    steps = [(op_, tap_index[(a_[1], a_[2], a_[3])] if op_ == OP_GET else a_, b_, c_) for op_, a_, b_, c_ in b.steps]
 
     def section(tag, words):
         return [tag, len(words)] + list(words)
 
+    acc_records = []
+    for tuples in products:
+        rec = [len(tuples)]
+        for t in tuples + [("live",) * 4] * (3 - len(tuples)):
+            rec += [col[name] for name in t]
+        acc_records += rec
     words = [MAGIC, 1, 7]
-    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_TRACE:v1__")))
+    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_TRACE:v2__")))
     words += section(SEC_GROUPS, [4 * n_acc, n_code, n_data])
     words += section(SEC_TAPS, [len(taps)] + [w for t in taps for w in t])
-    words += section(SEC_GLOBALS, [n_global, 8 * n_acc] + [col["pc"], col["next_pc"], col["cycle"]])
+    words += section(SEC_GLOBALS, [n_global, 16])
     words += section(SEC_POLY, [len(steps), x] + [w for st in steps for w in st])
     words += section(SEC_WITGEN, [n_code] + [w for cc in code_cols for w in cc] + [n_data] + [w for dc in data_cols for w in dc])
-    words += section(SEC_ACCUM, [n_acc] + [w for ac in acc_cols for w in ac])
+    words += section(SEC_ACCUM_FP, [n_acc] + acc_records)
     info = {"taps": len(taps), "steps": len(steps), "constraints": len(cons), "mul_per_point": b.n_mul, "addsub_per_point": b.n_add,
-            "groups": [4 * n_acc, n_code, n_data], "columns": TRACE_COLUMNS}
+            "groups": [4 * n_acc, n_code, n_data], "columns": len(TRACE_COLUMNS)}
     return words, info
 
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak run for the trace circuit on the GPU box: random RV32IM programs (ALU, M extension, loads / stores, forward branches of
-every kind, forward JALs, a backward loop around everything) are executed, their preflight traces become witnesses, the device
-proves each and the seal must equal the CPU oracle's word for word and verify bound to the control root.
+every kind, forward JALs, a backward loop around everything, a READ_WORDS / COMMIT pair) are executed, the device expands their
+compact preflight rows into the trace circuit's witness (r0h_trace_witgen) -- which must equal the host reference word for word --
+and proves each; the seal must equal the CPU oracle's word for word and verify bound to the control root.  Every eighth run is also
+tampered with (one register value read back wrong): both verifiers must refuse it.
 usage: python tools/soak_trace.py [minutes]"""
 import os
 import sys
@@ -41,7 +43,10 @@ def random_program(rng, n):
             body.append(J(int(rng.choice([8, 12])), int(rng.choice([0, 1, 5]))))
     body += [ADDI(0, 0, 0)] * 3  # landing room for the last forward jumps
     loop = flat(body, ADDI(29, 29, -1), B(-4 * (len(body) + 1), 0, 29, 1))
-    return flat(LI(28, 0x40000), ADDI(29, 0, int(rng.integers(1, 7))), loop, ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
+    n_io = int(rng.integers(0, 9))
+    io = flat(LI(A0, 0x50000), ADDI(11, 0, n_io), ADDI(A7, 0, 1), ECALL,                  # READ_WORDS(0x50000, n_io)
+              LI(A0, 0x50001), ADDI(11, 0, max(0, 4 * n_io - 2)), ADDI(A7, 0, 2), ECALL)    # COMMIT(0x50001, 4 n_io - 2)
+    return flat(LI(28, 0x40000), ADDI(29, 0, int(rng.integers(1, 7))), loop, io, ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
 
 
 def main():
@@ -51,7 +56,7 @@ def main():
     oc, gc = orc.circuit(blob), hal.load_circuit(blob)
     rng = np.random.default_rng(2026)
     fixed = {}
-    t0, n, rows_total, taken = time.time(), 0, 0, 0
+    t0, n, rows_total, taken, tampered = time.time(), 0, 0, 0, 0
     while time.time() - t0 < budget:
         prog = random_program(rng, int(rng.integers(40, 990)))  # the closing branch reaches back at most 4 KiB
         vm = r0.Vm()
@@ -59,29 +64,45 @@ def main():
         vm.set_pc(0x1000)
         for i in range(1, 28):
             vm.set_reg(i, int(rng.integers(0, 1 << 32)) if rng.random() < 0.7 else int(rng.choice([0, 1, 0xFFFFFFFF, 0x80000000])))
-        assert vm.run(segment_po2=20, keep_trace=True) == (0, 0)
-        rows = vm.preflight(0)
-        po2 = max(9, int(np.ceil(np.log2(len(rows)))))
+        vm.set_input([int(v) for v in rng.integers(0, 1 << 32, 8)])
+        assert vm.run(segment_po2=20, keep_trace=True, boundary_rows=True) == (0, 0)
+        rows, bounds = vm.preflight_arrays(0)
+        po2 = max(9, int(np.ceil(np.log2(len(rows) + len(bounds)))))
         if po2 not in fixed:
             code, synthetic, _ = hal.witgen(gc, po2, 0)
             synthetic.free()
-            fixed[po2] = (code, hal.code_root(gc, po2, code), oc.witgen(po2, 0)[0])
-        code, root, ocode = fixed[po2]
+            fixed[po2] = (hal.code_commit(gc, po2, code), oc.witgen(po2, 0)[0])
+            code.free()
+        cc, ocode = fixed[po2]
+        root = cc.root()
         data, glob = vm.trace_witness(0, po2)
-        dev = hal.copy_from(data)
-        seal = hal.prove_segment(gc, po2, code, dev, glob)
-        dev.free()
+        dev, dglob = hal.trace_witgen(rows, bounds, po2)
+        if not np.array_equal(dev.to_host(), data) or not np.array_equal(dglob, glob):
+            print("FAILED on program %d: the device's witness differs from the host reference" % n)
+            sys.exit(1)
+        seal = hal.prove_segment(gc, po2, cc, dev, glob)
         want = oc.prove(po2, ocode, data, glob)
         if not np.array_equal(seal, want) or oc.verify(seal, code_root=root)[0] != 0 or r0.verify_seal(blob, seal, code_root=root)[0] != 0:
             print("FAILED on program %d (%d rows, po2 %d)" % (n, len(rows), po2))
             sys.exit(1)
+        if n % 8 == 0:  # a register read that does not return what was written: refused by both verifiers
+            reads = [r for r in range(len(rows)) if (rows[r, 2] >> 15) & 31]
+            bad = rows.copy()
+            bad[reads[len(reads) // 2], 4] ^= 1 << int(rng.integers(0, 32))
+            hal.trace_witgen(bad, bounds, po2, into=dev)
+            forged = hal.prove_segment(gc, po2, cc, dev, glob)
+            if oc.verify(forged, code_root=root)[0] != 4 or r0.verify_seal(blob, forged, code_root=root)[0] != 4:
+                print("FAILED on program %d: an inconsistent register read was accepted" % n)
+                sys.exit(1)
+            tampered += 1
+        dev.free()
         n += 1
         rows_total += len(rows)
-        taken += sum(1 for w in rows if (w.insn & 0x7f) in (0x63, 0x6f) and w.next_pc != w.pc + 4)
+        taken += int((np.isin(rows[:, 2] & 0x7f, (0x63, 0x6f)) & (rows[:, 3] != rows[:, 1] + 4)).sum())
         if n % 50 == 0:
             print("%d executions proved (%d cycles, %d taken branches and jumps) after %.0f s" % (n, rows_total, taken, time.time() - t0), flush=True)
-    print("soak ok: %d random executions (%d cycles, %d taken branches and jumps): device seal == oracle seal word for word, both verifiers accept bound to the control root"
-          % (n, rows_total, taken))
+    print("soak ok: %d random executions (%d cycles, %d taken branches and jumps): device witness == host reference and device seal == oracle seal word for word, "
+          "both verifiers accept bound to the control root; %d tampered runs (a register read back wrong) refused by both" % (n, rows_total, taken, tampered))
 
 
 if __name__ == "__main__":
