@@ -149,6 +149,16 @@ _SIGNATURES = {
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
     "r0h_prove_elf": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _pp, _vp, _c.POINTER(_u64)],
+    "r0h_recursor_new": [_vp, _vp, _sz, _cp, _u32, _vp, _sz, _vp, _sz, _pp],
+    "r0h_recursor_free": [_vp],
+    "r0h_recursor_control_root": [_vp, _vp],
+    "r0h_lift": [_vp, _vp, _sz, _vp, _pp],
+    "r0h_join": [_vp, _vp, _vp, _pp],
+    "r0h_node_new": [_vp, _sz, _vp, _pp],
+    "r0h_node_free": [_vp],
+    "r0h_node_seal": [_vp, _pp, _c.POINTER(_sz)],
+    "r0h_node_claim": [_vp, _vp],
+    "r0h_node_verify": [_vp, _sz, _vp, _vp, _c.POINTER(_c.c_int)],
     "r0h_kernel_timing": [_vp, _c.c_int],
     "r0h_kernel_stats": [_vp, _vp, _sz],
     "r0h_last_profile": [_vp, _c.POINTER(_c.POINTER(_cp)), _c.POINTER(_c.POINTER(_c.c_float)), _c.POINTER(_u32)],

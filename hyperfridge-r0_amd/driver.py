@@ -14,6 +14,16 @@ def shard_segments(total, world, rank):
     return list(range(rank, total, world))
 
 
+def shard_contiguous(total, world, rank):
+    """Balanced partition into contiguous runs, rank order = segment order: what the lift/join tree needs (a join composes two
+    claims that follow one another, so a rank's nodes and its neighbour's must be neighbours in the session)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
 class DistEnv:
     """Rank bookkeeping + the three collectives the driver needs.  backend=None means single process."""
 

@@ -1,22 +1,24 @@
-"""lift + join tree over segment seals: the exchange-and-prove schedule of BASELINE.json configs[4] (SURVEY.md 8(a) a19,
-8(e)): risc0-zkvm `ProverServer::lift(SegmentReceipt)` turns every segment seal into a recursion-circuit proof, `join(a, b)`
-folds two of them into one, and the folds form a binary tree whose levels are the only inter-GPU exchange of the whole path.
+"""lift + join tree over segment receipts: the exchange schedule of BASELINE.json configs[4].
 
-What is reproduced here is that dataflow, with the same kernels: every lift and join is one STARK over a second,
-recursion-SHAPED circuit (circuits/recursion.r0c, proved at po2 = 18) whose 16 public inputs are the two 8-word digests the
-step stands for, after the step has checked the seals it consumes with the host-side verifier.  What is NOT reproduced is
-risc0's recursion circuit itself (its programs are downloaded at build time upstream): the check of the children happens
-beside the proof, not inside it, so the root is a verifiable tree of seals, not a succinct receipt.  Parity for this row is
-therefore "the seals verify (product verifier and oracle) and bind the digests", not word parity with risc0.
+risc0-zkvm `ProverServer::lift(SegmentReceipt)` turns every segment seal into a recursion-circuit proof, `join(a, b)` folds two of
+them into one, and the folds form a binary tree whose levels are the only inter-GPU exchange of the whole path.  The proving side --
+lift, join, the composition of claims ({pre: a.pre, post: b.post, ..}), the refusal of two nodes that do not follow one another --
+lives in the library behind the C ABI (csrc/recursion.hip: r0h_recursor_new / r0h_lift / r0h_join / r0h_node_*; what a node's
+proof is and is not -- children checked BESIDE the proof, not risc0's recursion circuit -- is stated there and in include/r0hip.h).
+This module is the transport only: which rank hands its subtree to which, and how a node travels.
 
 Transport: `torch.distributed` point-to-point send/recv (backend "nccl" = RCCL over xGMI on a GPU node, "gloo" on CPU), one
 process per GPU; partner of rank r at level l is r ^ (1 << l), the lower rank of a pair joins.  No collective is involved.
+A node travels as its claim (the 144 bytes of r0h_receipt_claim) followed by its seal.
 """
+import ctypes
+
 import numpy as np
 
-from . import Hal, seal_digest, verify_seal, R0HipError  # noqa: F401  (package __init__ is the ctypes harness)
+from . import Hal, ReceiptClaim, R0HipError, _check, _u32arr, _vp, _sz, lib, seal_digest, verify_seal  # noqa: F401  (package __init__ is the ctypes harness)
 
 RECURSION_PO2 = 18
+CLAIM_WORDS = ctypes.sizeof(ReceiptClaim) // 4
 
 
 def tree_schedule(world):
@@ -31,75 +33,104 @@ def tree_schedule(world):
 
 
 class Node:
-    """A proven tree node: its seal, the circuit it is a proof of, and the digests its public inputs carry."""
+    """A proven tree node (r0h_node): its seal and the composed claim it is carried with."""
 
-    def __init__(self, seal, left, right):
-        self.seal, self.left, self.right = np.ascontiguousarray(seal, dtype=np.uint32), left, right
+    def __init__(self, handle):
+        self.handle = handle
+        p, n = _vp(), _sz(0)
+        _check(lib().r0h_node_seal(handle, ctypes.byref(p), ctypes.byref(n)))
+        self.seal = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint32)), shape=(n.value,)).copy()
+        self.claim = ReceiptClaim()
+        _check(lib().r0h_node_claim(handle, ctypes.byref(self.claim)))
+
+    @classmethod
+    def from_parts(cls, seal, claim):
+        a, pa = _u32arr(seal)
+        h = _vp()
+        _check(lib().r0h_node_new(pa, a.size, ctypes.byref(claim), ctypes.byref(h)))
+        return cls(h)
+
+    def to_words(self):
+        return np.concatenate([np.frombuffer(bytes(self.claim), dtype=np.uint32), self.seal]).astype(np.uint32)
+
+    @classmethod
+    def from_words(cls, words):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        if words.size <= CLAIM_WORDS:
+            raise R0HipError("a node on the wire is %d claim words followed by its seal; got %d words" % (CLAIM_WORDS, words.size))
+        claim = ReceiptClaim.from_buffer_copy(words[:CLAIM_WORDS].tobytes())
+        return cls.from_parts(words[CLAIM_WORDS:], claim)
 
     @property
     def digest(self):
         return seal_digest(self.seal)
 
+    @property
+    def claim_words(self):
+        """public inputs 0..7: the words naming the node's composed claim"""
+        return self.seal[:8].copy()
+
+    @property
+    def consumed_digest(self):
+        """public inputs 8..15: the Poseidon2 digest of what the node consumed (a segment seal, or its two children's digests)"""
+        return self.seal[8:16].copy()
+
+    def free(self):
+        if self.handle:
+            lib().r0h_node_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
 
 class Recursor:
-    """Proves lift / join steps on one device.  `segment_blob` is the circuit the leaf seals belong to."""
+    """lift / join on one device (r0h_recursor).  `segment_blob` is the circuit the leaf seals belong to; `segment_roots`
+    {po2: root[8]} binds the leaves to the segment program (without it they are verified against the circuit alone)."""
 
-    def __init__(self, hal, recursion_blob, segment_blob, code_object=None, po2=RECURSION_PO2):
+    def __init__(self, hal, recursion_blob, segment_blob, code_object=None, po2=RECURSION_PO2, segment_roots=None):
         self.hal, self.po2 = hal, po2
         self.recursion_blob = np.ascontiguousarray(recursion_blob, dtype=np.uint32)
-        self.segment_blob = np.ascontiguousarray(segment_blob, dtype=np.uint32)
-        self.circuit = hal.load_circuit(self.recursion_blob, code_object)
-        if self.circuit.n_global != 16:
-            raise R0HipError("recursion circuit must expose 16 public inputs (two digests), this one has %d" % self.circuit.n_global)
+        rb, prb = _u32arr(self.recursion_blob)
+        sb, psb = _u32arr(segment_blob)
+        roots = np.zeros(9 * max(len(segment_roots or {}), 1), dtype=np.uint32)
+        for k, (size, root) in enumerate(sorted((segment_roots or {}).items())):
+            roots[9 * k] = size
+            roots[9 * k + 1:9 * k + 9] = root
+        self.handle = _vp()
+        _check(lib().r0h_recursor_new(hal.ctx, prb, rb.size, code_object.encode() if code_object else None, po2, psb, sb.size, roots.ctypes.data_as(_vp),
+                                      len(segment_roots or {}), ctypes.byref(self.handle)))
+        self.control_root = np.zeros(8, dtype=np.uint32)
+        _check(lib().r0h_recursor_control_root(self.handle, self.control_root.ctypes.data_as(_vp)))
 
-    def _prove(self, left_digest, right_digest):
-        public = np.concatenate([left_digest, right_digest]).astype(np.uint32)
-        seed = int(public[0]) | (int(public[8]) << 32)  # the rest of the witness is synthetic: any deterministic choice
-        code, data, glob = self.hal.witgen(self.circuit, self.po2, seed, globals_in=public)
-        try:
-            return self.hal.prove_segment(self.circuit, self.po2, code, data, glob)
-        finally:
-            code.free()
-            data.free()
-
-    def _checked(self, checks, prove):
-        """Run `prove()` on the device while host threads verify the seals this step consumes (checks = [(seal, blob, what)]);
-        the step only counts if every check passed.  The proof needs the digests, not the verdicts, so the two overlap."""
-        import threading
-        verdicts = [None] * len(checks)
-
-        def run(k):
-            verdicts[k] = verify_seal(checks[k][1], checks[k][0])
-
-        threads = [threading.Thread(target=run, args=(k,)) for k in range(len(checks))]
-        for t in threads:
-            t.start()
-        try:
-            seal = prove()
-        finally:
-            for t in threads:
-                t.join()
-        for (_, _, what), v in zip(checks, verdicts):
-            if v is None or v[0] != 0:
-                raise R0HipError("%s: the seal to be consumed does not verify: %s" % (what, v[1] if v else "verifier did not run"))
-        return seal
-
-    def lift(self, segment_seal):
-        """risc0 `lift`: one recursion-circuit proof standing for one segment seal."""
-        d = seal_digest(segment_seal)
-        zero = np.zeros(8, dtype=np.uint32)
-        seal = self._checked([(segment_seal, self.segment_blob, "lift")], lambda: self._prove(d, zero))
-        return Node(seal, d, zero)
+    def lift(self, segment_seal, claim):
+        """risc0 `lift`: one recursion-circuit proof standing for one segment seal and its claim."""
+        a, pa = _u32arr(segment_seal)
+        h = _vp()
+        _check(lib().r0h_lift(self.handle, pa, a.size, ctypes.byref(claim), ctypes.byref(h)))
+        return Node(h)
 
     def join(self, a, b):
-        """risc0 `join`: one recursion-circuit proof standing for two recursion proofs (seals given as arrays or Nodes)."""
-        sa, sb = (a.seal if isinstance(a, Node) else a), (b.seal if isinstance(b, Node) else b)
-        da, db = seal_digest(sa), seal_digest(sb)
-        seal = self._checked([(sa, self.recursion_blob, "join (left)"), (sb, self.recursion_blob, "join (right)")], lambda: self._prove(da, db))
-        return Node(seal, da, db)
+        """risc0 `join`: one proof standing for two nodes that follow one another; its claim is their composition."""
+        h = _vp()
+        _check(lib().r0h_join(self.handle, a.handle, b.handle, ctypes.byref(h)))
+        return Node(h)
+
+    def node_from_words(self, words):
+        return Node.from_words(words)
+
+    def verify(self, node):
+        """the node's seal verifies bound to the recursion circuit's control root and names the claim it is carried with"""
+        ok = ctypes.c_int(0)
+        rb, prb = _u32arr(self.recursion_blob)
+        _check(lib().r0h_node_verify(prb, rb.size, self.control_root.ctypes.data_as(_vp), node.handle, ctypes.byref(ok)))
+        return bool(ok.value)
 
     def fold(self, nodes):
-        """Left-to-right binary fold of this rank's own nodes (log depth)."""
+        """Left-to-right binary fold of this rank's own nodes (log depth); neighbours are joined, so consecutive segments stay consecutive."""
         nodes = list(nodes)
         while len(nodes) > 1:
             nxt = [self.join(nodes[i], nodes[i + 1]) for i in range(0, len(nodes) - 1, 2)]
@@ -109,13 +140,9 @@ class Recursor:
         return nodes[0]
 
     def close(self):
-        self.circuit.free()
-
-
-def public_inputs_of(recursion_blob, seal):
-    """The 16 public-input words a recursion seal opens with (its transcript commits to them): (left digest, right digest)."""
-    seal = np.ascontiguousarray(seal, dtype=np.uint32)
-    return seal[:8].copy(), seal[8:16].copy()
+        if self.handle:
+            _check(lib().r0h_recursor_free(self.handle))
+            self.handle = None
 
 
 FAILED = np.array([0xFFFFFFFF], dtype=np.uint32)  # handed up instead of a seal by a rank whose subtree could not be proved
@@ -123,7 +150,9 @@ EMPTY = np.zeros(0, dtype=np.uint32)               # handed up by a rank that ow
 
 
 def join_across_ranks(recursor, node, rank, world, send, recv):
-    """Run the cross-rank part of the tree.  `send(array, dst)` / `recv(src) -> array` move one seal (uint32 words).
+    """Run the cross-rank part of the tree.  `send(array, dst)` / `recv(src) -> array` move one node (uint32 words: claim, seal).
+    A rank's own nodes cover a contiguous run of segments and rank r's run precedes rank r + 1's (driver.shard_contiguous), so the
+    receiver's node is always the LEFT operand of the join.
     Returns the root Node on rank 0 and None elsewhere.
 
     Every rank takes part in every exchange the schedule gives it, whatever happened before: a rank without a node (empty
@@ -133,7 +162,7 @@ def join_across_ranks(recursor, node, rank, world, send, recv):
     failed = None
     for _level, receiver, sender in tree_schedule(world):
         if rank == sender:
-            send(FAILED if failed is not None else (EMPTY if node is None else node.seal), receiver)
+            send(FAILED if failed is not None else (EMPTY if node is None else node.to_words()), receiver)
             if failed is not None:
                 raise failed
             return None  # this rank's subtree has been handed up
@@ -143,7 +172,8 @@ def join_across_ranks(recursor, node, rank, world, send, recv):
                 failed = failed or R0HipError("join tree: rank %d reported a failure in its subtree" % sender)
             elif failed is None and other.size:
                 try:
-                    node = Node(other, None, None) if node is None else recursor.join(node, Node(other, None, None))
+                    arrived = recursor.node_from_words(other)
+                    node = arrived if node is None else recursor.join(node, arrived)
                 except Exception as exc:  # noqa: BLE001 -- carried up the tree, re-raised below
                     failed = exc
     if failed is not None:

@@ -475,6 +475,33 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
 typedef struct { uint32_t segments; uint64_t cycles; double executor_s, witgen_ms, prove_ms, wall_s; } r0h_session_stats;
 const char* r0h_last_session_stats(r0h_ctx* ctx, r0h_session_stats* out);
 
+/* ---- recursion: risc0-zkvm `ProverServer::{lift, join}` (risc0-circuit-recursion 4.0.4, Cargo.lock:3050-3085; BASELINE.json
+ * configs[4]).  `lift` stands one recursion-circuit proof for one segment seal and its claim; `join` folds two nodes into one whose
+ * claim is the composition {pre: a.pre, post: b.post, exit_code: b.exit_code, input: a.input, output: b.output}, and refuses two
+ * nodes that do not follow one another (a must end in SystemSplit with a.post == b.pre).  A node's 16 public inputs are the 8 words
+ * naming its composed claim (r0h_claim_globals) and the Poseidon2 digest of what it consumed.
+ * NOT risc0's recursion circuit: every node is a proof over a recursion-SHAPED circuit (circuits/recursion.r0c) made with the
+ * same kernels, and the seals it consumes are verified BESIDE that proof (host threads, while the device proves), not inside it --
+ * a root is a checkable tree of seals carrying the end-to-end claim, not a succinct receipt.  Moving nodes between ranks
+ * (the tree's levels) is the caller's: hyperfridge-r0_amd/recursion.py does it over torch.distributed point-to-point. ---- */
+typedef struct r0h_recursor r0h_recursor;
+typedef struct r0h_node r0h_node;
+/* segment_control_roots: n_roots records of 9 words [po2, root[8]] (r0h_code_root of the segment circuit); with n_roots = 0 the
+ * leaves are verified against the segment circuit alone */
+const char* r0h_recursor_new(r0h_ctx* ctx, const uint32_t* recursion_blob, size_t recursion_words, const char* code_object_path,
+                             uint32_t po2, const uint32_t* segment_blob, size_t segment_words, const uint32_t* segment_control_roots,
+                             size_t n_roots, r0h_recursor** out);
+const char* r0h_recursor_free(r0h_recursor* rc);
+const char* r0h_recursor_control_root(const r0h_recursor* rc, uint32_t root_out[8]); /* of the recursion circuit at its po2 */
+const char* r0h_lift(r0h_recursor* rc, const uint32_t* seal, size_t seal_words, const r0h_receipt_claim* claim, r0h_node** out);
+const char* r0h_join(r0h_recursor* rc, const r0h_node* a, const r0h_node* b, r0h_node** out);
+const char* r0h_node_new(const uint32_t* seal, size_t seal_words, const r0h_receipt_claim* claim, r0h_node** out); /* as received */
+const char* r0h_node_free(r0h_node* node);
+const char* r0h_node_seal(const r0h_node* node, const uint32_t** seal, size_t* seal_words);
+const char* r0h_node_claim(const r0h_node* node, r0h_receipt_claim* claim_out);
+const char* r0h_node_verify(const uint32_t* recursion_blob, size_t blob_words, const uint32_t* control_root, const r0h_node* node,
+                            int* ok_out);
+
 /* Optional per-kernel timing with HIP events on the context's stream (for bench.py's roofline object): enable, run,
  * then read {"kernel family": {"launches", "total_ms", "alg_bytes"}} as JSON.  Enabling resets the counters. */
 const char* r0h_kernel_timing(r0h_ctx* ctx, int enable);

@@ -104,8 +104,8 @@ def test_config3_batch_of_32_receipts_at_full_size(tmp_path, bench_circuit):
             assert bench_circuit["oc"].verify(np.array(s["seal"], dtype=np.uint32), code_root=bench_circuit["root"]) == (0, "ok"), (path, s["index"])
         rc = r0.Receipt.parse(text)
         assert rc.to_json() == text
-        assert rc.verify(bench_circuit["blob"], roots, bytes.fromhex(ids["image_ids"][r]))[:2] == (0, "ok"), path
-        assert rc.verify(bench_circuit["blob"], roots, bytes.fromhex(ids["image_ids"][(r + 1) % 32]))[0] == 8  # another receipt's image id
+        assert rc.verify(bench_circuit["blob"], roots, r0.image_id_from_hex(ids["image_ids"][r]))[:2] == (0, "ok"), path
+        assert rc.verify(bench_circuit["blob"], roots, r0.image_id_from_hex(ids["image_ids"][(r + 1) % 32]))[0] == 8  # another receipt's image id
 
 
 def test_config4_lift_join_tree_of_8_leaves_over_two_ranks(tmp_path, orc):
@@ -116,5 +116,9 @@ def test_config4_lift_join_tree_of_8_leaves_over_two_ranks(tmp_path, orc):
     d = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     assert d["n_gpus"] == 2 and d["segments"] == 8 and d["segment_po2"] == 20 and d["recursion_po2"] == 18
     assert d["cross_rank_join_steps"] == 1 and d["root_verifies"] is True and d["backend"] == "gloo"
+    assert d["root_claim_is_the_sessions_end_to_end_claim"] is True
     rec_blob = np.fromfile(circuit_path("recursion"), dtype=np.uint32)
-    assert orc.circuit(rec_blob).verify(np.load(root_file)) == (0, "ok")
+    root_seal = np.load(root_file)
+    assert orc.circuit(rec_blob).verify(root_seal, code_root=np.load(root_file + ".control_root.npy")) == (0, "ok")
+    claim = r0.ReceiptClaim.from_buffer_copy(open(root_file + ".claim.bin", "rb").read())
+    assert np.array_equal(root_seal[:8], claim.globals()) and (claim.exit_system, claim.exit_user) == (0, 0)  # the root names a halted, composed claim

@@ -34,15 +34,26 @@ def test_tree_schedule_is_a_binary_join_tree(world):
     assert max([lvl for lvl, _, _ in plan], default=-1) + 1 == (world - 1).bit_length()
 
 
+class _HashNode:
+    def __init__(self, seal):
+        self.seal = np.ascontiguousarray(seal, dtype=np.uint32)
+
+    def to_words(self):
+        return self.seal
+
+
 class _HashRecursor:
-    """Stand-in prover for the transport tests: a 'seal' is 8 words of SHA-256 over its children."""
+    """Stand-in prover for the transport tests: a 'seal' is 8 words of SHA-256 over its children (no claim travels with it)."""
 
     @staticmethod
     def leaf(i):
-        return recursion.Node(np.frombuffer(hashlib.sha256(b"leaf%d" % i).digest(), dtype=np.uint32), None, None)
+        return _HashNode(np.frombuffer(hashlib.sha256(b"leaf%d" % i).digest(), dtype=np.uint32))
 
     def join(self, a, b):
-        return recursion.Node(np.frombuffer(hashlib.sha256(a.seal.tobytes() + b.seal.tobytes()).digest(), dtype=np.uint32), a.seal, b.seal)
+        return _HashNode(np.frombuffer(hashlib.sha256(a.seal.tobytes() + b.seal.tobytes()).digest(), dtype=np.uint32))
+
+    def node_from_words(self, words):
+        return _HashNode(words)
 
 
 def _expected_root(world):
@@ -115,38 +126,108 @@ def test_oracle_public_inputs_are_planted_and_committed(orc):
     assert r0.seal_digest(seal).tolist() == orc.hash_elem_slice(seal % P).tolist()
 
 
+def test_contiguous_sharding_keeps_rank_order_equal_to_segment_order():
+    from hyperfridge_r0_amd import driver
+    for total in (0, 1, 3, 8, 13, 64):
+        for world in (1, 2, 3, 6, 8):
+            runs = [driver.shard_contiguous(total, world, r) for r in range(world)]
+            assert [s for run in runs for s in run] == list(range(total))
+            assert max(len(r) for r in runs) - min(len(r) for r in runs) <= 1
+
+
 @pytest.mark.gpu
 def test_lift_and_join_on_the_device(hal, orc):
+    """r0h_lift / r0h_join through the C ABI: nodes carry composed claims, their seals name them, the oracle reproduces a node's seal
+    word for word, two nodes that do not follow one another are refused."""
     seg_blob, rec_blob = _blob("small"), _blob("recursion")
     seg = hal.load_circuit(seg_blob)
+    journal = r0.serde_encode_str('{"n":4}')
+    claims, image_id = r0.session_claims(4, journal)
+    seg_cc = hal.code_commit(seg, 10)
     seals = []
-    for seed in (1, 2, 3):
-        code, data, glob = hal.witgen(seg, 10, seed)
-        seals.append(hal.prove_segment(seg, 10, code, data, glob))
-    rec = recursion.Recursor(hal, rec_blob, seg_blob, po2=12)
-    lifted = [rec.lift(s) for s in seals]
+    for k, cl in enumerate(claims):
+        code, data, glob = hal.witgen(seg, 10, 1 + k, globals_in=cl.globals())
+        seals.append(hal.prove_segment(seg, 10, seg_cc, data, glob))
+        code.free(); data.free()
+    rec = recursion.Recursor(hal, rec_blob, seg_blob, po2=12, segment_roots={10: seg_cc.root()})
+    lifted = [rec.lift(s, cl) for s, cl in zip(seals, claims)]
     oc = orc.circuit(rec_blob)
-    for node, s in zip(lifted, seals):
-        assert np.array_equal(node.left, r0.seal_digest(s)) and not node.right.any()
-        left, right = recursion.public_inputs_of(rec_blob, node.seal)
-        assert np.array_equal(left, node.left) and np.array_equal(right, node.right)
-        assert r0.verify_seal(rec_blob, node.seal) == (0, "ok", 12) and oc.verify(node.seal) == (0, "ok")
+    for node, s, cl in zip(lifted, seals, claims):
+        assert np.array_equal(node.claim_words, cl.globals()) and np.array_equal(node.consumed_digest, r0.seal_digest(s))
+        assert node.claim.digest() == cl.digest() and rec.verify(node)
+        assert r0.verify_seal(rec_blob, node.seal, code_root=rec.control_root) == (0, "ok", 12) and oc.verify(node.seal, code_root=rec.control_root) == (0, "ok")
     # bit-exact against the oracle proving the same step
-    public = np.concatenate([lifted[0].left, lifted[0].right])
+    public = np.concatenate([lifted[0].claim_words, lifted[0].consumed_digest])
     seed = int(public[0]) | (int(public[8]) << 32)
     ocode, odata, oglob = oc.witgen(12, seed, globals_in=public)
     assert np.array_equal(oc.prove(12, ocode, odata, oglob), lifted[0].seal)
-    root = rec.fold(lifted)  # join(join(l0, l1), l2)
-    assert r0.verify_seal(rec_blob, root.seal)[0] == 0 and oc.verify(root.seal) == (0, "ok")
-    inner = rec.join(lifted[0], lifted[1])
-    assert np.array_equal(root.left, r0.seal_digest(inner.seal)) and np.array_equal(root.right, lifted[2].digest)
+    root = rec.fold(lifted)  # join(join(l0, l1), join(l2, l3))
+    assert rec.verify(root) and oc.verify(root.seal, code_root=rec.control_root) == (0, "ok")
+    end_to_end = r0.ReceiptClaim.make(claims[0].pre, claims[-1].post, claims[-1].exit_system, claims[-1].exit_user, bytes(claims[-1].output_digest))
+    assert root.claim.digest() == end_to_end.digest() and root.claim.pre.digest() == image_id and np.array_equal(root.claim_words, end_to_end.globals())
+    left, right = rec.join(lifted[0], lifted[1]), rec.join(lifted[2], lifted[3])
+    assert np.array_equal(root.consumed_digest, r0.seal_digest(np.concatenate([r0.seal_digest(left.seal), r0.seal_digest(right.seal)])))
+    assert left.claim.pre.digest() == claims[0].pre.digest() and left.claim.post.digest() == claims[1].post.digest() and left.claim.exit_system == 2
+    # a node travels as claim + seal and arrives the same
+    back = recursion.Node.from_words(left.to_words())
+    assert np.array_equal(back.seal, left.seal) and back.claim.digest() == left.claim.digest() and rec.verify(back)
+    # refused: a swapped pair, a gap, something after a halt, a forged claim beside a genuine seal, a broken seal
+    with pytest.raises(r0.R0HipError, match="do not follow one another"):
+        rec.join(lifted[1], lifted[0])
+    with pytest.raises(r0.R0HipError, match="do not follow one another"):
+        rec.join(lifted[0], lifted[2])
+    with pytest.raises(r0.R0HipError, match="SystemSplit"):
+        rec.join(lifted[3], lifted[0])
+    forged = recursion.Node.from_parts(lifted[1].seal, claims[2])
+    with pytest.raises(r0.R0HipError, match="does not name the claim"):
+        rec.join(lifted[0], recursion.Node.from_parts(lifted[1].seal, r0.ReceiptClaim.make(claims[1].pre, claims[2].post, 2)))
+    assert not rec.verify(forged)
+    with pytest.raises(r0.R0HipError, match="do not name this claim"):
+        rec.lift(seals[0], claims[1])
     bad = seals[0].copy()
     bad[-1] ^= 1
     with pytest.raises(r0.R0HipError, match="does not verify"):
-        rec.lift(bad)
+        rec.lift(bad, claims[0])
+    tampered = lifted[1].seal.copy()
+    tampered[-1] ^= 1
     with pytest.raises(r0.R0HipError, match="does not verify"):
-        rec.join(lifted[0], seals[1])  # a segment seal is not a recursion seal
+        rec.join(lifted[0], recursion.Node.from_parts(tampered, claims[1]))
     rec.close()
+    seg_cc.free(); seg.free()
+
+
+@pytest.mark.gpu
+def test_the_segments_of_a_proved_run_join_into_one_root_with_the_receipts_claim(hal, orc):
+    """the segment receipts of `prove(env, elf)` with the trace circuit -- the run the device proved from its own
+    execution -- are lifted and joined into one root whose claim is the composite receipt's end-to-end claim."""
+    import __graft_entry__ as entry
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_session import elf_of
+    from test_rv32im import _guest
+    blob, rec_blob = _blob("trace"), _blob("recursion")
+    gc = hal.load_circuit(blob, entry.code_object_path("trace"))
+    receipt, image_id, cycles = hal.prove_elf(gc, elf_of(_guest(2000), 0x400), [7, 0x01020304], segment_po2=11)
+    seals, claims = [s for _, s in receipt.seals()], receipt.claims()
+    assert len(seals) >= 8
+    seals, claims = seals[-8:], claims[-8:]  # the last eight segments (the last one halts and carries the journal's digest)
+    roots = {}
+    for s in seals:
+        size = r0.verify_seal(blob, s)[2]
+        if size not in roots:
+            cc = hal.code_commit(gc, size)
+            roots[size] = cc.root()
+            cc.free()
+    rec = recursion.Recursor(hal, rec_blob, blob, entry.code_object_path("recursion"), po2=12, segment_roots=roots)
+    root = rec.fold([rec.lift(s, cl) for s, cl in zip(seals, claims)])
+    want = r0.ReceiptClaim.make(claims[0].pre, claims[-1].post, claims[-1].exit_system, claims[-1].exit_user, bytes(claims[-1].output_digest))
+    assert rec.verify(root) and root.claim.digest() == want.digest() and bytes(root.claim.output_digest) == r0.output_digest(receipt.journal)
+    assert orc.circuit(rec_blob).verify(root.seal, code_root=rec.control_root) == (0, "ok")
+    lifted = [rec.lift(seals[0], claims[0]), rec.lift(seals[1], claims[1])]
+    with pytest.raises(r0.R0HipError, match="do not follow one another"):
+        rec.join(lifted[1], lifted[0])
+    rec.close()
+    gc.free()
 
 
 def _run_tree(world, leaf_of, recursor_of):

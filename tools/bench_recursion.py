@@ -64,8 +64,13 @@ def main():
     rec_blob = np.fromfile(entry.circuit_blob_path("recursion"), dtype=np.uint32)
     seg_co = entry.code_object_path(args.circuit)
     seg = hal.load_circuit(seg_blob, seg_co if os.path.exists(seg_co) else None)
-    rec = recursion.Recursor(hal, rec_blob, seg_blob, entry.code_object_path("recursion"), po2=args.recursion_po2)
-    mine = driver.shard_segments(args.segments, world, rank)
+    # one session of args.segments segments: claims that chain (segment k ends in SystemSplit where k + 1 starts, the last one halts
+    # with the journal's output); every segment seal is proved FOR its claim, every rank owns a contiguous run of them
+    journal = r0.serde_encode_str('{"segments":%d}' % args.segments)
+    claims, image_id = r0.session_claims(args.segments, journal)
+    seg_cc = hal.code_commit(seg, args.segment_po2)
+    rec = recursion.Recursor(hal, rec_blob, seg_blob, entry.code_object_path("recursion"), po2=args.recursion_po2, segment_roots={args.segment_po2: seg_cc.root()})
+    mine = driver.shard_contiguous(args.segments, world, rank)
 
     def barrier():
         hal.sync()
@@ -73,20 +78,25 @@ def main():
             dist.barrier()
 
     # warm-up: one of everything (code objects loaded, pools filled)
-    code, data, glob = hal.witgen(seg, args.segment_po2, 999)
-    warm = hal.prove_segment(seg, args.segment_po2, code, data, glob)
-    rec.join(rec.lift(warm), rec.lift(warm))
+    wclaims, _ = r0.session_claims(2, journal, state_seed=b"warm-up")
+    warm = []
+    for k in range(2):
+        code, data, glob = hal.witgen(seg, args.segment_po2, 999 + k, globals_in=wclaims[k].globals())
+        warm.append(hal.prove_segment(seg, args.segment_po2, seg_cc, data, glob))
+        if k == 0:
+            code.free(); data.free()
+    rec.join(rec.lift(warm[0], wclaims[0]), rec.lift(warm[1], wclaims[1]))
 
     barrier()
     t0 = time.perf_counter()
     seals = []
     for s in mine:
-        c2, d2, g2 = hal.witgen(seg, args.segment_po2, 1000 + s)
-        seals.append(hal.prove_segment(seg, args.segment_po2, c2, d2, g2))
+        c2, d2, g2 = hal.witgen(seg, args.segment_po2, 1000 + s, globals_in=claims[s].globals())
+        seals.append(hal.prove_segment(seg, args.segment_po2, seg_cc, d2, g2))
         c2.free(); d2.free()
     barrier()
     t1 = time.perf_counter()
-    nodes = [rec.lift(s) for s in seals]
+    nodes = [rec.lift(seal, claims[s]) for seal, s in zip(seals, mine)]
     node = rec.fold(nodes) if nodes else None
     barrier()
     t2 = time.perf_counter()
@@ -96,18 +106,24 @@ def main():
     barrier()
     t3 = time.perf_counter()
     if rank == 0:
-        verdict = r0.verify_seal(rec_blob, node.seal)
+        # the root: its seal verifies bound to the recursion circuit's control root, names its claim, and that claim is the session's
+        # end-to-end claim (first pre-state = the image id, last post-state, Halted(0), the journal's output digest)
+        end_to_end = r0.ReceiptClaim.make(claims[0].pre, claims[-1].post, claims[-1].exit_system, claims[-1].exit_user, bytes(claims[-1].output_digest))
+        root_ok = rec.verify(node) and node.claim.digest() == end_to_end.digest() and node.claim.pre.digest() == image_id
         if args.root_out:
             np.save(args.root_out, node.seal)
+            np.save(args.root_out + ".control_root.npy", rec.control_root)
+            open(args.root_out + ".claim.bin", "wb").write(bytes(node.claim))
         steps = len(recursion.tree_schedule(world))
         bench.emit_result({
             "metric": "lift+join tree over segment seals (configs[4] in shape; recursion-shaped circuit, see hyperfridge-r0_amd/recursion.py)",
             "n_gpus": world, "segments": args.segments, "segment_po2": args.segment_po2, "recursion_po2": args.recursion_po2,
             "prove_segments_s": round(t1 - t0, 4), "lift_and_local_fold_s": round(t2 - t1, 4), "cross_rank_joins_s": round(t3 - t2, 4),
             "cross_rank_join_steps": steps, "tree_latency_s": round(t3 - t1, 4), "end_to_end_s": round(t3 - t0, 4),
-            "root_verifies": verdict[0] == 0, "root_seal_words": int(node.seal.size), "backend": args.backend if world > 1 else "none",
+            "root_verifies": bool(root_ok), "root_claim_is_the_sessions_end_to_end_claim": bool(node.claim.digest() == end_to_end.digest()),
+            "root_seal_words": int(node.seal.size), "backend": args.backend if world > 1 else "none",
             "data": "synthetic"})
-    code.free(); data.free()
+    code.free(); data.free(); seg_cc.free()
     rec.close(); seg.free()
     hal.close()
     if world > 1:
