@@ -563,9 +563,6 @@ const char* r0h_circuit_load(r0h_ctx* ctx, const uint32_t* blob, size_t n_words,
     delete c;
     return make_error("r0h_circuit_load: the code object has no eval_check_0 (built from another source?)");
   }
-  size_t words = c->n_global + c->n_mix + 4 * (size_t)c->plan.n_pow + 4;
-  e = hipMalloc((void**)&c->d_params, words * 4);
-  if (e != hipSuccess) { hipModuleUnload(c->module); delete c; return make_error("r0h_circuit_load: hipMalloc: %s", hipGetErrorString(e)); }
   ctx_retain(ctx);
   *out = c;
   return nullptr;
@@ -577,7 +574,6 @@ const char* r0h_circuit_free(r0h_circuit* c) {
   r0h_ctx* ctx = c->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (c->d_params) (void)hipFree(c->d_params);
   if (c->module) (void)hipModuleUnload(c->module);
   delete c;
   ctx_release(ctx);
@@ -701,10 +697,15 @@ const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, con
     uint32_t three_n = fpow(enc(3), (uint64_t)1 << po2), w4 = rou_fwd(2), w = ONE;
     for (int k = 0; k < 4; k++) { *p++ = inv(sub(mul(three_n, w), ONE)); w = mul(w, w4); }
   }
-  R0H_TRY(stage_h2d(ctx, c->d_params, params.data(), params.size() * 4));
+  // the parameter block comes from the calling context's pool (stream-ordered reuse), not from the circuit: one loaded circuit
+  // then serves every context of its device at once (r0h_prove_elf's prover lanes share it)
+  r0h_buf* pbuf = nullptr;
+  R0H_TRY(buf_alloc_pooled(ctx, params.size() * 4, &pbuf));
+  struct Free { r0h_buf* b; ~Free() { r0h_buf_free(b); } } pguard{pbuf};
+  R0H_TRY(stage_h2d(ctx, pbuf->ptr, params.data(), params.size() * 4));
   uint32_t* d_check = u32(check);
   const uint32_t *g0 = u32(g[0]), *g1 = u32(g[1]), *g2 = u32(g[2]);
-  const uint32_t *d_glob = c->d_params, *d_mix = d_glob + c->n_global, *d_pow = d_mix + c->n_mix, *d_van = d_pow + 4 * (size_t)c->plan.n_pow;
+  const uint32_t *d_glob = u32(pbuf), *d_mix = d_glob + c->n_global, *d_pow = d_mix + c->n_mix, *d_van = d_pow + 4 * (size_t)c->plan.n_pow;
   double alg = (double)domain * 16;
   for (int k = 0; k < 3; k++) alg += (double)domain * c->group_size[k] * 4;
   KScope ks(ctx, "eval_check", alg);

@@ -43,7 +43,6 @@ struct r0h_circuit {
   r0h::Plan plan;
   hipModule_t module = nullptr;
   std::vector<hipFunction_t> kernels;
-  uint32_t* d_params = nullptr;  // device: [n_global globals][n_mix mix][4*n_pow mixpow][4 inv_van]
 };
 
 namespace r0h {

@@ -170,8 +170,26 @@ const char* buf_alloc_pooled(r0h_ctx* ctx, size_t bytes, r0h_buf** out) {
 }
 
 void ctx_retain(r0h_ctx* ctx) { ctx->refs++; }
+const char* ctx_helper(r0h_ctx* ctx, size_t k, r0h_ctx** out) {
+  while (ctx->helpers.size() <= k) {
+    r0h_ctx* h = nullptr;
+    R0H_TRY(r0h_ctx_create(ctx->device, &h));
+    ctx->helpers.push_back(h);
+  }
+  r0h_ctx* h = ctx->helpers[k];
+  if (memcmp(&h->p2_host, &ctx->p2_host, sizeof(P2Consts)) != 0) {  // r0h_poseidon2_set_consts on the owner since the helper was made
+    h->p2_host = ctx->p2_host;
+    R0H_TRY_HIP(hipSetDevice(h->device));
+    R0H_TRY_HIP(hipStreamSynchronize(h->stream));
+    R0H_TRY_HIP(hipMemcpy(h->p2, &h->p2_host, sizeof(P2Consts), hipMemcpyHostToDevice));
+  }
+  *out = h;
+  return nullptr;
+}
 void ctx_release(r0h_ctx* ctx) {
   if (--ctx->refs > 0) return;
+  for (r0h_ctx* h : ctx->helpers) r0h_ctx_destroy(h);
+  ctx->helpers.clear();
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int d = 0; d < 2; d++) { (void)hipFree(ctx->tw_lo[d]); (void)hipFree(ctx->tw_hi[d]); (void)hipFree(ctx->tw12[d]); }

@@ -11,10 +11,11 @@
 // executor keeps one compact row per cycle plus one per address touched, the device expands them into the DATA group
 // (csrc/trace.hip: 72 bytes per cycle cross PCIe, not the 576 bytes of an expanded row), and the proof is over those columns --
 // contiguity, control flow and memory consistency as include/r0hip.h lists them (what an instruction computes is risc0's rv32im
-// circuit and stays unconstrained).  The guest runs ahead on its own host thread; the calling thread proves segment k while
-// segment k + 1 executes.  With any other circuit the witness is the blob's synthetic column program with the claim
+// circuit and stays unconstrained).  The guest runs ahead on its own host thread; two prover lanes (the caller's context and a
+// helper context of the same device) take the segments as they are cut.  With any other circuit the witness is the blob's synthetic column program with the claim
 // planted: the seal then proves "a satisfying trace of the loaded circuit exists whose public inputs name this claim", not
 // "this program ran".
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -109,6 +110,7 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
   std::deque<std::unique_ptr<Produced>> queue;
   std::vector<std::unique_ptr<Produced>> returned;  // proved segments on their way back: the executor refills their row buffers
   bool producer_done = false, stop = false;
+  size_t queue_depth = 2;  // finished segments that may wait for a prover lane (set once the lanes are known)
   const char* producer_err = nullptr;
   int exit_kind = R0H_VM_LIMIT;
   uint32_t exit_code = 0;
@@ -120,7 +122,7 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
         std::vector<std::unique_ptr<Produced>> back;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return stop || queue.size() < 2; });
+          cv.wait(lk, [&] { return stop || queue.size() < queue_depth; });
           if (stop) break;
           back.swap(returned);
         }
@@ -172,64 +174,128 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
     }
   } join{producer, mu, cv, stop};
 
-  // ---- prove every segment for its claim, as it arrives
+  // ---- prove every segment for its claim, as it arrives.  Two prover lanes by default (R0H_SESSION_LANES = 1..4): lane 0 is the caller's
+  // context on the calling thread, the others are helper contexts of the same device (kept with `ctx` between calls) on threads of
+  // their own -- while one lane waits for a transcript read-back the other keeps the device busy.  The circuit and the CODE
+  // commitments are shared; a segment's seal lands at its index whichever lane made it.
+  uint32_t n_lanes = 2;
+  if (const char* v = getenv("R0H_SESSION_LANES")) n_lanes = (uint32_t)strtoul(v, nullptr, 10);
+  n_lanes = n_lanes < 1 ? 1 : n_lanes > 4 ? 4 : n_lanes;
+  std::vector<r0h_ctx*> lane_ctx(n_lanes, ctx);
+  for (uint32_t k = 1; k < n_lanes; k++) R0H_TRY(ctx_helper(ctx, k - 1, &lane_ctx[k]));
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    queue_depth = n_lanes + 1;
+    cv.notify_all();
+  }
+  struct Proved { std::vector<uint32_t> seal; r0h_receipt_claim claim; bool done = false; };
+  std::vector<Proved> proved;
+  std::mutex commit_mu, result_mu;
+  CodeCommits commits;
+  r0h_system_state first_pre;
+  memset(&first_pre, 0, sizeof first_pre);
+  size_t next_index = 0;
+  const char* lane_err = nullptr;
+
+  auto lane_body = [&](r0h_ctx* lctx) -> const char* {
+    std::vector<uint32_t> seal((size_t)1 << 20), global(c->n_global);
+    for (;;) {
+      std::unique_ptr<Produced> seg;
+      size_t i;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !queue.empty() || producer_done || stop; });
+        if (stop) return nullptr;
+        if (queue.empty()) {
+          if (producer_err) { const char* e = producer_err; producer_err = nullptr; return e; }
+          return nullptr;
+        }
+        seg = std::move(queue.front());
+        queue.pop_front();
+        i = next_index++;
+        if (i == 0) first_pre = seg->info.pre;
+        cv.notify_all();
+      }
+      const uint64_t rows_needed = trace_mode ? seg->rows.size() + seg->bounds.size() : seg->info.user_cycles + seg->info.paging_cycles;
+      const uint32_t po2 = trace_size(rows_needed);
+      uint8_t cd[32];
+      claim_digest(seg->claim, cd);
+      std::fill(global.begin(), global.end(), 0u);
+      claim_globals(cd, global.data());
+      const size_t n = (size_t)1 << po2;
+      r0h_buf* data = nullptr;
+      R0H_TRY(buf_alloc_pooled(lctx, (size_t)c->group_size[R0H_GROUP_DATA] * n * 4, &data));
+      struct Free { r0h_buf* b; ~Free() { r0h_buf_free(b); } } data_guard{data};
+      r0h_code_commit* cc = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(commit_mu);
+        R0H_TRY(commits.get(lctx, c, po2, data, &cc));
+      }
+      const Clock::time_point t0 = Clock::now();
+      size_t words = 0;
+      if (trace_mode) {
+        {
+          std::lock_guard<std::mutex> lk(result_mu);
+          pins.pin(seg->rows.data(), seg->rows.capacity() * sizeof(r0h_preflight_row));
+        }
+        R0H_TRY(r0h_trace_witgen(lctx, seg->rows.data(), seg->rows.size(), seg->bounds.data(), seg->bounds.size(), po2, data, global.data()));
+      } else {
+        // synthetic column program with the claim planted (CODE is regenerated into a scratch block: only DATA is used)
+        r0h_buf* code = nullptr;
+        R0H_TRY(buf_alloc_pooled(lctx, (size_t)c->group_size[R0H_GROUP_CODE] * n * 4, &code));
+        const char* err = r0h_witgen_public(lctx, c, po2, 0x5E55 + i, global.data(), code, data);
+        r0h_buf_free(code);
+        if (err) return err;
+      }
+      const Clock::time_point t1 = Clock::now();
+      R0H_TRY(r0h_prove_segment_committed(lctx, c, po2, cc, data, global.data(), seal.data(), seal.size(), &words));
+      const Clock::time_point t2 = Clock::now();
+      {
+        std::lock_guard<std::mutex> lk(result_mu);
+        stats.witgen_ms += 1e3 * seconds(t0, t1);
+        stats.prove_ms += 1e3 * seconds(t1, t2);
+        stats.segments++;
+        if (proved.size() <= i) proved.resize(i + 1);
+        proved[i].seal.assign(seal.begin(), seal.begin() + words);
+        proved[i].claim = seg->claim;
+        proved[i].done = true;
+      }
+      if (trace_mode) {  // the row buffers go back to the executor
+        std::lock_guard<std::mutex> lk(mu);
+        returned.push_back(std::move(seg));
+      }
+    }
+  };
+  auto guarded = [&](r0h_ctx* lctx) {
+    const char* err = nullptr;
+    try {
+      err = lane_body(lctx);
+    } catch (const std::exception& ex) {
+      err = make_error("exception in a prover lane: %s", ex.what());
+    } catch (...) {
+      err = make_error("unknown exception in a prover lane");
+    }
+    if (err) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!lane_err) lane_err = err;
+      else r0h_free_error(err);
+      stop = true;  // the other lanes and the executor leave at their next look
+      cv.notify_all();
+    }
+  };
+  {
+    std::vector<std::thread> workers;
+    for (uint32_t k = 1; k < n_lanes; k++) workers.emplace_back(guarded, lane_ctx[k]);
+    guarded(lane_ctx[0]);
+    for (std::thread& t : workers) t.join();
+  }
+  if (lane_err) return lane_err;
   r0h_receipt* rc = nullptr;
   R0H_TRY(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, nullptr, 0, &rc));
   std::unique_ptr<r0h_receipt, const char* (*)(r0h_receipt*)> rc_guard(rc, r0h_receipt_free);
-  CodeCommits commits;
-  std::vector<uint32_t> seal((size_t)1 << 20), global(c->n_global);
-  r0h_system_state first_pre;
-  memset(&first_pre, 0, sizeof first_pre);
-  for (size_t i = 0;; i++) {
-    std::unique_ptr<Produced> seg;
-    {
-      std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return !queue.empty() || producer_done; });
-      if (queue.empty()) {
-        if (producer_err) { const char* e = producer_err; producer_err = nullptr; return e; }
-        break;
-      }
-      seg = std::move(queue.front());
-      queue.pop_front();
-      cv.notify_all();
-    }
-    if (i == 0) first_pre = seg->info.pre;
-    const uint64_t rows_needed = trace_mode ? seg->rows.size() + seg->bounds.size() : seg->info.user_cycles + seg->info.paging_cycles;
-    const uint32_t po2 = trace_size(rows_needed);
-    uint8_t cd[32];
-    claim_digest(seg->claim, cd);
-    std::fill(global.begin(), global.end(), 0u);
-    claim_globals(cd, global.data());
-    const size_t n = (size_t)1 << po2;
-    r0h_buf* data = nullptr;
-    R0H_TRY(buf_alloc_pooled(ctx, (size_t)c->group_size[R0H_GROUP_DATA] * n * 4, &data));
-    struct Free { r0h_buf* b; ~Free() { r0h_buf_free(b); } } data_guard{data};
-    r0h_code_commit* cc = nullptr;
-    R0H_TRY(commits.get(ctx, c, po2, data, &cc));
-    const Clock::time_point t0 = Clock::now();
-    size_t words = 0;
-    if (trace_mode) {
-      pins.pin(seg->rows.data(), seg->rows.capacity() * sizeof(r0h_preflight_row));
-      R0H_TRY(r0h_trace_witgen(ctx, seg->rows.data(), seg->rows.size(), seg->bounds.data(), seg->bounds.size(), po2, data, global.data()));
-    } else {
-      // synthetic column program with the claim planted (CODE is regenerated into a scratch block: only DATA is used)
-      r0h_buf* code = nullptr;
-      R0H_TRY(buf_alloc_pooled(ctx, (size_t)c->group_size[R0H_GROUP_CODE] * n * 4, &code));
-      const char* err = r0h_witgen_public(ctx, c, po2, 0x5E55 + i, global.data(), code, data);
-      r0h_buf_free(code);
-      if (err) return err;
-    }
-    const Clock::time_point t1 = Clock::now();
-    R0H_TRY(r0h_prove_segment_committed(ctx, c, po2, cc, data, global.data(), seal.data(), seal.size(), &words));
-    const Clock::time_point t2 = Clock::now();
-    stats.witgen_ms += 1e3 * seconds(t0, t1);
-    stats.prove_ms += 1e3 * seconds(t1, t2);
-    stats.segments++;
-    R0H_TRY(r0h_receipt_add_segment_claim(rc, seal.data(), words, (uint32_t)i, &seg->claim, nullptr));
-    if (trace_mode) {  // the row buffers go back to the executor
-      std::lock_guard<std::mutex> lk(mu);
-      returned.push_back(std::move(seg));
-    }
+  for (size_t i = 0; i < proved.size(); i++) {
+    R0H_REQUIRE(proved[i].done, "r0h_prove_elf: segment %zu was never proved", i);
+    R0H_TRY(r0h_receipt_add_segment_claim(rc, proved[i].seal.data(), proved[i].seal.size(), (uint32_t)i, &proved[i].claim, nullptr));
   }
   producer.join();  // finished: the machine is this thread's again
   R0H_REQUIRE(exit_kind != R0H_VM_LIMIT, "r0h_prove_elf: the guest did not halt within %llu cycles (session limit)", (unsigned long long)max_cycles);

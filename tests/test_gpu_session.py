@@ -182,6 +182,15 @@ def test_prove_elf_with_the_trace_circuit_proves_the_run_it_executed(hal, orc):
     rc2 = r0.Receipt.new(receipt.journal, [seal] + [s for _, s in seals[1:]], [forged] + claims[1:])
     assert rc2.verify(blob, roots, forged.pre.digest())[:3] == (5, "a seal's public inputs do not name its claim", 0)
     dev.free(); cc.free()
+    # the number of prover lanes (contexts of the device that take segments as the executor cuts them) changes who proves what,
+    # not what is proved: one lane and three lanes give the receipt of the default two, seal for seal
+    for lanes in ("1", "3"):
+        os.environ["R0H_SESSION_LANES"] = lanes
+        try:
+            again, image_again, _ = hal.prove_elf(gc, elf, stream, segment_po2=po2)
+        finally:
+            del os.environ["R0H_SESSION_LANES"]
+        assert image_again == image_id and again.to_json() == receipt.to_json(), lanes
     # a guest that fails or never halts is an error, not a receipt
     with pytest.raises(r0.R0HipError, match="did not halt"):
         hal.prove_elf(gc, elf, stream, segment_po2=po2, max_cycles=100)

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int j = 0; j < 4; j++) {
           int64_t T = (int64_t)P << 25;
 #pragma unroll
-          for (int s = 0; s < 7; s++) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(T) : "v"(acc[s][j]), "v"(c_w[s]) : "vcc");
+          for (int s = 0; s < 7; s++) T += (int64_t)acc[s][j] * (int64_t)c_w[s];  // v_mad_i64_i32 (plain C: the compiler then pads the MFMA -> VALU read hazard itself)
           const uint32_t x = reduce64((uint64_t)T);
           if (round < NR) *(uint32_t*)(O + (16 * t + 4 * (lane >> 4) + j) * O_STRIDE + 4 * round) = x;
         }
@@ -183,6 +183,14 @@ int main() {
     if (bad) {
       for (size_t k = 0, shown = 0; k < a.size() && shown < 8; k++)
         if (a[k] != b[k]) { printf("  row %zu round %zu: valu %u mfma %u\n", k / NR, k % NR, a[k], b[k]); shown++; }
+      size_t by_lane[64] = {0}, by_round[NR] = {0}, by_wave[4] = {0};
+      for (size_t k = 0; k < a.size(); k++)
+        if (a[k] != b[k]) { by_lane[(k / NR) & 63]++; by_round[k % NR]++; by_wave[((k / NR) >> 6) & 3]++; }
+      printf("  mismatches by lane:");
+      for (int l = 0; l < 64; l++) printf(" %zu", by_lane[l]);
+      printf("\n  by round:");
+      for (int r = 0; r < NR; r++) printf(" %zu", by_round[r]);
+      printf("\n  by wave of the block: %zu %zu %zu %zu\n", by_wave[0], by_wave[1], by_wave[2], by_wave[3]);
       return 1;
     }
   }
