@@ -555,11 +555,11 @@ def cpu_baseline(blob, cpu_po2, po2):
     candidates = sorted({avail, min(avail, quota or avail), min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True)
     calib = {}
     if len(candidates) > 1:
-        ccode, cdata, cglob = oc.witgen(14, seed=1)
+        ccode, cdata, cglob = oc.witgen(12, seed=1)
         for t in candidates:
             orc.L.orc_set_threads(t)
             t0 = time.perf_counter()
-            oc.prove(14, ccode, cdata, cglob)
+            oc.prove(12, ccode, cdata, cglob)
             calib[t] = round(time.perf_counter() - t0, 3)
         cores = min(calib, key=calib.get)
     else:
@@ -575,7 +575,7 @@ def cpu_baseline(blob, cpu_po2, po2):
     dt, words = timed(cpu_po2)
     scale = 1 << (po2 - cpu_po2)
     out = {"value": round(1.0 / (dt * scale), 6), "unit": "segments/s", "cores": cores, "kind": "port",
-           "cores_in_affinity_mask": avail, "cgroup_cpu_quota": quota, "thread_calibration_s_at_po2_14": calib or None,
+           "cores_in_affinity_mask": avail, "cgroup_cpu_quota": quota, "thread_calibration_s_at_po2_12": calib or None,
            "sample": "oracle/liborc.so (C, OpenMP) proved one 2^%d-row segment of the same circuit in %.2f s on %d threads (%d cores in the affinity "
                      "mask, cgroup quota %s; the thread count is the fastest of a calibration over %s)%s; seal %d words.  The risc0 CPU prover cannot "
                      "be built here (Rust)." % (cpu_po2, dt, cores, avail, quota, sorted(calib) or [cores],

@@ -165,7 +165,7 @@ const char* bit_reverse_ext(r0h_ctx* ctx, r0h_buf* io, uint32_t count, uint32_t 
 const char* ntt_init_device();
 // batched synthetic division (DEEP step): job j divides polynomial poly_idx[j] of `polys` by (x - points[4j..]); one read-back
 const char* poly_divide_batch(r0h_ctx* ctx, r0h_buf* polys, uint32_t n, const uint32_t* poly_idx, const uint32_t* points, uint32_t n_jobs, uint32_t* remainders_host);
-// rv32im.hip: the preflight rows of segment i are moved out of the machine (the session proves them while the guest runs on)
+// rv32im.cpp: the preflight rows of segment i are moved out of the machine (the session proves them while the guest runs on)
 void vm_take_trace(r0h_vm* vm, size_t i, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds);
 void vm_recycle_trace(r0h_vm* vm, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds);
 // the k-th helper context of `ctx` (same device, same Poseidon2 table), created on first use and kept until ctx goes

@@ -8,7 +8,7 @@
 //     (host/src/main.rs:251-252, verifier/src/main.rs:118-119): {"inner": ..., "journal": {"bytes": [...]}}.
 // What the reference's fixtures pin: the envelope with "inner":"Fake" and the journal framing.  The composite layout
 // (segments with seal / index / hashfn / verifier_parameters / claim, assumption_receipts, metadata) follows risc0-zkvm 3.x as
-// recalled ("parity unpinned"); the digests inside it are computed in claim.hip.
+// recalled ("parity unpinned"); the digests inside it are computed in claim.cpp.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,4 +1,4 @@
-// Receipt / claim types shared by receipt.hip (JSON reader and writer) and claim.hip (digests, receipt verification).
+// Receipt / claim types shared by receipt.cpp (JSON reader and writer) and claim.cpp (digests, receipt verification).
 #pragma once
 #include <stdint.h>
 

@@ -14,7 +14,7 @@
 //     touched / dirtied (page_in_cycles / page_out_cycles) and, with boundary_rows, one row per distinct register or memory word
 //     touched (what the trace circuit spends on each address's first and last value); risc0's rv32im-v2 charges differ and are
 //     not reproducible from the reference;
-//   * the state digest is risc0-binfmt's SystemState{pc, merkle_root} (csrc/claim.hip) with merkle_root = a SHA-256 binary Merkle
+//   * the state digest is risc0-binfmt's SystemState{pc, merkle_root} (csrc/claim.cpp) with merkle_root = a SHA-256 binary Merkle
 //     tree over the 1 KiB pages of the 32-bit address space, all-zero subtrees folded (risc0's image id is also a page Merkle root;
 //     its exact tree shape and tags are not pinned here).
 // No guest ELF exists in the reference (only sources: methods/guest/src/main.rs; the ELF is built by `risc0_build::embed_methods()`,
@@ -661,7 +661,7 @@ const char* r0h_vm_run(r0h_vm* vm, const r0h_vm_limits* limits, int* exit_kind, 
 
 }  // extern "C"
 namespace r0h {
-// the rows of segment i change hands (session.hip hands them to the prover while the guest runs on)
+// the rows of segment i change hands (session.cpp hands them to the prover while the guest runs on)
 void vm_take_trace(r0h_vm* vm, size_t i, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds) {
   rows.swap(vm->segments[i].rows);
   bounds.swap(vm->segments[i].bounds);
@@ -755,7 +755,7 @@ const char* r0h_vm_journal(const r0h_vm* vm, const uint8_t** bytes, size_t* n) {
   *n = vm->journal.size();
   return nullptr;
 }
-// the receipt claim of segment i (csrc/claim.hip): pre/post system states and exit code from the run, the output digest on the last one
+// the receipt claim of segment i (csrc/claim.cpp): pre/post system states and exit code from the run, the output digest on the last one
 const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* out) {
   R0H_REQUIRE(vm && out, "r0h_vm_segment_claim: NULL argument");
   R0H_REQUIRE(i < vm->segments.size(), "r0h_vm_segment_claim: segment %zu of %zu", i, vm->segments.size());

@@ -2,10 +2,10 @@
 // into segments, prove every segment, assemble the composite receipt.  risc0-zkvm 3.0.5 `LocalProver::prove` = executor
 // (`ExecutorImpl::run` -> Session{segments}) + `prove_session` (one `prove_segment` per segment) + CompositeReceipt.
 //
-// What each stage is here: the executor is csrc/rv32im.hip (RV32IM by the specification; this library's ecall ABI and cycle model,
+// What each stage is here: the executor is csrc/rv32im.cpp (RV32IM by the specification; this library's ecall ABI and cycle model,
 // see there); `prove_segment` is the device-resident sequencer (csrc/prover.hip) at the trace size the segment needs; the claim of
 // every segment (system states from the run, exit code, the journal's output digest on the last one) is bound to its seal through
-// the public inputs (csrc/claim.hip).
+// the public inputs (csrc/claim.cpp).
 //
 // With the trace circuit (circuits/trace.r0c, ProtocolInfo "R0HIP_TRACE:v2__") the seal of a segment attests THAT segment: the
 // executor keeps one compact row per cycle plus one per address touched, the device expands them into the DATA group

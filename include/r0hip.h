@@ -243,7 +243,7 @@ const char* r0h_journal_commitment_span(const uint8_t* bytes, size_t n, size_t* 
 #define R0H_RECEIPT_COMPOSITE 1
 typedef struct r0h_receipt r0h_receipt;
 /* risc0-binfmt `SystemState` and risc0-zkvm `ReceiptClaim`, flattened (field names, tags and digest layout are recalled from the
- * public risc0 sources: unpinned, see csrc/claim.hip).  exit_system / exit_user: Halted(u) = (0, u), Paused(u) = (1, u),
+ * public risc0 sources: unpinned, see csrc/claim.cpp).  exit_system / exit_user: Halted(u) = (0, u), Paused(u) = (1, u),
  * SystemSplit = (2, 0), SessionLimit = (2, 2).  input_digest / output_digest: Digest::ZERO stands for None. */
 typedef struct { uint32_t pc; uint8_t merkle_root[32]; } r0h_system_state;
 typedef struct {
@@ -355,7 +355,7 @@ const char* r0h_ebics_env_inputs(const r0h_ebics* e, const char* pub_bank_pem, s
 const char* r0h_aes128_block(const uint8_t key[16], const uint8_t in[16], int decrypt, uint8_t out[16]);
 const char* r0h_zlib_inflate(const uint8_t* in, size_t n, uint8_t** out, size_t* out_len);
 
-/* ---- RV32IM executor, segmenter and preflight trace (csrc/rv32im.hip): the part of `prover.prove(env, elf)`
+/* ---- RV32IM executor, segmenter and preflight trace (csrc/rv32im.cpp): the part of `prover.prove(env, elf)`
  * that runs before prove_segment.  Pure host code.  Instruction semantics are the RISC-V specification's; the ecall ABI, the cycle
  * model and the page Merkle root are this library's own documented choices (risc0's are recalled in outline only: see the source).
  * ecall (a7): 0 HALT(a0) | 1 READ_WORDS(a0 = dst, a1 = n) | 2 COMMIT(a0 = src, a1 = n bytes) | 3 CYCLES -> a0 | 4 PAUSE(a0).

@@ -1,4 +1,4 @@
-"""Receipt claims and `receipt.verify(image_id)` (csrc/claim.hip; verifier/src/main.rs:118-126).
+"""Receipt claims and `receipt.verify(image_id)` (csrc/claim.cpp; verifier/src/main.rs:118-126).
 
 Pinned: SHA-256 by the FIPS 180-4 example vectors and hashlib.  Recalled from the public risc0 sources, NOT pinned by anything
 the reference holds (its receipts are `"inner":"Fake"`): the tagged-struct layout, the tags, the field names of the composite

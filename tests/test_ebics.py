@@ -1,4 +1,4 @@
-"""The native EBICS pre-processor (csrc/ebics.hip) against the reference's own files -- the one row of
+"""The native EBICS pre-processor (csrc/ebics.cpp) against the reference's own files -- the one row of
 the scope table that reference-held fixtures pin.  tests/golden/camt53/ holds, copied unchanged: the raw response
 (data/response_template-generated.xml, byte-identical to data/test/test.xml-generated.xml), the three PUBLIC keys (data/pub_*.pem)
 and the six pre-processed files data/test/test.xml-* that data/checkResponse.sh made from that response with xmllint / openssl /

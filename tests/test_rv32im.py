@@ -1,4 +1,4 @@
-"""RV32IM executor, segmenter and preflight trace (csrc/rv32im.hip).  The reference ships no guest ELF
+"""RV32IM executor, segmenter and preflight trace (csrc/rv32im.cpp).  The reference ships no guest ELF
 (only sources: methods/guest/src/main.rs), so programs are hand-encoded instruction words.  Instruction semantics are checked
 against an independent interpreter written here in Python from the RISC-V specification; the ecall ABI, the cycle model and the
 page Merkle root are this library's own (documented in the source) and are checked for self-consistency: segments chain, the

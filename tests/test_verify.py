@@ -1,4 +1,4 @@
-"""The product's host-side verifier (r0h_verify_seal, hyperfridge-r0_amd/csrc/verify.hip) -- the `receipt.verify(image_id)`
+"""The product's host-side verifier (r0h_verify_seal, hyperfridge-r0_amd/csrc/verify.cpp) -- the `receipt.verify(image_id)`
 half of the boundary (verifier/src/main.rs:124-126).  It needs no GPU, so these run in the CPU suite: it must accept the
 frozen golden seal and seals made by the oracle prover, and agree with the oracle's independent verifier -- verdict AND
 reason -- on every mutation (word flips in each region of the seal, truncation, extension, a different circuit)."""

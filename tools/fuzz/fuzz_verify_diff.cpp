@@ -1,4 +1,4 @@
-// Differential fuzzing of the two verifiers: the product's (csrc/verify.hip, what `receipt.verify` rests on) and the CPU oracle's
+// Differential fuzzing of the two verifiers: the product's (csrc/verify.cpp, what `receipt.verify` rests on) and the CPU oracle's
 // (oracle/orc_prove.c) must return the same verdict for every edit of a genuine seal -- accept together, and name the same first
 // failed check when they reject.  Built and run by tools/fuzz/run_diff.sh (CPU only, libFuzzer + ASan).
 #include <stdint.h>

@@ -1,6 +1,6 @@
 #!/bin/bash
-# libFuzzer + AddressSanitizer + UndefinedBehaviorSanitizer over the host-only parsers (tools/fuzz/fuzz_host.cpp).  CPU only: the .hip sources are compiled
-# for the host alone (--cuda-host-only), no device code is built or run.
+# libFuzzer + AddressSanitizer + UndefinedBehaviorSanitizer over the host-only parsers (tools/fuzz/fuzz_host.cpp).  CPU only: the host-only translation units (.cpp) and the host
+# side of circuit.hip are compiled with the sanitizers; no device code is run.
 #   tools/fuzz/run.sh [seconds, default 120] [work dir, default /tmp/r0h_fuzz] [parallel jobs, default 1]
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
@@ -9,11 +9,11 @@ CLANG=/opt/rocm/lib/llvm/bin/clang++
 mkdir -p "$WORK/obj" "$WORK/corpus"
 FLAGS="-O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined,fuzzer-no-link -fno-sanitize-recover=undefined"
 for f in ebics rv32im receipt claim verify ctx circuit; do
-  src=$ROOT/hyperfridge-r0_amd/csrc/$f.hip
+  src=$ROOT/hyperfridge-r0_amd/csrc/$f.cpp; [ -f "$src" ] || src=$ROOT/hyperfridge-r0_amd/csrc/$f.hip  # host-only units are .cpp, circuit is .hip
   if [ ! -f "$WORK/obj/$f.o" ] || [ "$src" -nt "$WORK/obj/$f.o" ]; then
     # circuit.hip (the blob parser and the code generator live there) carries kernels: its host stubs need the code object, so it
     # is compiled whole with the sanitizer on the host side only; the rest is host code
-    if [ $f = circuit ]; then MODE="--offload-arch=gfx950 -fno-gpu-sanitize"; else MODE="--cuda-host-only"; fi
+    if [ $f = circuit ]; then MODE="--offload-arch=gfx950 -fno-gpu-sanitize"; else MODE="-D__HIP_PLATFORM_AMD__ -I/opt/rocm/include"; fi
     # field arithmetic (verifier, transcript, claims) gets edge counters only: libFuzzer's compare-tracing hooks slow it down a
     # hundredfold and guide nothing there; the parsers keep them (magic numbers, lengths)
     case $f in verify|ctx|claim) F=${FLAGS/fuzzer-no-link/} ; F="${F/-fsanitize=address,undefined,/-fsanitize=address,undefined} -fsanitize-coverage=inline-8bit-counters,pc-table" ;; *) F=$FLAGS ;; esac

@@ -9,9 +9,9 @@ mkdir -p "$WORK/obj" "$WORK/corpus"
 # coverage counters only: the compare-tracing hooks of -fsanitize=fuzzer-no-link slow field arithmetic down a hundredfold
 FLAGS="-O2 -g -fno-omit-frame-pointer -fsanitize=address -fsanitize-coverage=inline-8bit-counters,pc-table"
 for f in verify ctx circuit; do
-  src=$ROOT/hyperfridge-r0_amd/csrc/$f.hip
+  src=$ROOT/hyperfridge-r0_amd/csrc/$f.cpp; [ -f "$src" ] || src=$ROOT/hyperfridge-r0_amd/csrc/$f.hip  # host-only units are .cpp, circuit is .hip
   if [ ! -f "$WORK/obj/$f.o" ] || [ "$src" -nt "$WORK/obj/$f.o" ]; then
-    if [ $f = circuit ]; then MODE="--offload-arch=gfx950 -fno-gpu-sanitize"; else MODE="--cuda-host-only"; fi
+    if [ $f = circuit ]; then MODE="--offload-arch=gfx950 -fno-gpu-sanitize"; else MODE="-D__HIP_PLATFORM_AMD__ -I/opt/rocm/include"; fi
     /opt/rocm/bin/hipcc $MODE $FLAGS -w -c "$src" -o "$WORK/obj/$f.o"
   fi
 done

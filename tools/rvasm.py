@@ -2,7 +2,7 @@
 """A small RV32IM assembler (labels, forward references, lui+addi address loads) for the hand-written guests of this repository.
 The reference's guest is Rust compiled by the risc0 toolchain (methods/build.rs:2), which is absent here; guests are therefore
 written as instruction streams.  Encodings follow the RISC-V unprivileged specification (chapter 2, M extension); the executor
-that runs them (csrc/rv32im.hip) is checked against an independent interpreter in tests/test_rv32im.py."""
+that runs them (csrc/rv32im.cpp) is checked against an independent interpreter in tests/test_rv32im.py."""
 import struct
 
 ZERO, RA, SP, GP, TP, T0, T1, T2, S0, S1, A0, A1, A2, A3, A4, A5, A6, A7 = range(18)
