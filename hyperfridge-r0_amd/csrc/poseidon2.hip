@@ -141,8 +141,10 @@ const char* r0h_hash_fold(r0h_ctx* ctx, r0h_buf* nodes, uint32_t output_size) {
 
 // Hal::hash_fold(io, input_size, output_size): the trait names both sizes (the fold halves a level, so input_size == 2 * output_size)
 const char* r0h_hash_fold_io(r0h_ctx* ctx, r0h_buf* io, uint32_t input_size, uint32_t output_size) {
+  R0H_GUARD_BEGIN
   R0H_REQUIRE(input_size == 2 * (size_t)output_size, "r0h_hash_fold_io: a fold takes 2 * output_size = %zu digests in, not %u", 2 * (size_t)output_size, input_size);
   return r0h_hash_fold(ctx, io, output_size);
+  R0H_GUARD_END
 }
 
 const char* r0h_merkle_build(r0h_ctx* ctx, r0h_buf* nodes, const r0h_buf* matrix, uint32_t rows, uint32_t cols) {

@@ -675,10 +675,12 @@ void vm_recycle_trace(r0h_vm* vm, std::vector<r0h_preflight_row>& rows, std::vec
 extern "C" {
 
 const char* r0h_vm_release_trace(r0h_vm* vm, size_t i) {
+  R0H_GUARD_BEGIN
   R0H_REQUIRE(vm && i < vm->segments.size(), "r0h_vm_release_trace: no such segment");
   std::vector<r0h_preflight_row>().swap(vm->segments[i].rows);
   std::vector<r0h_preflight_bound>().swap(vm->segments[i].bounds);
   return nullptr;
+  R0H_GUARD_END
 }
 
 size_t r0h_vm_n_segments(const r0h_vm* vm) { return vm ? vm->segments.size() : 0; }
