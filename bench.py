@@ -379,8 +379,8 @@ def main():
     phases = lanes[0]["hal"].last_profile()
     lanes[0]["hal"].kernel_timing(False)
 
-    # `prove(env, elf)` end to end, once, beside the headline (rank 0 of a single-GPU run): the guest-shaped program of
-    # tools/guest_rsa.py on the reference's EBICS fixture, executed on a host thread, its compact preflight rows expanded on the device,
+    # `prove(env, elf)` end to end, once, beside the headline (rank 0 of a single-GPU run): the hand-assembled guest of
+    # tools/guest_camt53.py on the reference's EBICS fixture, executed on a host thread, its compact preflight rows expanded on the device,
     # every segment proved with circuits/trace.r0c -- executor, witness generation and proofs all inside the timed region
     session = None
     if env.rank == 0 and env.world == 1 and not args.segments and not args.no_session and not args.profile_mode and po2 == 20:
@@ -413,7 +413,8 @@ def main():
             # (tools/p2_issue_floor.py).  frac <= 1 by construction; the rate-table estimate beside it prices the same
             # stream at the rates isolated streams of each instruction sustain.
             rows = 4 << po2
-            perms = rows * sum(-(-g // 16) for g in circuit.group_size) + rows  # three groups + CHECK (16 columns)
+            hashed = [g for k, g in enumerate(circuit.group_size) if not (code_commit is not None and k == 1)]  # CODE is hashed once, outside
+            perms = rows * sum(-(-g // 16) for g in hashed) + rows  # the groups hashed per segment + CHECK (16 columns)
             d = 1 << po2
             while d > 256:  # FRI rounds: 4d/16 rows of 64 columns
                 perms += (4 * d // 16) * 4
@@ -471,13 +472,15 @@ def main():
 
 
 def prove_elf_session(hal, entry):
-    """r0h_prove_elf over the guest-shaped RSA / SHA-256 program (tools/guest_rsa.py) on the reference's fixture with the trace
-    circuit at po2 = 20, timed as one call (the second of two: the first pays for the code object, the CODE commitment, the pools)."""
+    """r0h_prove_elf over the hand-assembled hyperfridge pipeline (tools/guest_camt53.py: RSA x3, SHA-256, AES-128-CBC, inflate, unzip,
+    camt.053 fields) on the reference's fixture with the trace circuit at po2 = 20, timed as one call (the second of two: the first
+    pays for the code object, the CODE commitment, the pools).  Its journal is compared with the reference's committed receipt's."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import numpy as np
-    import guest_rsa
+    import guest_camt53
     import hyperfridge_r0_amd as r0
-    image, stream, what = guest_rsa.elf_and_input()
+    image, stream, what = guest_camt53.elf_and_input(form=1)
+    want_journal = bytes(json.load(open(os.path.join(ROOT, "tests", "golden", "reference_receipt_6bb95807_latest.json")))["journal"]["bytes"])
     blob = np.fromfile(entry.circuit_blob_path("trace"), dtype=np.uint32)
     gc = hal.load_circuit(blob, entry.code_object_path("trace"))
     try:
@@ -501,7 +504,8 @@ def prove_elf_session(hal, entry):
                 "witgen_ms_per_segment": round(st["witgen_ms"] / n, 2), "prove_ms_per_segment": round(st["prove_ms"] / n, 2),
                 "circuit": "trace.r0c W=(%d accum, %d code, %d data): contiguity, control flow and memory consistency of the run (not instruction semantics)" % tuple(gc.group_size),
                 "receipt_verified_against_image_id": verdict[:2] == (0, "ok"),
-                "journal": r0.journal_commitment(receipt.journal).decode()[:120]}
+                "journal_is_the_reference_receipt_fixtures": receipt.journal == want_journal,
+                "journal": r0.journal_commitment(receipt.journal).decode()[:80] + " ..."}
     finally:
         gc.free()
 

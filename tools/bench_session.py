@@ -3,11 +3,12 @@
 preflight rows (r0h_trace_witgen, upload included) and the proof of every segment are all inside the timed region -- one JSON line.
 
 The guest is hand-assembled (the reference ships no ELF): by default the memory-traffic loop of tests/test_rv32im.py (_guest),
-sized by --cycles; with --guest rsa the guest-shaped program of tools/guest_rsa.py (SHA-256 + RSA-2048 signature check on the
-reference's own inputs), when that file exists.  What is reported: segments per second of the whole pipeline, the executor's rate,
+sized by --cycles; with --guest rsa the program of tools/guest_rsa.py (SHA-256 + three RSA-2048 public-key operations on the reference's
+own inputs); with --guest camt53 the whole pipeline of tools/guest_camt53.py (RSA, SHA-256, AES-128-CBC, inflate, unzip, camt.053 fields),
+whose journal is the reference's committed receipt's.  What is reported: segments per second of the whole pipeline, the executor's rate,
 host milliseconds per segment (executor thread; it overlaps the device), device-side milliseconds per segment for witness
 generation and proof.  The receipt is verified against the image id before the line is printed.
-usage: python tools/bench_session.py [--po2 20] [--cycles 8000000] [--guest loop|rsa] [--repeat 2]"""
+usage: python tools/bench_session.py [--po2 20] [--cycles 8000000] [--guest loop|rsa|camt53] [--repeat 2]"""
 import argparse
 import json
 import os
@@ -44,10 +45,10 @@ def main():
     import __graft_entry__ as entry
     entry.ensure_built()
     import hyperfridge_r0_amd as r0
-    if args.guest == "rsa":
+    if args.guest in ("rsa", "camt53"):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import guest_rsa
-        elf, stream, what = guest_rsa.elf_and_input()
+        mod = __import__("guest_" + args.guest)
+        elf, stream, what = mod.elf_and_input()
     else:
         from test_rv32im import ADDI, A0, A1, A7, B, ECALL, I, LI, R, S, S0, T0, T1, T2, flat
         buf, scratch, n_loop = 0x10000, 0x20000, max(1, (args.cycles - 40) // 7)
@@ -90,7 +91,7 @@ def main():
             "device": {"witgen_ms_per_segment": round(st["witgen_ms"] / n, 3), "prove_ms_per_segment": round(st["prove_ms"] / n, 3),
                        "note": "witgen = upload of 72 B/cycle + 16 B/boundary row and the expansion kernel; prove = r0h_prove_segment_committed (CODE committed once per trace size)"},
             "circuit": "trace.r0c W=(%d accum, %d code, %d data)" % tuple(gc.group_size), "seal_words": int(seals[0][1].size),
-            "receipt_verified": True, "data": "synthetic guest; no guest ELF exists in the reference (needs the Rust toolchain)"}
+            "receipt_verified": True, "journal_commitment": r0.journal_commitment(receipt.journal).decode("utf-8", "replace")[:160] if receipt.journal[:1] != b"\x07" else None, "data": "synthetic guest; no guest ELF exists in the reference (needs the Rust toolchain)"}
     print(json.dumps(line))
     gc.free()
     hal.close()

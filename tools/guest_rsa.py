@@ -54,7 +54,11 @@ class Layout:
         return self.data_sym[name] if name in self.data_sym else self.bss_sym[name]
 
 
-def build():
+def build(extend=None):
+    """The ELF image, the assembler's labels and the memory layout.  `extend` (tools/guest_camt53.py) is an object with hooks
+    layout(L), after_operands(a, L, k) -- emitted when the operands of RSA operation k = 0, 1, 2 have been read --, main(a, L, fresh,
+    halt) -- emitted after the three RSA checks, before the commit of this file (which it replaces when it returns True) -- and
+    library(a, L, fresh), emitted after the library of this file."""
     L = Layout()
     L.const("K", struct.pack("<64I", *K256))
     L.const("H0", struct.pack("<8I", *H256))
@@ -64,6 +68,8 @@ def build():
     for name, size in (("LEN", 4), ("MSG", MAX_MSG + 128), ("W", 256), ("DIGEST", 32), ("DIGEST2", 32), ("BASE", 256), ("N", 256), ("WANT", 256), ("EXPO", 4),
                        ("N0INV", 4), ("T", 66 * 4), ("ONE_M", 256), ("R2", 256), ("X", 256), ("ACC", 256), ("OUT", 256), ("PLAIN1", 256), ("EM", 256)):
         L.var(name, size)
+    if extend:
+        extend.layout(L)
     a = Asm(TEXT)
     counter = [0]
 
@@ -136,9 +142,23 @@ def build():
     read_message()
     hash_message("DIGEST")
     read_rsa_operands(False)
+    if extend:
+        extend.after_operands(a, L, 0)
     check_signature("DIGEST", 1)
     # 2. the transaction key: decrypted block ^ e mod n_client == the ciphertext in the response
     read_rsa_operands(True)
+    if extend:
+        extend.after_operands(a, L, 1)
+    if extend:  # the decrypted block is needed again (its last 16 bytes are the AES key): BASE is reused by step 3
+        a.la(T0, L["BASE"])
+        a.la(T1, L["TXBLOCK"])
+        a.addi(T2, T0, 256)
+        a.label("keep_block")
+        a.lw(T3, 0, T0)
+        a.sw(T3, 0, T1)
+        a.addi(T0, T0, 4)
+        a.addi(T1, T1, 4)
+        a.bne(T0, T2, "keep_block")
     a.call("rsa_pub")
     a.la(A0, L["OUT"])
     a.la(A1, L["WANT"])
@@ -150,7 +170,22 @@ def build():
     read_message()
     hash_message("DIGEST2")
     read_rsa_operands(False)
+    if extend:
+        extend.after_operands(a, L, 2)
     check_signature("DIGEST2", 3)
+    if extend and extend.main(a, L, fresh, halt):
+        pass  # the extension commits and halts itself
+    else:
+        emit_commit(a, L, frame, halt)
+    emit_library(a, L)
+    if extend:
+        extend.library(a, L, fresh)
+    words = a.assemble()
+    image = elf([(TEXT, struct.pack("<%dI" % len(words), *words), 5), (DATA, L.data, 6)], a.labels["_start"])
+    return image, a.labels, L
+
+
+def emit_commit(a, L, frame, halt):
     # 4. the commitment: both digests in hex inside the JSON template, serde-framed
     a.la(A0, L["DIGEST"])
     a.la(A1, L["JSON"] + 4 + TEMPLATE.index(b"0" * 64))
@@ -164,6 +199,8 @@ def build():
     a.ecall()
     halt(0)
 
+
+def emit_library(a, L):
     # ------------------------------------------------------------------ hex32(a0 = 8 digest words, a1 = 64 output bytes)
     a.label("hex32")
     a.li(T0, 0)
@@ -590,10 +627,6 @@ def build():
     a.li(T6, 256)
     a.bne(T0, T6, "ct_l")
     a.ret()
-
-    words = a.assemble()
-    image = elf([(TEXT, struct.pack("<%dI" % len(words), *words), 5), (DATA, L.data, 6)], a.labels["_start"])
-    return image, a.labels, L
 
 
 def limbs(value):
