@@ -498,7 +498,7 @@ def prove_elf_session(hal, entry):
                 cc.free()
         verdict = receipt.verify(blob, roots, image_id)
         n = st["segments"]
-        return {"value": round(n / wall, 3), "unit": "segments/s (one context; executor + device witness generation + proofs inside the timed call)",
+        return {"value": round(n / wall, 3), "unit": "segments/s (executor thread + two prover lanes on the one GPU; execution, device witness generation and proofs inside the timed call)",
                 "segments": n, "cycles": cycles, "wall_s": round(wall, 4), "guest": what,
                 "executor_MHz_with_trace_kept": round(cycles / st["executor_s"] / 1e6, 1), "executor_host_ms_per_segment": round(1e3 * st["executor_s"] / n, 2),
                 "witgen_ms_per_segment": round(st["witgen_ms"] / n, 2), "prove_ms_per_segment": round(st["prove_ms"] / n, 2),
