@@ -8,6 +8,12 @@
 // are synthetic names (there is no executor here), segment k runs from state k to state k+1, all but the last end in SystemSplit,
 // the last halts with the journal's output; the claim's eight naming words are planted as the segment's public inputs.  The image
 // id (digest of state 0) and the control root of the trace size are printed for the verifier (`r0h_verify --receipt`).
+//
+//   usage: r0h_prove <trace.r0c> --elf guest.elf --input words.bin [--code-object file.hsaco] [--po2 N] [--device D] --receipt-out file.json
+// `prover.prove(env, ELF)` itself (host/src/main.rs:420-423) as a compiled host: the guest ELF is executed on the u32 input stream
+// (the ExecutorEnv frames, little-endian words in a file), every segment is proved (r0h_prove_elf: with circuits/trace.r0c the
+// seals are proofs over the segments' own cycles), the receipt is written as JSON, and one line of JSON names the image id in
+// the reference's IMAGE_ID.hex form, the control root of every trace size used, the cycle and segment counts and the timing.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -33,10 +39,11 @@ static void die(const char* what, const char* err) {
 
 int main(int argc, char** argv) {
   if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) {
-    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json | --receipt-dir dir] [--journal text] [--receipts R]\n%s\n", r0h_version());
+    printf("usage: r0h_prove <circuit.r0c> [--code-object file.hsaco] [--po2 N] [--segments K] [--seed S] [--device D] [--contexts C] [--seal-out file] [--verify 1] [--receipt-out file.json | --receipt-dir dir] [--journal text] [--receipts R]\n"
+           "       r0h_prove <trace.r0c> --elf guest.elf --input words.bin [--code-object file.hsaco] [--po2 N] [--device D] --receipt-out file.json\n%s\n", r0h_version());
     return argc < 2 ? 1 : 0;
   }
-  std::string blob_path = argv[1], co_path, seal_out, receipt_out, receipt_dir, journal_text;
+  std::string blob_path = argv[1], co_path, seal_out, receipt_out, receipt_dir, journal_text, elf_path, input_path;
   unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0, receipts = 1;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
@@ -52,6 +59,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--receipt-dir")) receipt_dir = argv[i + 1];
     else if (!strcmp(argv[i], "--journal")) journal_text = argv[i + 1];
     else if (!strcmp(argv[i], "--receipts")) receipts = (unsigned)atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--elf")) elf_path = argv[i + 1];
+    else if (!strcmp(argv[i], "--input")) input_path = argv[i + 1];
     else { fprintf(stderr, "r0h_prove: unknown option %s\n", argv[i]); return 1; }
   }
   FILE* f = fopen(blob_path.c_str(), "rb");
@@ -62,6 +71,73 @@ int main(int argc, char** argv) {
   std::vector<uint32_t> blob((size_t)sz / 4);
   if (fread(blob.data(), 4, blob.size(), f) != blob.size()) { fprintf(stderr, "r0h_prove: short read\n"); return 1; }
   fclose(f);
+  if (!elf_path.empty()) {  // prove(env, elf)
+    auto slurp = [](const std::string& path, std::vector<uint8_t>* out) {
+      FILE* g = fopen(path.c_str(), "rb");
+      if (!g) return false;
+      uint8_t buf[65536];
+      for (size_t got; (got = fread(buf, 1, sizeof buf, g)) > 0;) out->insert(out->end(), buf, buf + got);
+      fclose(g);
+      return true;
+    };
+    std::vector<uint8_t> elf, raw;
+    if (!slurp(elf_path, &elf)) { fprintf(stderr, "r0h_prove: cannot open %s\n", elf_path.c_str()); return 1; }
+    if (!input_path.empty() && !slurp(input_path, &raw)) { fprintf(stderr, "r0h_prove: cannot open %s\n", input_path.c_str()); return 1; }
+    if (raw.size() % 4) { fprintf(stderr, "r0h_prove: --input is a stream of 32-bit words\n"); return 1; }
+    if (receipt_out.empty()) { fprintf(stderr, "r0h_prove: --elf needs --receipt-out\n"); return 1; }
+    std::vector<uint32_t> words(raw.size() / 4);
+    if (!words.empty()) memcpy(words.data(), raw.data(), raw.size());
+    r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; r0h_receipt* rc = nullptr;
+    CHECK(r0h_ctx_create((int)device, &ctx));
+    CHECK(r0h_circuit_load(ctx, blob.data(), blob.size(), co_path.empty() ? nullptr : co_path.c_str(), &circ));
+    uint8_t image_id[32];
+    uint64_t cycles = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    CHECK(r0h_prove_elf(ctx, circ, elf.data(), elf.size(), words.data(), words.size(), po2, 0, &rc, image_id, &cycles));
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    char* text = nullptr;
+    CHECK(r0h_receipt_to_json(rc, &text));
+    FILE* o = fopen(receipt_out.c_str(), "wb");
+    if (!o || fwrite(text, 1, strlen(text), o) != strlen(text)) { fprintf(stderr, "r0h_prove: cannot write %s\n", receipt_out.c_str()); return 1; }
+    fclose(o);
+    r0h_free_error(text);
+    // the control root of every trace size the segments were proved at: what `r0h_verify --control-root` takes
+    const size_t n_seg = r0h_receipt_n_segments(rc);
+    const uint32_t n_glob = r0h_circuit_n_global(circ);
+    std::vector<uint32_t> sizes;
+    for (size_t i = 0; i < n_seg; i++) {
+      const uint32_t* seal; size_t n_words;
+      CHECK(r0h_receipt_segment(rc, i, &seal, &n_words, nullptr));
+      int verdict = -1; uint32_t size = 0;
+      CHECK(r0h_verify_seal(blob.data(), blob.size(), nullptr, nullptr, seal, n_words, &verdict, &size));
+      if (verdict != R0H_VERIFY_OK) { fprintf(stderr, "r0h_prove: the verifier rejects seal %zu: %s\n", i, r0h_verify_reason(verdict)); return 3; }
+      if (std::find(sizes.begin(), sizes.end(), size) == sizes.end()) sizes.push_back(size);
+    }
+    (void)n_glob;
+    char hex[65];
+    CHECK(r0h_image_id_to_hex(image_id, hex));
+    r0h_session_stats st;
+    CHECK(r0h_last_session_stats(ctx, &st));
+    printf("{\"image_id\": \"%s\", \"segments\": %zu, \"cycles\": %llu, \"seconds\": %.4f, \"segments_per_s\": %.3f, \"executor_s\": %.4f, \"control_roots\": [", hex, n_seg,
+           (unsigned long long)cycles, secs, n_seg / secs, st.executor_s);
+    for (size_t k = 0; k < sizes.size(); k++) {
+      const size_t n = (size_t)1 << sizes[k];
+      r0h_buf *code = nullptr, *data = nullptr;
+      CHECK(r0h_buf_alloc(ctx, (size_t)r0h_circuit_group_size(circ, R0H_GROUP_CODE) * n * 4, &code));
+      CHECK(r0h_buf_alloc(ctx, (size_t)r0h_circuit_group_size(circ, R0H_GROUP_DATA) * n * 4, &data));
+      CHECK(r0h_witgen(ctx, circ, sizes[k], 0, code, data, nullptr));  // the circuit's fixed CODE columns
+      uint32_t root[8];
+      CHECK(r0h_code_root(ctx, code, r0h_circuit_group_size(circ, R0H_GROUP_CODE), sizes[k], root));
+      printf("%s\"%u:%u,%u,%u,%u,%u,%u,%u,%u\"", k ? ", " : "", sizes[k], root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7]);
+      CHECK(r0h_buf_free(code));
+      CHECK(r0h_buf_free(data));
+    }
+    printf("]}\n");
+    CHECK(r0h_receipt_free(rc));
+    CHECK(r0h_circuit_free(circ));
+    CHECK(r0h_ctx_destroy(ctx));
+    return 0;
+  }
   if (contexts < 1 || contexts > 16) { fprintf(stderr, "r0h_prove: --contexts must be 1..16\n"); return 1; }
   if (receipts < 1 || (receipts > 1 && !receipt_out.empty())) { fprintf(stderr, "r0h_prove: --receipts R > 1 writes one file per receipt: use --receipt-dir\n"); return 1; }
   if (!receipt_out.empty() && !receipt_dir.empty()) { fprintf(stderr, "r0h_prove: --receipt-out and --receipt-dir exclude each other\n"); return 1; }

@@ -97,3 +97,37 @@ def test_batch_of_receipts_on_a_work_queue(tmp_path):
     assert info["receipts"] == 4 and info["segments"] == 3 and info["receipts_per_s"] > 0 and abs(info["segments_per_s"] / info["receipts_per_s"] - 3) < 1e-3
     bad = subprocess.run([CLI, circuit_path("small"), "--receipts", "2", "--receipt-out", str(tmp_path / "r.json")], capture_output=True, text=True)
     assert bad.returncode == 1 and "--receipt-dir" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_compiled_hosts_prove_the_guest_and_verify_the_receipt_like_host_and_verifier(tmp_path):
+    """The reference's flow with compiled programs only (host/src/main.rs:420-423 + :251-252, verifier/src/main.rs:118-128):
+    `r0h_prove <trace circuit> --elf <guest> --input <ExecutorEnv words>` executes the hand-assembled hyperfridge guest on the
+    reference's fixture and writes the receipt; `r0h_verify --receipt .. --image-id .. --control-root ..` accepts it and prints the
+    commitment -- which is the commitment inside the reference's own receipt file."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import __graft_entry__ as entry
+    import guest_camt53
+    import hyperfridge_r0_amd as r0
+    elf_path = os.path.join(ROOT, "circuits", "guest_camt53.elf")
+    _, stream, _ = guest_camt53.elf_and_input(form=1)
+    words = tmp_path / "env.bin"
+    np.array(stream, dtype=np.uint32).tofile(words)
+    receipt = str(tmp_path / "receipt.json")
+    out = subprocess.run([CLI, circuit_path("trace"), "--code-object", entry.code_object_path("trace"), "--elf", elf_path, "--input", str(words), "--po2", "20",
+                          "--receipt-out", receipt], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["segments"] >= 11 and info["cycles"] > 11_000_000 and len(info["image_id"]) == 64
+    bind = ["--image-id", info["image_id"]]
+    for root in info["control_roots"]:
+        bind += ["--control-root", root]
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace")] + bind, capture_output=True, text=True, timeout=600)
+    report = json.loads(out.stdout)
+    assert out.returncode == 0 and report["accepted"] is True and report["journal_bound"] is True and report["segments"] == info["segments"]
+    want = bytes(json.load(open(os.path.join(ROOT, "tests", "golden", "reference_receipt_6bb95807_latest.json")))["journal"]["bytes"])
+    assert report["commitment"] == r0.journal_commitment(want).decode()
+    other = "0" * 64
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", other] + bind[2:], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 1 and "image id" in json.loads(out.stdout)["reason"]

@@ -46,7 +46,7 @@ def main():
         assert len(files) == n_rc
         for r, path in enumerate(files):
             rc = r0.Receipt.parse(open(path).read())
-            v = rc.verify(blob, roots, bytes.fromhex(ids["image_ids"][r]))
+            v = rc.verify(blob, roots, r0.image_id_from_hex(ids["image_ids"][r]))
             if v[0] != 0:
                 print("receipt %s rejected in round %d: %r" % (path, rounds, v))
                 sys.exit(1)
