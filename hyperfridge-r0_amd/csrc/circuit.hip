@@ -311,7 +311,56 @@ static std::vector<bool> lazy_additions(const r0h_circuit* c) {
   return lazy;
 }
 
-static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& done, const std::vector<bool>& lazy, std::ostringstream& os) {
+// Sums of products reduced once.  An ADD tree whose inner nodes have no other reader and whose leaves include two or more products
+// that have no other reader either -- a0 b0 + a1 b1 (+ ...) (+ other terms) -- is emitted as ONE Montgomery reduction of the 64-bit sum
+// of those products (fred64: up to four products of reduced words, T < 4 p^2; a product with an uncorrected operand counts double),
+// the other leaves added afterwards: per product fused, a v_mul_lo_u32, a v_mad_u64_u32 and a conditional subtraction less.  Same
+// canonical word as the step-by-step form (both are the sum mod p, fully reduced).  In the bench circuit: the 2,612 padded
+// constraints t0 t1 + t2 t3 + ..
+// MEASURED AND LEFT OFF (round 3, profiles/r03/eval_check_fusion.md): fewer multiplier instructions, but the fused form keeps four
+// factors and a 64-bit sum live per constraint -- 242 / 230 / 190 VGPRs instead of 165 / 166 / 150 for the three kernels of `bench`,
+// two waves per SIMD instead of three -- and eval_check runs 8 % SLOWER (11.05 vs 10.26 ms); cut into eight kernels that fit 162
+// VGPRs it is still 5 % slower.  R0H_EC_FUSION=1 turns it on for experiments (tools/tune_evalcheck.py).
+struct Fuse { std::vector<uint32_t> muls, rest; };
+static std::vector<Fuse> plan_fusion(const r0h_circuit* c, const std::vector<bool>& lazy) {
+  const size_t nf = c->fp_step.size();
+  std::vector<Fuse> fuse(nf);
+  if (!getenv("R0H_EC_FUSION")) return fuse;
+  std::vector<uint32_t> uses(nf, 0);
+  std::vector<bool> read_by_add_only(nf, true);  // every reader is an ADD (only then can the node dissolve into its reader's tree)
+  for (const Step& s : c->steps) {
+    if (s.op == R0H_OP_ADD || s.op == R0H_OP_SUB || s.op == R0H_OP_MUL) {
+      uses[s.a]++; uses[s.b]++;
+      if (s.op != R0H_OP_ADD) read_by_add_only[s.a] = read_by_add_only[s.b] = false;
+    }
+    if (s.op == R0H_OP_AND_EQZ || s.op == R0H_OP_AND_COND) { uses[s.b]++; read_by_add_only[s.b] = false; }
+  }
+  auto op_of = [&](uint32_t v) { return c->steps[c->fp_step[v]].op; };
+  auto inner = [&](uint32_t v) { return op_of(v) == R0H_OP_ADD && uses[v] == 1 && read_by_add_only[v]; };  // dissolves into its reader
+  for (uint32_t v = 0; v < nf; v++) {
+    if (op_of(v) != R0H_OP_ADD || inner(v)) continue;  // only the root of a tree is emitted
+    Fuse f;
+    uint32_t weight = 0;
+    std::vector<uint32_t> stack{v};
+    while (!stack.empty()) {
+      const uint32_t x = stack.back();
+      stack.pop_back();
+      const Step& s = c->steps[c->fp_step[x]];
+      for (uint32_t y : {s.a, s.b}) {
+        if (inner(y)) { stack.push_back(y); continue; }
+        const Step& m = c->steps[c->fp_step[y]];
+        const uint32_t w = op_of(y) == R0H_OP_MUL ? ((lazy[m.a] || lazy[m.b]) ? 2u : 1u) : 0u;
+        if (w && uses[y] == 1 && read_by_add_only[y] && weight + w <= 3) { f.muls.push_back(y); weight += w; }
+        else f.rest.push_back(y);
+      }
+    }
+    if (f.muls.size() >= 2) fuse[v] = f;
+  }
+  return fuse;
+}
+
+static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& done, const std::vector<bool>& lazy, const std::vector<Fuse>& fuse,
+                     std::ostringstream& os) {
   // iterative post-order emission of the expression DAG below `root`
   std::vector<std::pair<uint32_t, int>> stack;
   stack.push_back({root, 0});
@@ -319,9 +368,19 @@ static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& don
     auto [v, state] = stack.back();
     if (done[v]) { stack.pop_back(); continue; }
     const Step& s = c->steps[c->fp_step[v]];
+    const Fuse& f = fuse[v];
     bool binary = s.op == R0H_OP_ADD || s.op == R0H_OP_SUB || s.op == R0H_OP_MUL;
     if (binary && state == 0) {
       stack.back().second = 1;
+      if (!f.muls.empty()) {  // the factors of the fused products and the other leaves, not the tree's own nodes
+        for (uint32_t y : f.rest) if (!done[y]) stack.push_back({y, 0});
+        for (uint32_t m : f.muls) {
+          const Step& ms = c->steps[c->fp_step[m]];
+          if (!done[ms.b]) stack.push_back({ms.b, 0});
+          if (!done[ms.a]) stack.push_back({ms.a, 0});
+        }
+        continue;
+      }
       if (!done[s.b]) stack.push_back({s.b, 0});
       if (!done[s.a]) stack.push_back({s.a, 0});
       continue;
@@ -329,6 +388,19 @@ static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& don
     stack.pop_back();
     done[v] = true;
     os << "  const u32 v" << v << " = ";
+    if (!f.muls.empty()) {
+      std::ostringstream sum;
+      sum << "fred64(";
+      for (size_t k = 0; k < f.muls.size(); k++) {
+        const Step& ms = c->steps[c->fp_step[f.muls[k]]];
+        sum << (k ? " + " : "") << "(u64)v" << ms.a << " * v" << ms.b;
+      }
+      sum << ")";
+      std::string expr = sum.str();
+      for (uint32_t y : f.rest) expr = "fadd(" + expr + ", v" + std::to_string(y) + ")";
+      os << expr << ";\n";
+      continue;
+    }
     switch (s.op) {
       case R0H_OP_CONST: os << enc(s.a) << "u"; break;
       case R0H_OP_GET: {
@@ -352,6 +424,7 @@ static void emit_var(const r0h_circuit* c, uint32_t root, std::vector<bool>& don
 // Code-generation tunables (environment overrides exist for experiments; defaults are the measured best):
 //   R0H_EC_BUDGET  expression nodes per kernel          R0H_EC_SCOPE  terms per register scope (0 = one scope)
 //   R0H_EC_WAVES   __launch_bounds__ waves/SIMD hint (0 = none)
+//   R0H_EC_FUSION  sums of products share one reduction (plan_fusion; measured slower, off)
 static uint32_t tunable(const char* name, uint32_t dflt) {
   const char* v = getenv(name);
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
@@ -367,6 +440,7 @@ static void emit_accumulate(const Plan& pl, uint32_t term, uint32_t position, st
 static std::string emit_source(const r0h_circuit* c) {
   const Plan& pl = c->plan;
   const std::vector<bool> lazy = lazy_additions(c);
+  const std::vector<Fuse> fuse = plan_fusion(c, lazy);
   const uint32_t scope_terms = tunable("R0H_EC_SCOPE", 0), waves = tunable("R0H_EC_WAVES", 0);
   std::ostringstream os;
   os << PRELUDE;
@@ -394,8 +468,8 @@ static std::string emit_source(const r0h_circuit* c) {
         in_scope = 0;
       }
       const Term& tm = pl.terms[t];
-      emit_var(c, tm.v, done, lazy, os);
-      for (uint32_t g : tm.conds) emit_var(c, g, done, lazy, os);
+      emit_var(c, tm.v, done, lazy, fuse, os);
+      for (uint32_t g : tm.conds) emit_var(c, g, done, lazy, fuse, os);
       // value of the term: the constraint times its enclosing gates
       std::ostringstream val;
       for (size_t g = 0; g < tm.conds.size(); g++) val << "fmul(v" << tm.conds[g] << ", ";

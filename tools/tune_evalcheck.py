@@ -18,6 +18,10 @@ OUT = os.path.join(ROOT, "build", "ec")
 
 def emit(name, scope, waves, budget, circuit="bench"):
     os.environ["R0H_EC_SCOPE"], os.environ["R0H_EC_WAVES"], os.environ["R0H_EC_BUDGET"] = scope, waves, budget
+    if name.startswith("fuse"):  # sums of products share one reduction (circuit.hip plan_fusion); off by default
+        os.environ["R0H_EC_FUSION"] = "1"
+    else:
+        os.environ.pop("R0H_EC_FUSION", None)
     blob = np.fromfile(os.path.join(ROOT, "circuits", circuit + ".r0c"), dtype=np.uint32)
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, name + ".hip"), "w") as f:
