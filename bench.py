@@ -135,7 +135,7 @@ def spawn_ranks(script, argv, n, extra_env=None):
     return 0
 
 
-def pin_to_gpu_numa_node(local_rank):
+def pin_to_gpu_numa_node(local_rank, min_cores=12):
     """Keep this rank's host threads (one lane thread per in-flight context, transcripts, launches) on the cores of the NUMA node
     its GPU hangs off, when the PCI device's numa_node is readable and names a node whose cores this process may use; otherwise
     leave the affinity as it is.  Eight ranks x eight lane threads on a two-socket host otherwise wander across sockets.
@@ -152,8 +152,8 @@ def pin_to_gpu_numa_node(local_rank):
             lo, _, hi = part.partition("-")
             cpus.update(range(int(lo), int(hi or lo) + 1))
         usable = cpus & os.sched_getaffinity(0)
-        if not usable:
-            return "node %d has no core in this process's affinity mask: left as is" % node
+        if len(usable) < min_cores:  # pinning must never starve the lanes: a node with too few usable cores is not worth it
+            return "node %d offers %d usable cores (< %d wanted): affinity left as is" % (node, len(usable), min_cores)
         os.sched_setaffinity(0, usable)  # the calling (main) thread; the lane threads started later inherit it
         return "pinned to NUMA node %d of %s (%d cores)" % (node, bdf, len(usable))
     except Exception as exc:  # noqa: BLE001 -- a sysfs layout we do not know is not an error
