@@ -33,7 +33,9 @@ class DistEnv:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = device
-        if self.world > 1:
+        # R0H_FORCE_PROCESS_GROUP=1: build the process group even for one rank, so that the backend's path (RCCL init with a device id,
+        # barrier, device-tensor all-reduce) can be exercised on a one-GPU box (tests/test_gpu_bench.py)
+        if self.world > 1 or (backend is not None and os.environ.get("R0H_FORCE_PROCESS_GROUP") == "1"):
             if backend is None:
                 raise ValueError("WORLD_SIZE > 1 needs a backend")
             import torch.distributed as dist

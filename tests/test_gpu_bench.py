@@ -29,3 +29,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_the_rccl_path_of_the_driver_runs_with_one_rank():
+    """The multi-GPU runs go through torch.distributed with backend "nccl" (= RCCL): process group bound to the rank's device, barrier
+    around the timed region, MAX / SUM all-reduces of device tensors.  A one-GPU box cannot hold two RCCL ranks, but it can hold one:
+    R0H_FORCE_PROCESS_GROUP=1 builds the group for a single rank, so the very calls the 8-GPU run makes are executed here."""
+    env = dict(os.environ, R0H_FORCE_PROCESS_GROUP="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--po2", "12", "--circuit", "small",
+                          "--cpu-po2", "0", "--contexts", "2", "--backend", "nccl"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["steps"] == 2
