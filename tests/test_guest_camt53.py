@@ -9,6 +9,7 @@ data/test/test.xml-* and the public keys (tests/golden/camt53/, copies of the re
 checked against Python's zlib / zipfile / hashlib and the product's own AES block function; payloads the reference does not hold
 (stored and fixed-Huffman deflate blocks, stored ZIP members, other accounts, corrupted streams) are signed here with a throw-away
 RSA key generated in the test."""
+import base64
 import hashlib
 import io
 import json
@@ -42,7 +43,9 @@ def guest():
 def run(guest, iban=guest_camt53.REFERENCE_IBAN, host="host:main", form=1, inputs=None, po2=20):
     vm = r0.Vm()
     vm.load_elf(guest["elf"])
-    vm.set_input(guest_camt53.input_stream(iban, host, form=form, **(inputs or guest["ref"])))
+    inputs = dict(inputs or guest["ref"])
+    authenticated = inputs.pop("authenticated", None)
+    vm.set_input(guest_camt53.input_stream(iban, host, guest_camt53.reference_authenticated() if authenticated is None else authenticated, form=form, **inputs))
     return vm, vm.run(segment_po2=po2, max_cycles=200_000_000)
 
 
@@ -131,7 +134,16 @@ def _sign(key, message):
     return pow(int.from_bytes(em, "big"), key["d"], key["n"]).to_bytes(256, "big")
 
 
-def _inputs(key, payload_zlib, aes_key=bytes(range(16)), signed_info=b"<ds:SignedInfo>anything</ds:SignedInfo>", pad=None):
+AUTHENTICATED = b'<header authenticate="true"><static><HostID>TOY</HostID></static></header><DataEncryptionInfo authenticate="true"/>'
+
+
+def _signed_info(authenticated):
+    return (b'<ds:SignedInfo><ds:Reference URI="#xpointer(//*[@authenticate=\'true\'])"><ds:DigestValue>'
+            + base64.b64encode(hashlib.sha256(authenticated).digest()) + b"</ds:DigestValue></ds:Reference></ds:SignedInfo>")
+
+
+def _inputs(key, payload_zlib, aes_key=bytes(range(16)), signed_info=None, pad=None, authenticated=AUTHENTICATED):
+    signed_info = _signed_info(authenticated) if signed_info is None else signed_info
     pad = 16 - len(payload_zlib) % 16 if pad is None else pad
     plain = payload_zlib + bytes(pad - 1) + bytes([pad & 0xFF]) if pad else payload_zlib
     ct, prev = b"", bytes(16)
@@ -141,7 +153,7 @@ def _inputs(key, payload_zlib, aes_key=bytes(range(16)), signed_info=b"<ds:Signe
     block = b"\x00\x02" + bytes([7] * 237) + b"\x00" + aes_key
     return dict(signed_info=signed_info, bank_sig=_sign(key, signed_info), bank_n=key["n"], tx_plain=block, client_n=key["n"],
                 tx_cipher=pow(int.from_bytes(block, "big"), 65537, key["n"]).to_bytes(256, "big"), order_data=ct, witness_sig=_sign(key, ct),
-                witness_n=key["n"])
+                witness_n=key["n"], authenticated=authenticated)
 
 
 def _doc(iban, seq, amount, ccy="EUR", cd="OPBD", day="2024-02-29"):
@@ -203,6 +215,11 @@ def test_what_the_guest_refuses(guest, toy_key):
         (dict(iban=mine), dict(base, tx_plain=b"\x00\x01" + base["tx_plain"][2:], tx_cipher=pow(int.from_bytes(b"\x00\x01" + base["tx_plain"][2:], "big"), 65537, toy_key["n"]).to_bytes(256, "big")), 9),
         (dict(iban=mine), dict(base, order_data=flip(base["order_data"], 5)), 3),                  # the witness signed other data
         (dict(iban=mine), dict(base, bank_sig=flip(base["bank_sig"], 200)), 1),
+        (dict(iban=mine), dict(base, authenticated=flip(AUTHENTICATED, 30)), 10),                  # the signed digest is of other header data
+        (dict(iban=mine), dict(base, authenticated=AUTHENTICATED + b" "), 10),
+        (dict(iban=mine), _inputs(toy_key, good, signed_info=b"<ds:SignedInfo>no digest in here</ds:SignedInfo>"), 10),
+        (dict(iban=mine), _inputs(toy_key, good, signed_info=_signed_info(AUTHENTICATED)[:-60]), 10),  # the value is cut short
+        (dict(iban=mine), dict(base, authenticated=bytes(guest_rsa.MAX_MSG + 1)), 5),
     ]
     for kw, inputs, want in cases:
         vm, (kind, code) = run(guest, host="h", form=0, inputs=inputs, **kw)
@@ -213,6 +230,16 @@ def test_what_the_guest_refuses(guest, toy_key):
     z[22] ^= 1
     vm, (kind, code) = run(guest, iban=mine, host="h", form=0, inputs=_inputs(toy_key, zlib.compress(bytes(z), 9)))
     assert (kind, code) == (0, 7)
+    # ... or about its checksum (stored member: the byte changed is the document's, the archive stays well-formed)
+    for method in (zipfile.ZIP_STORED, zipfile.ZIP_DEFLATED):
+        z = bytearray(_zip([_doc(mine, 1, "1.00")], method))
+        z[14] ^= 0x10
+        vm, (kind, code) = run(guest, iban=mine, host="h", form=0, inputs=_inputs(toy_key, zlib.compress(bytes(z), 9)))
+        assert (kind, code) == (0, 11) and vm.journal == b""
+    z = bytearray(_zip([_doc(mine, 1, "1.00")], zipfile.ZIP_STORED))
+    z[30 + len("camt53/doc_0.xml") + 100] ^= 0x20  # a byte of the document itself
+    vm, (kind, code) = run(guest, iban=mine, host="h", form=0, inputs=_inputs(toy_key, zlib.compress(bytes(z), 9)))
+    assert (kind, code) == (0, 11)
 
 
 @pytest.mark.gpu

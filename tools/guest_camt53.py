@@ -6,12 +6,15 @@ On top of tools/guest_rsa.py (SHA-256 of SignedInfo + the bank's RSA-2048 signat
 signature over SHA-256 of the order data: methods/guest/src/main.rs:450-485, 663-718, 757-833) this guest does what
 methods/guest/src/main.rs:719-756 (`decrypt_order_data`) and :836-981 (the camt53 parse) do and commits what :214-262 commits:
 
+  0. hashes the authenticated part of the response (`<xml>-authenticated`), base64-encodes the digest and compares it with the
+     <ds:DigestValue> inside the SignedInfo the bank signed (methods/guest/src/main.rs:556-560; test_xmlparse.rs:43-67) -- exit 10;
   5. takes the AES-128 key out of the decrypted transaction-key block (00 02 PS 00 key: the key is the last 16 bytes, the 00 at
      byte 239) and decrypts the order data -- AES-128-CBC, zero ICV (FIPS 197 inverse cipher, byte-oriented, tables for the
      S-boxes and the GF(2^8) products by 9, 11, 13, 14) -- exit 9 on a malformed block or padding;
   6. inflates the zlib stream (RFC 1950 header and Adler-32, RFC 1951 stored / fixed / dynamic blocks, canonical Huffman decoding
      a bit at a time) into the ZIP archive it holds -- exit 6 on a malformed stream;
-  7. walks the archive's local file headers and inflates every member (raw deflate; stored members are copied) -- exit 7;
+  7. walks the archive's local file headers, inflates every member (raw deflate; stored members are copied) and checks its
+     CRC-32 against the header's -- exit 7 (malformed archive) / 11 (checksum);
   8. in every camt.053 document whose statement account `<Acct><Id><IBAN>` is the IBAN the host named, reads ElctrncSeqNb,
      FrDtTm, ToDtTm and the first balance's Amt / Ccy / Cd, and
   9. commits {"hostinfo":..,"iban":..,"pub_bank_pem":..,"pub_witness_pem":..,"pub_client_pem":..,"stmts":[{"elctrnc_seq_nb":..,
@@ -23,7 +26,7 @@ The reference holds two committed receipts for this fixture and the program's jo
 (tests/test_guest_camt53.py): data/test/test.xml-Receipt-6bb958..-latest.json in the current form above (commitment form 1), and
 data/test/test.xml-Receipt-test.json, written before the guest began to commit the keys (form 0: hostinfo, iban, stmts; the form
 is the last word of the input).  Not reproduced: the XML tokenizer (tags are located by substring search), the
-parse of the pre-processed EbicsResponse snippets, CRC-32 of ZIP members, and the RSA PRIVATE-key decryption of the transaction key,
+parse of the pre-processed EbicsResponse snippets, and the RSA PRIVATE-key decryption of the transaction key,
 which the reference's guest can also be told to skip by handing it the decrypted block (`decrypted_tx_key_bin`, as here)."""
 import os
 import struct
@@ -83,7 +86,7 @@ DEXT = [0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10
 ORDER = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
 STRINGS = {  # needles in the camt.053 documents and the pieces of the commitment
     "N_IBAN": b"<Acct><Id><IBAN>", "N_IBAN_END": b"</IBAN>", "N_SEQ": b"<ElctrncSeqNb>", "N_FR": b"<FrDtTm>", "N_TO": b"<ToDtTm>", "N_BAL": b"<Bal>",
-    "N_CD": b"<Cd>", "N_AMT": b'<Amt Ccy="',
+    "N_CD": b"<Cd>", "N_AMT": b'<Amt Ccy="', "N_DIGEST": b"<ds:DigestValue>",
     "J_HOST": b'{"hostinfo":"', "J_IBAN": b'","iban":"', "J_STMTS": b'","stmts":[', "J_BANK": b'","pub_bank_pem":"', "J_WITNESS": b'","pub_witness_pem":"',
     "J_CLIENT": b'","pub_client_pem":"', "PEM_BEGIN": b"-----BEGIN PUBLIC KEY-----\\n", "PEM_END": b"-----END PUBLIC KEY-----\\n", "ESC_NL": b"\\n",
     "B64": b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/",
@@ -108,12 +111,78 @@ class Camt53:
             L.const(name, struct.pack("<%dI" % len(table), *table))
         for name, text in STRINGS.items():
             L.const(name, text)
-        for name, size in (("N_BANK", 256), ("N_CLIENT", 256), ("N_WITNESS", 256), ("DERBUF", 296), ("FORM", 4), ("IBAN_LEN", 4), ("IBAN", 64), ("HOST_LEN", 4), ("HOST", 256), ("RK", 176), ("ST", 16), ("TMP16", 16), ("KEY", 16),
+        crc = []
+        for n in range(256):  # CRC-32 (IEEE 802.3, reflected, polynomial 0xEDB88320): the table of the byte-at-a-time form
+            c = n
+            for _ in range(8):
+                c = (c >> 1) ^ (0xEDB88320 if c & 1 else 0)
+            crc.append(c)
+        L.const("CRC_TABLE", struct.pack("<256I", *crc))
+        for name, size in (("AUTH_LEN", 4), ("AUTH", guest_rsa.MAX_MSG + 128), ("DIGEST3", 32), ("B64OUT", 48), ("N_BANK", 256), ("N_CLIENT", 256), ("N_WITNESS", 256), ("DERBUF", 296), ("FORM", 4), ("IBAN_LEN", 4), ("IBAN", 64), ("HOST_LEN", 4), ("HOST", 256), ("RK", 176), ("ST", 16), ("TMP16", 16), ("KEY", 16),
                            ("PLAIN", guest_rsa.MAX_MSG + 32), ("LENCODE", 64 + 4 * 288), ("DISTCODE", 64 + 4 * 32), ("CLCODE", 64 + 4 * 19), ("OFFS", 64),
                            ("CL_LENGTHS", 4 * 19), ("LENGTHS", 4 * 320), ("ZIPBUF", ZIP_MAX), ("DOC", DOC_MAX), ("JP", 4), ("N_STMTS", 4), ("JOUT", OUT_MAX),
                            ("TXBLOCK", 256)):
             L.var(name, size)
         assert L.bss_top < STACK_TOP - 4096
+
+    def after_signed_info(self, a, L, fresh, halt):
+        """step 0: SHA-256 of the authenticated part, base64, must be the <ds:DigestValue> of the SignedInfo in MSG"""
+        a.li(SP, STACK_TOP)
+        a.la(A0, L["AUTH_LEN"])
+        a.li(A1, 1)
+        a.li(A7, 1)
+        a.ecall()
+        a.la(T0, L["AUTH_LEN"])
+        a.lw(S0, 0, T0)
+        a.li(T1, guest_rsa.MAX_MSG)
+        ok = fresh("auth_len_ok")
+        a.bgeu(T1, S0, ok)
+        halt(5)
+        a.label(ok)
+        a.addi(A1, S0, 3)
+        a.srli(A1, A1, 2)
+        a.la(A0, L["AUTH"])
+        a.li(A7, 1)
+        a.ecall()
+        a.la(A0, L["AUTH"])
+        a.la(T0, L["AUTH_LEN"])
+        a.lw(A1, 0, T0)
+        a.la(A2, L["DIGEST3"])
+        a.call("sha256")
+        a.la(A0, L["DIGEST3"])
+        a.la(A1, L["B64OUT"])
+        a.call("b64_digest")
+        a.la(A0, L["MSG"])           # SignedInfo
+        a.la(T0, L["LEN"])
+        a.lw(A1, 0, T0)
+        a.add(A1, A0, A1)
+        a.mv(S0, A1)
+        a.la(A2, L["N_DIGEST"])
+        a.li(A3, len(STRINGS["N_DIGEST"]))
+        a.call("find")
+        bad = fresh("digest_bad")
+        a.beq(A0, ZERO, bad)
+        a.addi(T0, A0, 45)           # 44 characters and the '<' of the closing tag
+        a.bltu(S0, T0, bad)
+        a.la(T1, L["B64OUT"])
+        a.li(T2, 0)
+        a.label("digest_cmp")
+        a.add(T3, A0, T2)
+        a.lbu(T3, 0, T3)
+        a.add(T4, T1, T2)
+        a.lbu(T4, 0, T4)
+        a.bne(T3, T4, bad)
+        a.addi(T2, T2, 1)
+        a.li(T5, 44)
+        a.bne(T2, T5, "digest_cmp")
+        a.lbu(T3, 44, A0)
+        a.li(T4, ord("<"))
+        a.bne(T3, T4, bad)
+        ok = fresh("digest_ok")
+        a.j(ok)
+        a.label(bad)
+        halt(10)
+        a.label(ok)
 
     def after_operands(self, a, L, k):  # the modulus of RSA operation k is kept: the commitment names the three keys
         a.la(T0, L["N"])
@@ -300,8 +369,20 @@ class Camt53:
         a.sw(S0, 0, SP)
         a.sw(S1, 4, SP)
         a.sw(S6, 8, SP)
+        a.sw(A0, 12, SP)             # end of the document
         a.mv(A1, A0)
         a.mv(A0, T0)
+        a.call("crc32")              # ... and the checksum it announced
+        a.mv(S2, A0)
+        a.lw(S0, 0, SP)
+        a.addi(A0, S0, 14)
+        a.call("ldu32")
+        crc_ok = fresh("crc_ok")
+        a.beq(A0, S2, crc_ok)
+        halt(11)
+        a.label(crc_ok)
+        a.la(A0, L["DOC"])
+        a.lw(A1, 12, SP)
         a.call("statement")
         a.lw(S0, 0, SP)
         a.lw(S1, 4, SP)
@@ -463,6 +544,74 @@ class Camt53:
         a.label("pem_closed")
         self.append_const(a, L, "PEM_END")
         epilogue(S0, S1, S2)
+
+        # ---- crc32(a0 = bytes, a1 = end) -> a0 (IEEE 802.3, as ZIP stores it)
+        a.label("crc32")
+        a.li(T0, -1)
+        a.la(T1, L["CRC_TABLE"])
+        a.label("crc_l")
+        a.beq(A0, A1, "crc_d")
+        a.lbu(T2, 0, A0)
+        a.xor(T2, T2, T0)
+        a.andi(T2, T2, 0xFF)
+        a.slli(T2, T2, 2)
+        a.add(T2, T1, T2)
+        a.lw(T2, 0, T2)
+        a.srli(T0, T0, 8)
+        a.xor(T0, T0, T2)
+        a.addi(A0, A0, 1)
+        a.j("crc_l")
+        a.label("crc_d")
+        a.not_(A0, T0)
+        a.ret()
+
+        # ---- b64_digest(a0 = 8 digest words, a1 = 44 characters out): base64 of the 32 digest bytes (ten triples, then two bytes and '=')
+        a.label("b64_digest")
+        a.la(T0, L["TMP16"])         # the bytes, most significant byte of each word first; TMP16 and the 16 bytes of KEY behind it
+        a.li(T1, 0)
+        a.label("b64d_bytes")
+        a.add(T2, A0, T1)
+        a.lw(T2, 0, T2)
+        a.add(T3, T0, T1)
+        for k, sh in enumerate((24, 16, 8, 0)):
+            a.srli(T4, T2, sh)
+            a.sb(T4, k, T3)
+        a.addi(T1, T1, 4)
+        a.li(T6, 32)
+        a.bne(T1, T6, "b64d_bytes")
+        a.la(T5, L["B64"])
+        a.li(T1, 0)
+        a.label("b64d_triple")
+        a.add(T2, T0, T1)
+        a.lbu(T3, 0, T2)
+        a.lbu(T4, 1, T2)
+        a.slli(T3, T3, 16)
+        a.slli(T4, T4, 8)
+        a.or_(T3, T3, T4)
+        a.li(T6, 30)
+        a.beq(T1, T6, "b64d_tail")   # the last group has two bytes: three characters and the pad
+        a.lbu(T4, 2, T2)
+        a.or_(T3, T3, T4)
+        for sh in (18, 12, 6, 0):
+            a.srli(T4, T3, sh)
+            a.andi(T4, T4, 63)
+            a.add(T4, T5, T4)
+            a.lbu(T4, 0, T4)
+            a.sb(T4, 0, A1)
+            a.addi(A1, A1, 1)
+        a.addi(T1, T1, 3)
+        a.j("b64d_triple")
+        a.label("b64d_tail")
+        for sh in (18, 12, 6):
+            a.srli(T4, T3, sh)
+            a.andi(T4, T4, 63)
+            a.add(T4, T5, T4)
+            a.lbu(T4, 0, T4)
+            a.sb(T4, 0, A1)
+            a.addi(A1, A1, 1)
+        a.li(T4, ord("="))
+        a.sb(T4, 0, A1)
+        a.ret()
 
         # ---- ldu16 / ldu32(a0 = any address) -> a0: little-endian loads byte by byte
         a.label("ldu16")
@@ -1220,10 +1369,19 @@ def build():
     return guest_rsa.build(extend=Camt53())
 
 
-def input_stream(iban, host_info, form=1, **rsa_inputs):
-    """the RSA guest's inputs, then the two strings the commitment opens with (host/src/main.rs:405-409: iban, host_info) and the
+def input_stream(iban, host_info, authenticated, form=1, e=65537, **x):
+    """the guest's input words, in the order it reads them: SignedInfo, the authenticated part, the operands of the three RSA operations
+    (as tools/guest_rsa.py takes them), the two strings the commitment opens with (host/src/main.rs:405-409: iban, host_info) and the
     commitment form (1: the current one with the three keys; 0: the earlier one of test.xml-Receipt-test.json)"""
-    return guest_rsa.input_stream(**rsa_inputs) + guest_rsa.message_frame(iban.encode()) + guest_rsa.message_frame(host_info.encode()) + [form]
+    limbs, frame = guest_rsa.limbs, guest_rsa.message_frame
+    words = frame(x["signed_info"]) + frame(authenticated) + limbs(int.from_bytes(x["bank_sig"], "big")) + limbs(x["bank_n"]) + [e]
+    words += limbs(int.from_bytes(x["tx_plain"], "big")) + limbs(x["client_n"]) + limbs(int.from_bytes(x["tx_cipher"], "big")) + [e]
+    words += frame(x["order_data"]) + limbs(int.from_bytes(x["witness_sig"], "big")) + limbs(x["witness_n"]) + [e]
+    return words + frame(iban.encode()) + frame(host_info.encode()) + [form]
+
+
+def reference_authenticated():
+    return open(os.path.join(ROOT, "tests", "golden", "camt53", "test.xml-authenticated"), "rb").read()
 
 
 REFERENCE_IBAN, REFERENCE_HOST_INFO = "CH4308307000289537312", "host:main"  # host/src/main.rs:452 TEST_IBAN; the host info of the reference's test run
@@ -1231,7 +1389,7 @@ REFERENCE_IBAN, REFERENCE_HOST_INFO = "CH4308307000289537312", "host:main"  # ho
 
 def elf_and_input(form=1):
     image, _, _ = build()
-    return image, input_stream(REFERENCE_IBAN, REFERENCE_HOST_INFO, form=form, **guest_rsa.reference_inputs()), (
+    return image, input_stream(REFERENCE_IBAN, REFERENCE_HOST_INFO, reference_authenticated(), form=form, **guest_rsa.reference_inputs()), (
         "the hyperfridge pipeline on the reference's EBICS fixture (tools/guest_camt53.py): SHA-256, three RSA-2048 public-key operations, AES-128-CBC, "
         "inflate, unzip, camt.053 field extraction; commits the journal of the reference's receipt fixture")
 

@@ -56,7 +56,8 @@ class Layout:
 
 def build(extend=None):
     """The ELF image, the assembler's labels and the memory layout.  `extend` (tools/guest_camt53.py) is an object with hooks
-    layout(L), after_operands(a, L, k) -- emitted when the operands of RSA operation k = 0, 1, 2 have been read --, main(a, L, fresh,
+    layout(L), after_signed_info(a, L, fresh, halt) -- emitted when SignedInfo has been hashed and is still in MSG --,
+    after_operands(a, L, k) -- emitted when the operands of RSA operation k = 0, 1, 2 have been read --, main(a, L, fresh,
     halt) -- emitted after the three RSA checks, before the commit of this file (which it replaces when it returns True) -- and
     library(a, L, fresh), emitted after the library of this file."""
     L = Layout()
@@ -141,6 +142,8 @@ def build(extend=None):
     # 1. the bank's signature over SHA-256(SignedInfo)
     read_message()
     hash_message("DIGEST")
+    if extend:
+        extend.after_signed_info(a, L, fresh, halt)  # SignedInfo is still in MSG, its length in LEN
     read_rsa_operands(False)
     if extend:
         extend.after_operands(a, L, 0)
