@@ -234,7 +234,7 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
   R0H_TRY(parse_blob(&circ, blob, blob_words));
   if (circ.n_global < 8) return done(R0H_RECEIPT_V_NO_BINDING, 0);
   const size_t n = rc->segments.size();
-  const bool trace_circuit = !memcmp(circ.info, "R0HIP_TRACE:v2__", 16);  // its seals also carry the first and last pc of the segment
+  const bool trace_circuit = !memcmp(circ.info, "R0HIP_TRACE:v3__", 16);  // its seals also carry the first and last pc of the segment
   for (size_t i = 0; i < n; i++)  // before any claim is read (the chain check below looks one segment ahead)
     if (!rc->segments[i].has_claim) return done(R0H_RECEIPT_V_NO_CLAIM, i);
   for (size_t i = 0; i < n; i++) {

@@ -47,6 +47,10 @@
 #include "trace.hpp"
 
 namespace {
+// Guest memory is the low 1 GiB: the trace circuit carries a pc as one field element and keeps registers above 2^28 word addresses
+// (R0H_REG_BASE); an access above it is a guest trap like a misaligned one.
+constexpr uint32_t ADDRESS_BITS = 30;
+static_assert(R0H_REG_BASE == 1u << (ADDRESS_BITS - 2), "registers sit right above the memory words");
 constexpr uint32_t PAGE_BYTES = 1024, PAGE_WORDS = PAGE_BYTES / 4, PAGE_SHIFT = 10, N_PAGE_BITS = 32 - PAGE_SHIFT;  // 2^22 pages
 constexpr uint64_t MAX_JOURNAL_BYTES = (uint64_t)1 << 28, MAX_IO_WORDS = (uint64_t)1 << 26;
 constexpr size_t MAX_RESIDENT_PAGES = (size_t)1 << 21;  // 2 GiB of guest memory: a run that wants more is refused, not swapped
@@ -268,6 +272,7 @@ struct Run {
   }
   bool load(uint32_t addr, uint32_t width, bool sign, uint32_t* out) {
     if (addr & (width - 1)) { err = "misaligned load"; return false; }
+    if (addr >> ADDRESS_BITS) { err = "load outside the 1 GiB address space"; return false; }
     uint32_t w;
     mem_access(addr & ~3u, false, 0, &w);
     const uint32_t sh = 8 * (addr & 3);
@@ -279,6 +284,7 @@ struct Run {
   }
   bool store(uint32_t addr, uint32_t width, uint32_t v) {
     if (addr & (width - 1)) { err = "misaligned store"; return false; }
+    if (addr >> ADDRESS_BITS) { err = "store outside the 1 GiB address space"; return false; }
     if (width == 4) { uint32_t old; mem_access(addr, true, v, &old); return true; }
     // a narrow store rewrites part of the word: the new word depends on the old one, read in the same access
     Page* p = page(addr & ~3u, true);
@@ -294,6 +300,7 @@ struct Run {
   bool step() {
     r0h_vm& m = vm;
     if (m.pc & 3) { err = "misaligned pc"; return false; }
+    if (m.pc >> ADDRESS_BITS) { err = "pc outside the 1 GiB address space"; return false; }
     // segment boundary: the next cycle, the pages it may bring in and write back (its own and one more) and the boundary rows of
     // what it may touch for the first time (three registers, one word, the fetched word) must still fit
     const uint64_t worst = (uint64_t)lim.page_in_cycles * 2 + lim.page_out_cycles + (lim.boundary_rows ? 5 : 0);
@@ -439,6 +446,7 @@ struct Run {
             }
             const uint32_t off = m.io_total - a1;
             uint32_t left;
+            if ((fn == 1 ? a0 + 4 * off : a0 + off) >> ADDRESS_BITS) { err = "ecall buffer outside the 1 GiB address space"; return false; }
             if (fn == 1) {
               uint32_t old;
               mem_access(a0 + 4 * off, true, m.input_pos < m.input.size() ? m.input[m.input_pos] : 0u, &old);
@@ -509,23 +517,36 @@ const Tables& trace_tables() {
     Tables t;
     memset(&t, 0, sizeof t);
     for (uint32_t i = 1; i < 32; i++) t.inv_small[i] = inv(enc(i));
-    for (int c = 0; c < 4; c++)
-      for (uint32_t op = 0; op < 128; op++) t.inv_op[c][op] = op == opcode_class(c) ? 0u : inv(sub(enc(op), enc(opcode_class(c))));
     return t;
   }();
   return T;
 }
-static const char* const COLUMN_NAMES[] = {
-    "live", "bnd", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi",
-    "bit0", "bit1", "bit2", "bit3", "bit4", "bit5", "bit6", "bit7", "bit8", "bit9", "bit10", "bit11", "bit12", "bit13", "bit14", "bit15",
-    "bit16", "bit17", "bit18", "bit19", "bit20", "bit21", "bit22", "bit23", "bit24", "bit25", "bit26", "bit27", "bit28", "bit29", "bit30", "bit31",
-    "is_jal", "is_jalr", "is_branch", "is_ecall", "inv_jal", "inv_jalr", "inv_branch", "inv_ecall",
-    "z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0",
-    "z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1",
-    "act2", "addr2", "inv_rd", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2",
-    "mem_kind", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "tw3",
-    "addr4", "p4", "tw4"};
-static_assert(sizeof COLUMN_NAMES / sizeof COLUMN_NAMES[0] == DIG0, "column names out of step with the enum");
+// the names tools/gen_circuit.py gives the columns (TRACE_COLUMNS), built the same way
+const char* column_name(uint32_t column) {
+  static const std::vector<std::string> names = [] {
+    std::vector<std::string> n;
+    auto run = [&](const char* stem, int count) { for (int k = 0; k < count; k++) n.push_back(stem + std::to_string(k)); };
+    for (const char* s : {"live", "bnd", "cycle", "pc", "next_pc", "insn_lo", "insn_hi"}) n.push_back(s);
+    run("bit", 32);
+    for (const char* s : {"lui", "auipc", "jal", "jalr", "branch", "load", "store", "imm", "op", "fence", "system"}) n.push_back(std::string("opc_") + s);
+    run("f3_", 8);
+    for (const char* s : {"alu", "mext", "z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0", "z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1",
+                          "zrd", "inv_rd", "act2", "addr2", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2",
+                          "mem_kind", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "tw3", "addr4", "p4", "tw4"})
+      n.push_back(s);
+    for (int k = 0; k < 5; k++) run(("d" + std::to_string(k) + "_").c_str(), 12);
+    run("ub", 32);
+    run("vb", 32);
+    run("zd", 16);
+    run("wd", 16);
+    for (const char* s : {"res_lo", "res_hi", "c0", "c1", "lt", "eq", "zinv", "ob0", "ob1", "sb", "sgn", "p8", "sx", "sm"}) n.push_back(s);
+    run("mb", 4);
+    run("cx", 4);
+    n.push_back("c3");
+    return n;
+  }();
+  return column < names.size() ? names[column].c_str() : nullptr;
+}
 }  // namespace trace
 }  // namespace r0h
 
@@ -706,17 +727,7 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
   *n = vm->segments[i].bounds.size();
   return nullptr;
 }
-const char* r0h_trace_column_name(uint32_t column) {
-  static char digit_names[60][8];
-  static bool ready = false;
-  if (column < trace::DIG0) return trace::COLUMN_NAMES[column];
-  if (column >= trace::N_COLS) return nullptr;
-  if (!ready) {
-    for (int k = 0; k < 60; k++) snprintf(digit_names[k], sizeof digit_names[k], "d%d_%d", k / 12, k % 12);
-    ready = true;
-  }
-  return digit_names[column - trace::DIG0];
-}
+const char* r0h_trace_column_name(uint32_t column) { return column < trace::N_COLS ? trace::column_name(column) : nullptr; }
 
 // The DATA group of the trace circuit on the host (the reference tests compare r0h_trace_witgen's device kernel with): cycles first,
 // then the boundary rows, blank rows to the end -- csrc/trace.hpp holds the expansion both sides compile.

@@ -7,7 +7,7 @@
 // every segment (system states from the run, exit code, the journal's output digest on the last one) is bound to its seal through
 // the public inputs (csrc/claim.cpp).
 //
-// With the trace circuit (circuits/trace.r0c, ProtocolInfo "R0HIP_TRACE:v2__") the seal of a segment attests THAT segment: the
+// With the trace circuit (circuits/trace.r0c, ProtocolInfo "R0HIP_TRACE:v3__") the seal of a segment attests THAT segment: the
 // executor keeps one compact row per cycle plus one per address touched, the device expands them into the DATA group
 // (csrc/trace.hip: 72 bytes per cycle cross PCIe, not the 576 bytes of an expanded row), and the proof is over those columns --
 // contiguity, control flow and memory consistency as include/r0hip.h lists them (what an instruction computes is risc0's rv32im
@@ -84,7 +84,7 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
                           uint64_t max_cycles, r0h_receipt** receipt_out, uint8_t image_id_out[32], uint64_t* cycles_out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && c && elf && receipt_out && (input_words || !n_input), "r0h_prove_elf: NULL argument");
-  const bool trace_mode = !memcmp(c->info, "R0HIP_TRACE:v2__", 16);
+  const bool trace_mode = !memcmp(c->info, "R0HIP_TRACE:v3__", 16);
   R0H_REQUIRE(segment_po2 >= 9 && segment_po2 <= (trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2), "r0h_prove_elf: segment_po2 %u outside [9, %u]", segment_po2,
               (unsigned)(trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2));
   R0H_REQUIRE(c->has_column_program, "r0h_prove_elf: the circuit has no column program (CODE columns, accumulation)");

@@ -1,12 +1,15 @@
 """The trace circuit (tools/gen_circuit.py trace, circuits/trace.r0c): a circuit whose DATA group IS the executor's preflight trace
 -- what the prover commits to comes from an execution, not from a synthetic column program.
 It constrains that the cycles form one contiguous run from the public first pc to the public last pc in the public number of
-cycles, that control flow follows the instruction words, and MEMORY CONSISTENCY over registers and memory as one address space
-(offline memory checking: a grand product over r0h_prefix_products in ACCUM, timestamps ordered through radix-4 digits in DATA):
-what is read from a register or a word -- an instruction word included -- is what was last written there.  What an instruction
-computes is risc0's rv32im circuit's business (its tap table and constraint polynomial cannot be reproduced here) and is not
-constrained.  The non-gpu tests prove with the oracle; both verifiers check.  The expansion of the compact rows into columns is
-restated here in numpy, independently of csrc/trace.hpp, and compared with the host reference and with the device kernel."""
+cycles, WHAT EVERY INSTRUCTION DOES (decode, ALU / shifter / multiplier results, branch decisions, jump targets, load / store
+addresses and the narrow accesses' byte lanes -- DIV / REM results and what an ecall reads and writes are range-checked only) and
+MEMORY CONSISTENCY over registers and memory as one address space (offline memory checking: a grand product over
+r0h_prefix_products in ACCUM, timestamps ordered through radix-4 digits in DATA): what is read from a register or a word -- an
+instruction word included -- is what was last written there.  It is this library's circuit for this library's executor, not
+risc0's rv32im circuit (whose tap table and constraint polynomial cannot be reproduced here).  The non-gpu tests prove with the
+oracle; both verifiers check.  The columns that come straight from the compact rows are restated here in numpy, independently of
+csrc/trace.hpp; the derived ones (operand bits, digits, carries) are checked by evaluating every constraint on the witness
+(tools/gen_circuit.py check_trace_rows names the constraint a witness breaks)."""
 import os
 import sys
 
@@ -18,7 +21,7 @@ from conftest import circuit_path
 from test_rv32im import _guest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-from gen_circuit import TRACE_COLUMNS  # noqa: E402
+from gen_circuit import OPCODES, TRACE_COLUMNS, check_trace_rows  # noqa: E402
 
 COL = {name: i for i, name in enumerate(TRACE_COLUMNS)}
 P = 2013265921
@@ -36,9 +39,16 @@ def _run(n_loop=60, po2=20):
     return vm, base
 
 
+PRIMARY = (["live", "bnd", "cycle", "pc", "next_pc", "insn_lo", "insn_hi"] + ["bit%d" % k for k in range(32)] + ["opc_" + n for n, _ in OPCODES]
+           + ["f3_%d" % k for k in range(8)] + ["z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0", "z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1"]
+           + ["zrd", "inv_rd", "act2", "addr2", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2", "mem_kind", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "tw3"]
+           + ["addr4", "p4", "tw4"] + ["d%d_%d" % (k, i) for k in (0, 1, 2, 4) for i in range(12)])
+
+
 def expand(rows, bounds, po2):
-    """The DATA group as canonical integers, [column, row], from the compact rows: the specification of include/r0hip.h
-    (r0h_preflight_row, r0h_preflight_bound, the trace-circuit paragraph) written out with numpy."""
+    """The columns of the DATA group that come straight from the compact rows (PRIMARY), as canonical integers, [column, row]: the
+    specification of include/r0hip.h (r0h_preflight_row, r0h_preflight_bound, the trace-circuit paragraph) written out with numpy.
+    (Access 3's digits are left out: rows that multiply keep carries there.)"""
     n, nr, nb = 1 << po2, len(rows), len(bounds)
     m = np.zeros((len(TRACE_COLUMNS), n), dtype=np.int64)
     inv = lambda v: pow(int(v) % P, P - 2, P)
@@ -49,17 +59,15 @@ def expand(rows, bounds, po2):
     m[COL["cycle"], L] = cyc
     m[COL["pc"], L] = r[:, F["pc"]]
     m[COL["next_pc"], L] = r[:, F["next_pc"]]
-    m[COL["is_seq"], L] = r[:, F["next_pc"]] == ((r[:, F["pc"]] + 4) & 0xFFFFFFFF)
     m[COL["insn_lo"], L] = insn & 0xFFFF
     m[COL["insn_hi"], L] = insn >> 16
     for k in range(32):
         m[COL["bit%d" % k], L] = (insn >> k) & 1
-    op = np.zeros(n, dtype=np.int64)
-    op[L] = insn & 0x7F
-    for name, code in (("jal", 0x6F), ("jalr", 0x67), ("branch", 0x63), ("ecall", 0x73)):
-        m[COL["is_" + name]] = (op == code) & (np.arange(n) < nr)
-        table = np.array([0 if o == code else inv(o - code) for o in range(128)], dtype=np.int64)
-        m[COL["inv_" + name]] = table[op]  # every row: a blank row carries opcode 0
+    for name, code in OPCODES:
+        m[COL["opc_" + name], L] = (insn & 0x7F) == code
+    m[COL["f3_0"]] = 1
+    for k in range(8):
+        m[COL["f3_%d" % k], L] = ((insn >> 12) & 7) == k
     small = np.array([0] + [inv(i) for i in range(1, 32)], dtype=np.int64)
     for k, (z, iv, act, addr, lo, hi, p, tw, shift, val) in enumerate((("z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0", 15, "rs1"),
                                                                       ("z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1", 20, "rs2"))):
@@ -74,6 +82,8 @@ def expand(rows, bounds, po2):
         m[COL[addr], L] = np.where(on, REG + idx, 0)
         m[COL[p], L] = np.where(on, r[:, F["prev"] + k], 0)
         m[COL[tw], L] = np.where(on, 5 * cyc + k + 1, 0)
+    m[COL["zrd"]] = 1
+    m[COL["zrd"], L] = ((insn >> 7) & 31) == 0
     m[COL["inv_rd"], L] = small[(insn >> 7) & 31]
     wr = r[:, F["rd"]] != 0
     m[COL["act2"], L] = wr
@@ -94,7 +104,7 @@ def expand(rows, bounds, po2):
     m[COL["addr4"], L] = r[:, F["pc"]] >> 2
     m[COL["p4"], L] = r[:, F["prev"] + 4]
     m[COL["tw4"], L] = 5 * cyc + 5
-    for k in range(5):
+    for k in (0, 1, 2, 4):
         diff = np.where(m[COL["tw%d" % k], L] > 0, m[COL["tw%d" % k], L] - m[COL["p%d" % k], L] - 1, 0)
         assert (diff >= 0).all() and (diff < 1 << 24).all()
         for i in range(12):
@@ -107,17 +117,38 @@ def expand(rows, bounds, po2):
         m[COL["after_lo"], B], m[COL["after_hi"], B] = bb[:, 1] & 0xFFFF, bb[:, 1] >> 16     # written: the value found, timestamp 0
         m[COL["before_lo"], B], m[COL["before_hi"], B] = bb[:, 2] & 0xFFFF, bb[:, 2] >> 16   # read: the value left, at its last timestamp
         m[COL["p3"], B] = bb[:, 3]
+        assert (bb[:, 0] < (1 << 28) + 32).all()
+        top = bb[:, 0] >> 28                                                                 # the address: fourteen digits and the register bit
+        low = bb[:, 0] - (top << 28)
+        for i in range(14):
+            m[COL["d%d_%d" % (i // 12, i % 12)], B] = (low >> (2 * i)) & 3
+        m[COL["d1_2"], B] = top
         gap = np.concatenate([[0], bb[1:, 0] - bb[:-1, 0] - 1])
-        assert (gap >= 0).all()
-        for i in range(12):
-            m[COL["d3_%d" % i], B] = (gap >> (2 * i)) & 3
-        for i in range(4):
+        assert (gap >= 0).all() and (gap < 1 << 30).all()
+        for i in range(3):
             m[COL["d2_%d" % i], B] = (gap >> (2 * (12 + i))) & 3
     return m
 
 
 def montgomery(m):
     return ((m.astype(object) << 32) % P).astype(np.uint32)
+
+
+R_INV = pow(1 << 32, P - 2, P)
+
+
+def canonical(words, po2):
+    """witness words (Montgomery form, column-major) -> [column, row] canonical integers"""
+    return (words.reshape(len(TRACE_COLUMNS), 1 << po2).astype(np.int64) * R_INV) % P
+
+
+def broken(vm, k, po2, edits=()):
+    """names of the constraints the witness of segment k breaks, after `edits` [(column, row, canonical value)]"""
+    data, glob = vm.trace_witness(k, po2)
+    m = canonical(data, po2)
+    for c, r, v in edits:
+        m[COL[c], r] = v % P
+    return [name for name, _ in check_trace_rows(m, [int(g) * R_INV % P for g in glob])]
 
 
 def test_column_list_is_the_one_the_library_fills():
@@ -130,9 +161,11 @@ def test_the_witness_is_the_preflight_trace(orc):
     n, po2 = len(rows), 10
     assert 256 < n and n + len(bounds) <= 1 << po2 and len(bounds) == vm.segments()[0].boundary_rows
     data, glob = vm.trace_witness(0, po2)
-    want = expand(rows, bounds, po2)
+    want = montgomery(expand(rows, bounds, po2))
     got = data.reshape(r0.TRACE_COLUMNS, 1 << po2)
-    assert np.array_equal(got, montgomery(want)), [TRACE_COLUMNS[c] for c in np.nonzero((got != montgomery(want)).any(axis=1))[0]]
+    primary = [COL[c] for c in PRIMARY]
+    assert np.array_equal(got[primary], want[primary]), [TRACE_COLUMNS[c] for c in primary if (got[c] != want[c]).any()]
+    assert broken(vm, 0, po2) == []  # ... and the derived columns satisfy every constraint
     assert [orc.dec(int(g)) for g in glob] == [0] * 8 + [base, int(rows[-1, F["next_pc"]]), n]
     # the rows themselves: timestamps name the previous access, boundary rows are each address once, in order, with what was found and left
     last, value = {}, {}
@@ -211,12 +244,12 @@ def test_an_execution_proves_and_an_altered_one_does_not(orc):
     assert c.verify(s, code_root=root)[0] != 0
     # control flow follows the instruction words
     br = next(r for r, w in enumerate(rows) if (w.insn & 0x7f) == 0x63 and w.next_pc != w.pc + 4)   # a taken branch
-    assert rejected(edit(("is_branch", br, 0)), glob)                  # ... cannot pass as an ordinary instruction
+    assert rejected(edit(("opc_branch", br, 0)), glob)                 # ... cannot pass as an ordinary instruction
     assert rejected(edit(("bit0", br, 0)), glob)                       # ... nor can its word be changed under it (halves and opcode pin the bits)
     assert rejected(edit(("next_pc", br, rows[br].pc + 8), ("pc", br + 1, rows[br].pc + 8), ("addr4", br + 1, (rows[br].pc + 8) >> 2)), glob)  # nor go elsewhere
     alu = next(r for r, w in enumerate(rows) if (w.insn & 0x7f) == 0x13 and r > 4)
-    assert rejected(edit(("next_pc", alu, rows[alu].pc + 8), ("is_seq", alu, 0), ("pc", alu + 1, rows[alu].pc + 8)), glob)  # an ALU instruction that skips the next one
-    assert rejected(edit(("is_jal", alu, 1)), glob)                    # ... and cannot be flagged as a jump to get away with it
+    assert rejected(edit(("next_pc", alu, rows[alu].pc + 8), ("pc", alu + 1, rows[alu].pc + 8)), glob)  # an ALU instruction that skips the next one
+    assert rejected(edit(("opc_jal", alu, 1)), glob)                   # ... and cannot be flagged as a jump to get away with it
     io = next(r for r, w in enumerate(rows) if w.insn == 0x73 and w.next_pc == w.pc)  # an I/O ecall repeating: to pc or pc + 4, nowhere else
     assert rejected(edit(("next_pc", io, rows[io].pc + 8), ("pc", io + 1, rows[io].pc + 8)), glob)
 
@@ -248,11 +281,10 @@ def test_an_execution_proves_and_an_altered_one_does_not(orc):
     assert rejected(edit(("p3", b0, bounds[3].last_ts + 5)), glob)
     assert rejected(edit(("addr3", b0, bounds[2].addr)), glob)                     # an address twice among the boundary rows (two histories)
     assert rejected(edit(("bnd", b0, 0)), glob)                                    # a boundary row dropped
-    # what the circuit does not see, by design: what an instruction computes.  A consistent lie -- the value an instruction writes
-    # changed together with every later sight of it, up to the register's next write or its boundary row -- is accepted: the
-    # statement proved is "memory is consistent", not "the ALU computed this" (risc0's rv32im circuit)
+    # a consistent lie about what an instruction computed -- the value written changed together with its result column and with every
+    # later sight of it, up to the register's next write or its boundary row: memory stays consistent, the instruction does not
     lie = (rows[w_row].rd_after & 0xffff) ^ 1
-    chain = [("new_lo", w_row, lie)]
+    chain = [("new_lo", w_row, lie), ("res_lo", w_row, lie)]
     r = w_row
     while True:  # every later sight of that register value up to its next write
         nxt = [q for q in range(r + 1, n) if ((rows[q].insn >> 15) & 31) == reg or ((rows[q].insn >> 20) & 31) == reg or rows[q].rd == reg]
@@ -267,7 +299,66 @@ def test_an_execution_proves_and_an_altered_one_does_not(orc):
         if rows[r].rd == reg:
             chain.append(("old_lo", r, lie))
             break
-    assert not rejected(edit(*chain), glob)
+    assert rejected(edit(*chain), glob)
+
+
+def forged_result(r, value, word="z"):
+    """the edits of a prover that claims instruction r wrote `value`: the register's new value, the result columns and the
+    range-checked word the result is read from (Z or W) with everything the always-on definitions derive from it"""
+    lo, hi = value & 0xFFFF, value >> 16
+    edits = [("new_lo", r, lo), ("new_hi", r, hi), ("res_lo", r, lo), ("res_hi", r, hi)]
+    edits += [("%sd%d" % (word, i), r, (value >> (2 * i)) & 3) for i in range(16)]
+    if word == "z":
+        edits += [("ob0", r, value & 1), ("ob1", r, (value >> 1) & 1), ("eq", r, int(value == 0)), ("zinv", r, pow(lo + hi, P - 2, P) if value else 0)]
+    return edits
+
+
+def test_what_an_instruction_computes_is_constrained_kind_by_kind(orc):
+    """Random programs over every RV32IM instruction kind (tools/soak_trace.py): the genuine witness satisfies every constraint,
+    and for each kind that writes a register the most careful lie available -- another value written, the result columns and the
+    range-checked word changed with it -- breaks a constraint that belongs to that instruction's unit.  Stores: another word
+    written.  Branches: the other way taken.  (DIV / REM and ecall rows are the two kinds whose result is range-checked only.)"""
+    from soak_trace import random_program
+    rng = np.random.default_rng(21)
+    seen = {}
+    for trial in range(6):
+        vm = r0.Vm()
+        vm.load(0x1000, random_program(rng, 350))
+        vm.set_pc(0x1000)
+        for i in range(1, 28):
+            vm.set_reg(i, int(rng.integers(0, 1 << 32)) if rng.random() < 0.7 else int(rng.choice([0, 1, 0xFFFFFFFF, 0x80000000])))
+        vm.set_input([int(x) for x in rng.integers(0, 1 << 32, 8)])
+        assert vm.run(segment_po2=20, keep_trace=True, boundary_rows=True, max_cycles=50_000) == (0, 0)
+        seg = vm.segments()[0]
+        po2 = max(9, int(np.ceil(np.log2(seg.user_cycles + seg.boundary_rows))))
+        assert broken(vm, 0, po2) == []
+        rows = vm.preflight(0)
+        for r, w in enumerate(rows):
+            op, f3, f7 = w.insn & 0x7F, (w.insn >> 12) & 7, w.insn >> 25
+            kind = (op, f3, f7 if op == 0x33 else (f7 & 0x20) if (op == 0x13 and f3 == 5) else 0)
+            if kind in seen or r == len(rows) - 1:
+                continue
+            if w.rd:
+                from_w = op in (0x6F, 0x67) or (op in (0x13, 0x33) and f3 == 5 and f7 != 1) or (op == 0x33 and f7 == 1 and f3 in (1, 2, 3))
+                bad = broken(vm, 0, po2, forged_result(r, w.rd_after ^ 0x10, "w" if from_w else "z"))
+                free = op == 0x73 or (op == 0x33 and f7 == 1 and f3 >= 4)
+                assert (bad == []) == free, (hex(w.insn), bad)
+                if not free:
+                    assert not any(name.startswith(("rd:", "run:", "accum", "bit:", "digit:")) for name in bad), (hex(w.insn), bad)
+                seen[kind] = bad
+            elif op == 0x23:
+                bad = broken(vm, 0, po2, [("after_lo", r, (w.mem_after & 0xFFFF) ^ 0x100)])
+                assert bad and all(name.startswith(("sb:", "sh:", "sw:")) for name in bad), (hex(w.insn), bad)
+                seen[kind] = bad
+            elif op == 0x63:
+                other = w.pc + 4 if w.next_pc != w.pc + 4 else (w.pc + 8) & 0xFFFFFFFF
+                bad = broken(vm, 0, po2, [("next_pc", r, other), ("pc", r + 1, other), ("addr4", r + 1, other >> 2)])
+                assert "next:branch" in bad, (hex(w.insn), bad)
+                seen[kind] = bad
+    ops = {k[0] for k in seen}
+    assert {0x37, 0x17, 0x6F, 0x67, 0x63, 0x03, 0x23, 0x13, 0x33, 0x73} <= ops and len(seen) >= 50, sorted(seen)
+    assert {(0x33, f3, 1) for f3 in range(8)} <= set(seen) and {(0x33, 0, 0x20), (0x33, 5, 0x20), (0x13, 5, 0x20), (0x13, 1, 0)} <= set(seen)
+    assert {(0x03, f3, 0) for f3 in (0, 1, 2, 4, 5)} | {(0x23, f3, 0) for f3 in range(3)} | {(0x63, f3, 0) for f3 in (0, 1, 4, 5, 6, 7)} <= set(seen)
 
 
 def test_jumps_and_branches_of_every_kind_satisfy_the_control_flow_constraints(orc):

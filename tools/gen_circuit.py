@@ -13,7 +13,7 @@ Shapes:
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
   recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
-  trace  W=(16, 4, 144)                     columns = the executor's preflight rows; one contiguous run, control flow per the words, memory consistency
+  trace  W=(16, 4, 276)                     columns = the executor's preflight rows; one contiguous run, every instruction's semantics, memory consistency
 """
 import argparse
 import struct
@@ -248,30 +248,435 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
 
 # ---- the trace circuit: columns ARE the executor's preflight rows (include/r0hip.h: r0h_preflight_row / r0h_preflight_bound;
 # csrc/trace.hpp holds the same column list and the expansion of a row into it) ---------------------------------------------------
-# Not the rv32im circuit (risc0's constrains every instruction's semantics; that tap table and polynomial are not reproducible
-# here).  This one constrains
+# Stands where risc0's rv32im circuit stands; it is NOT that circuit (its tap table and polynomial are machine-generated and not
+# reproducible here) but one written for this library's executor.  It constrains
 #   * that the cycles form ONE contiguous run from the public first pc to the public last pc in the public number of cycles;
-#   * that control flow follows the instruction words (it leaves the sequential path only at JAL / JALR / branch / ecall words, JAL
-#     and branches go where their immediates say, an ecall to pc or pc + 4);
+#   * WHAT EVERY INSTRUCTION DOES: the word is decoded (one-hot opcode and funct3, illegal encodings have no satisfying row); the
+#     value written to rd, the word written to memory, the address of a load / store and the next pc are the ones RV32IM
+#     prescribes for the operands read.  Units: a 32-bit adder over 16-bit halves (ADD / ADDI / AUIPC / address generation / JALR
+#     target; run backwards for SUB, SLT[I][U] and the six branches), bit-sliced logic over the decomposed operands, a byte-limb
+#     multiplier with a range-checked carry chain (MUL / MULH / MULHSU / MULHU, and the shifts as products with 2^s resp. 2^(32-s),
+#     the sign of MULH* / SRA folded into the chain), byte / half selection for the narrow loads and stores.  Every word written
+#     is range-checked (radix-4 digits) or composed of range-checked parts.  Not yet constrained: DIV / DIVU / REM / REMU results
+#     and what an ecall row reads and writes (both are range-checked only) -- DESIGN.md 4;
 #   * MEMORY CONSISTENCY over registers and memory as one address space, by offline memory checking: each of a cycle's five
 #     accesses (x[rs1], x[rs2], x[rd], the memory word, the fetched word) reads the tuple (address, value, timestamp) that the
 #     previous access to the address wrote and writes a new one with a larger timestamp (the difference is range-checked through
-#     radix-4 digits); boundary rows, one per address in strictly increasing order, write the first tuple (timestamp 0) and read
-#     the last.  Multiset equality of tuples read and written is a grand product in ACCUM (four running products over fingerprints
+#     radix-4 digits); boundary rows, one per address in strictly increasing order (addresses below 2^28 + 32: 1 GiB of memory and
+#     the registers above it), write the first tuple (timestamp 0) and read the last.  Multiset equality of tuples read and written is a grand product in ACCUM (four running products over fingerprints
 #     alpha - addr - b1 lo - b2 hi - b3 t with alpha, b1..b3 drawn after DATA is committed), compared on the last row.
 # Public inputs: 8 words naming the segment's ReceiptClaim, first pc, pc after the last cycle, number of cycles.
-TRACE_COLUMNS = (["live", "bnd", "cycle", "pc", "next_pc", "is_seq", "insn_lo", "insn_hi"]
+OPCODES = [("lui", 0x37), ("auipc", 0x17), ("jal", 0x6F), ("jalr", 0x67), ("branch", 0x63), ("load", 0x03), ("store", 0x23), ("imm", 0x13),
+           ("op", 0x33), ("fence", 0x0F), ("system", 0x73)]
+TRACE_COLUMNS = (["live", "bnd", "cycle", "pc", "next_pc", "insn_lo", "insn_hi"]
                  + ["bit%d" % k for k in range(32)]                                                   # the instruction word, bit by bit
-                 + ["is_jal", "is_jalr", "is_branch", "is_ecall", "inv_jal", "inv_jalr", "inv_branch", "inv_ecall"]  # opcode classes, pinned by inverses
+                 + ["opc_" + name for name, _ in OPCODES]                                             # one-hot opcode
+                 + ["f3_%d" % k for k in range(8)]                                                    # one-hot funct3
+                 + ["alu", "mext"]                                                                    # OP-IMM or base-ISA OP; M-extension OP
                  + ["z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0"]                   # access 0: x[rs1] read
                  + ["z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1"]                   # access 1: x[rs2] read
-                 + ["act2", "addr2", "inv_rd", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2"]  # access 2: x[rd] write
+                 + ["zrd", "inv_rd", "act2", "addr2", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2"]  # access 2: x[rd] write
                  + ["mem_kind", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "tw3"]  # access 3: memory word / boundary row
                  + ["addr4", "p4", "tw4"]                                                             # access 4: instruction fetch
-                 + ["d%d_%d" % (k, i) for k in range(5) for i in range(12)])                          # radix-4 digits of (own - previous - 1)
+                 + ["d%d_%d" % (k, i) for k in range(5) for i in range(12)]                           # radix-4 digits of (own - previous - 1)
+                 + ["ub%d" % k for k in range(32)]                                                    # operand U bit by bit: x[rs1], or the memory word of a load / store
+                 + ["vb%d" % k for k in range(32)]                                                    # operand V: x[rs2] or the I-immediate
+                 + ["zd%d" % k for k in range(16)]                                                    # word Z in radix-4 digits: sum / difference / low product word
+                 + ["wd%d" % k for k in range(16)]                                                    # word W: high product word, link, pc
+                 + ["res_lo", "res_hi", "c0", "c1", "lt", "eq", "zinv", "ob0", "ob1", "sb", "sgn", "p8", "sx", "sm"]
+                 + ["mb%d" % k for k in range(4)]                                                     # second multiplier operand, byte limbs
+                 + ["cx%d" % k for k in range(4)] + ["c3"])                                           # carry digits beyond access 3's twelve; top carry
 TRACE_GLOBALS = 11   # claim words 0..7, first pc, pc after the last cycle, cycles
-REG_BASE = 1 << 30
+REG_BASE = 1 << 28   # registers sit above 2^28 words = 1 GiB of memory
 SEC_ACCUM_FP = 8
+
+
+class E:
+    """A base-field expression under construction: a Builder variable, its degree in the trace columns, its value if constant."""
+    __slots__ = ("b", "v", "deg", "k")
+
+    def __init__(self, b, v, deg, k=None):
+        self.b, self.v, self.deg, self.k = b, v, deg, k
+
+    @staticmethod
+    def of(b, x):
+        return x if isinstance(x, E) else E(b, b.const(x % P), 0, x % P)
+
+    def __add__(self, o):
+        o = E.of(self.b, o)
+        if o.k == 0:
+            return self
+        if self.k == 0:
+            return o
+        if self.k is not None and o.k is not None:
+            return E.of(self.b, self.k + o.k)
+        return E(self.b, self.b.add(self.v, o.v), max(self.deg, o.deg))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        o = E.of(self.b, o)
+        if o.k == 0:
+            return self
+        if self.k is not None and o.k is not None:
+            return E.of(self.b, self.k - o.k)
+        return E(self.b, self.b.sub(self.v, o.v), max(self.deg, o.deg))
+
+    def __rsub__(self, o):
+        return E.of(self.b, o) - self
+
+    def __mul__(self, o):
+        o = E.of(self.b, o)
+        if self.k is not None and o.k is not None:
+            return E.of(self.b, self.k * o.k)
+        for x, y in ((self, o), (o, self)):
+            if x.k == 1:
+                return y
+            if x.k == 0:
+                return x
+        return E(self.b, self.b.mul(self.v, o.v), self.deg + o.deg)
+
+    __rmul__ = __mul__
+
+
+def lin(b, terms):
+    acc = E.of(b, 0)
+    for coeff, v in terms:
+        acc = acc + coeff * v
+    return acc
+
+
+def trace_constraints():
+    """-> (Builder, [(name, fp var, degree, touches ACCUM)], products): every polynomial that must vanish on every row of a trace"""
+    col = {name: i for i, name in enumerate(TRACE_COLUMNS)}
+    n_data, n_code, n_acc = len(TRACE_COLUMNS), 4, 4
+    b = Builder()
+    for g, size in ((G_ACCUM, 4 * n_acc), (G_CODE, n_code), (G_DATA, n_data)):
+        for c in range(size):
+            b.taps.add((g, c, 0))
+    cons = []
+
+    def d(name, back=0):
+        return E(b, b.get(G_DATA, col[name], back), 1)
+
+    def C(name, e, accum=False):
+        assert e.deg <= 5, (name, e.deg)
+        cons.append((name, e.v, e.deg, accum))
+
+    def bit(v, name):
+        C("bit:" + name, v * (v - 1))
+
+    def digit(v, name):
+        C("digit:" + name, v * (v - 1) * ((v - 2) * (v - 3)))
+
+    first, last = E(b, b.get(G_CODE, 0, 0), 1), E(b, b.get(G_CODE, 1, 0), 1)
+    not_first = 1 - first
+    live, prev_live, bnd, prev_bnd = d("live"), d("live", 1), d("bnd"), d("bnd", 1)
+    not_live = 1 - live
+    pc, next_pc, cycle = d("pc"), d("next_pc"), d("cycle")
+    # --- the run: live rows first, then boundary rows, then blank rows
+    bit(live, "live")
+    bit(bnd, "bnd")
+    C("live.bnd", live * bnd)
+    gate = not_first * live                                             # a live row that has a predecessor
+    C("run:pc", gate * (pc - d("next_pc", 1)))                         # ... starts where that one went
+    C("run:cycle", gate * (cycle - d("cycle", 1) - 1))                 # ... one cycle later
+    C("run:after_live", gate * (1 - prev_live))                        # ... and follows a live row
+    C("run:bnd_after", not_first * bnd * (1 - prev_live - prev_bnd))   # a boundary row follows a live or a boundary row
+    for name in ("pc", "next_pc", "cycle", "mem_kind", "act2"):        # rows that are not cycles carry none of these
+        C("idle:" + name, not_live * d(name))
+    # --- decoding
+    bits = [d("bit%d" % k) for k in range(32)]
+    for k, bk in enumerate(bits):
+        bit(bk, "bit%d" % k)
+    C("insn_lo", d("insn_lo") - lin(b, [(1 << k, bits[k]) for k in range(16)]))
+    C("insn_hi", d("insn_hi") - lin(b, [(1 << k, bits[16 + k]) for k in range(16)]))
+    opc = {name: d("opc_" + name) for name, _ in OPCODES}
+    for name, v in opc.items():
+        bit(v, "opc_" + name)
+    C("opc:one", lin(b, [(1, v) for v in opc.values()]) - live)
+    C("opc:code", lin(b, [(code, opc[name]) for name, code in OPCODES]) - lin(b, [(1 << k, bits[k]) for k in range(7)]))
+    f3 = [d("f3_%d" % k) for k in range(8)]
+    for k, v in enumerate(f3):
+        bit(v, "f3_%d" % k)
+    C("f3:one", lin(b, [(1, v) for v in f3]) - 1)
+    C("f3:code", lin(b, [(k, f3[k]) for k in range(8)]) - (bits[12] + 2 * bits[13] + 4 * bits[14]))
+    alu, mext = d("alu"), d("mext")
+    C("alu", alu - (opc["imm"] + opc["op"] * (1 - bits[25])))
+    C("mext", mext - opc["op"] * bits[25])
+    for k in (26, 27, 28, 29, 31):
+        C("op:f7_%d" % k, opc["op"] * bits[k])
+    C("op:f7_m_alt", opc["op"] * bits[25] * bits[30])
+    C("op:f7_alt", opc["op"] * bits[30] * (1 - f3[0] - f3[5]))
+    for k in range(25, 32):
+        C("slli:f7_%d" % k, opc["imm"] * f3[1] * bits[k])
+        if k != 30:
+            C("srxi:f7_%d" % k, opc["imm"] * f3[5] * bits[k])
+    C("jalr:f3", opc["jalr"] * (1 - f3[0]))
+    C("branch:f3", opc["branch"] * (f3[2] + f3[3]))
+    C("load:f3", opc["load"] * (f3[3] + f3[6] + f3[7]))
+    C("store:f3", opc["store"] * (1 - f3[0] - f3[1] - f3[2]))
+    C("system:lo", opc["system"] * (d("insn_lo") - 0x73))              # ecall is the one SYSTEM word that runs
+    C("system:hi", opc["system"] * d("insn_hi"))
+    sign = bits[31]
+    immi = [lin(b, [(1 << (k - 20), bits[k]) for k in range(20, 31)]) + 0xF800 * sign, 0xFFFF * sign]   # sign-extended, as two halves
+    imms = [lin(b, [(1 << (k - 7), bits[k]) for k in range(7, 12)] + [(1 << (k - 20), bits[k]) for k in range(25, 31)]) + 0xF800 * sign, 0xFFFF * sign]
+    immu = [lin(b, [(1 << k, bits[k]) for k in range(12, 16)]), d("insn_hi")]
+    imm_j = lin(b, [(-(1 << 20), bits[31])] + [(1 << k, bits[k]) for k in range(12, 20)] + [(1 << 11, bits[20])] + [(1 << (k - 20), bits[k]) for k in range(21, 31)])
+    imm_b = lin(b, [(-(1 << 12), bits[31]), (1 << 11, bits[7])] + [(1 << (k - 20), bits[k]) for k in range(25, 31)] + [(1 << (k - 7), bits[k]) for k in range(8, 12)])
+    # --- the words the units work on
+    ub, vb = [d("ub%d" % k) for k in range(32)], [d("vb%d" % k) for k in range(32)]
+    for k in range(32):
+        bit(ub[k], "ub%d" % k)
+        bit(vb[k], "vb%d" % k)
+    zd, wd = [d("zd%d" % k) for k in range(16)], [d("wd%d" % k) for k in range(16)]
+    for k in range(16):
+        digit(zd[k], "zd%d" % k)
+        digit(wd[k], "wd%d" % k)
+    halves = lambda digs: [lin(b, [(4 ** i, digs[i]) for i in range(8)]), lin(b, [(4 ** i, digs[8 + i]) for i in range(8)])]
+    u = [lin(b, [(1 << k, ub[k]) for k in range(16)]), lin(b, [(1 << k, ub[16 + k]) for k in range(16)])]
+    v = [lin(b, [(1 << k, vb[k]) for k in range(16)]), lin(b, [(1 << k, vb[16 + k]) for k in range(16)])]
+    z, w = halves(zd), halves(wd)
+    a = [d("rs1_lo"), d("rs1_hi")]
+    rs2 = [d("rs2_lo"), d("rs2_hi")]
+    before, after = [d("before_lo"), d("before_hi")], [d("after_lo"), d("after_hi")]
+    res = [d("res_lo"), d("res_hi")]
+    is_mem = opc["load"] + opc["store"]
+    use_b, use_i = opc["op"] + opc["branch"] + opc["store"], opc["imm"] + opc["load"] + opc["jalr"]
+    for h, nm in enumerate(("lo", "hi")):
+        C("u:" + nm, u[h] - (is_mem * before[h] + (1 - is_mem) * a[h]))      # U: the word of a load / store, x[rs1] otherwise
+        C("v:" + nm, v[h] - (use_b * rs2[h] + use_i * immi[h]))               # V: x[rs2] or the I-immediate
+    c0, c1, lt, eq, zinv, ob0, ob1 = d("c0"), d("c1"), d("lt"), d("eq"), d("zinv"), d("ob0"), d("ob1")
+    for nm, x in (("c0", c0), ("c1", c1), ("lt", lt), ("eq", eq), ("ob0", ob0), ("ob1", ob1)):
+        bit(x, nm)
+    C("z:low_bits", zd[0] - ob0 - 2 * ob1)
+    C("eq:zero", eq * (z[0] + z[1]))                                    # eq = 1 iff Z = 0 (both halves are 16-bit: no wrap)
+    C("eq:inv", (z[0] + z[1]) * zinv - (1 - eq))
+    differ = ub[31] + vb[31] - 2 * ub[31] * vb[31]
+    C("lt", lt - (differ * ub[31] + (1 - differ) * c1))                 # signed U < V given the borrow c1 of U - V
+    # --- the adder: X + Y = Z + 2^32 carry (halves, two carry bits), or backwards: Y + Z = X + 2^32 borrow
+    sub_rr = alu * f3[0] * (opc["op"] * bits[30])
+    sel_add = opc["jalr"] + opc["load"] + alu * f3[0] - sub_rr
+    sel_sub = opc["branch"] + alu * (f3[2] + f3[3]) + sub_rr
+    C("add:lo", sel_add * (a[0] + v[0] - z[0] - 65536 * c0))
+    C("add:hi", sel_add * (a[1] + v[1] + c0 - z[1] - 65536 * c1))
+    C("store:addr_lo", opc["store"] * (a[0] + imms[0] - z[0] - 65536 * c0))
+    C("store:addr_hi", opc["store"] * (a[1] + imms[1] + c0 - z[1] - 65536 * c1))
+    C("auipc:pc", opc["auipc"] * (w[0] + 65536 * w[1] - pc))
+    C("auipc:lo", opc["auipc"] * (w[0] + immu[0] - z[0] - 65536 * c0))
+    C("auipc:hi", opc["auipc"] * (w[1] + immu[1] + c0 - z[1] - 65536 * c1))
+    C("sub:lo", sel_sub * (v[0] + z[0] - a[0] - 65536 * c0))
+    C("sub:hi", sel_sub * (v[1] + z[1] + c0 - a[1] - 65536 * c1))
+    # --- control flow
+    link = opc["jal"] + opc["jalr"]
+    C("next:plain", (live - link - opc["branch"] - opc["system"]) * (next_pc - pc - 4))
+    C("next:jal", opc["jal"] * (next_pc - pc - imm_j))
+    C("next:jalr", opc["jalr"] * (next_pc - (z[0] + 65536 * z[1] - ob0)))
+    C("jalr:range", opc["jalr"] * zd[15])                               # targets stay below 2^30: the pc is a field element
+    C("jalr:aligned", opc["jalr"] * ob1)
+    taken = f3[0] * eq + f3[1] * (1 - eq) + f3[4] * lt + f3[5] * (1 - lt) + f3[6] * c1 + f3[7] * (1 - c1)
+    C("next:branch", opc["branch"] * (next_pc - pc - 4 - taken * (imm_b - 4)))
+    step = next_pc - pc
+    C("next:ecall", opc["system"] * step * (step - 4))                  # an I/O ecall repeats (pc) or completes (pc + 4)
+    C("link", link * (w[0] + 65536 * w[1] - pc - 4))
+    # --- loads and stores
+    C("mem:kind", (1 - opc["system"]) * (d("mem_kind") - opc["load"] - 2 * opc["store"]))
+    C("mem:addr", is_mem * (4 * d("addr3") + zd[0] - z[0] - 65536 * z[1]))
+    C("mem:range", is_mem * zd[15])                                     # 1 GiB of memory
+    narrow_h = opc["load"] * (f3[1] + f3[5]) + opc["store"] * f3[1]
+    word = (opc["load"] + opc["store"]) * f3[2]
+    C("mem:aligned_h", narrow_h * ob0)
+    C("mem:aligned_w", word * (ob0 + ob1))
+    sel_byte = [(1 - ob0) * (1 - ob1), ob0 * (1 - ob1), (1 - ob0) * ob1, ob0 * ob1]
+    ubyte = [lin(b, [(1 << i, ub[8 * k + i]) for i in range(8)]) for k in range(4)]
+    vbyte = [lin(b, [(1 << i, vb[8 * k + i]) for i in range(8)]) for k in range(4)]
+    sb, sgn = d("sb"), d("sgn")
+    C("sb", sb - lin(b, [(1, sel_byte[k] * ubyte[k]) for k in range(4)]))
+    C("sgn", sgn - lin(b, [(1, sel_byte[k] * ub[8 * k + 7]) for k in range(4)]))
+    sh = (1 - ob1) * u[0] + ob1 * u[1]
+    sgnh = (1 - ob1) * ub[15] + ob1 * ub[31]
+    ld = opc["load"]
+    C("lb:lo", ld * f3[0] * (res[0] - sb - 0xFF00 * sgn))
+    C("lb:hi", ld * f3[0] * (res[1] - 0xFFFF * sgn))
+    C("lh:lo", ld * f3[1] * (res[0] - sh))
+    C("lh:hi", ld * f3[1] * (res[1] - 0xFFFF * sgnh))
+    C("lw:lo", ld * f3[2] * (res[0] - u[0]))
+    C("lw:hi", ld * f3[2] * (res[1] - u[1]))
+    C("lbu:lo", ld * f3[4] * (res[0] - sb))
+    C("lbu:hi", ld * f3[4] * res[1])
+    C("lhu:lo", ld * f3[5] * (res[0] - sh))
+    C("lhu:hi", ld * f3[5] * res[1])
+    st = opc["store"]
+    nb = [sel_byte[k] * vbyte[0] + (1 - sel_byte[k]) * ubyte[k] for k in range(4)]
+    C("sb:lo", st * f3[0] * (after[0] - nb[0] - 256 * nb[1]))
+    C("sb:hi", st * f3[0] * (after[1] - nb[2] - 256 * nb[3]))
+    C("sh:lo", st * f3[1] * (after[0] - ((1 - ob1) * v[0] + ob1 * u[0])))
+    C("sh:hi", st * f3[1] * (after[1] - (ob1 * v[0] + (1 - ob1) * u[1])))
+    C("sw:lo", st * f3[2] * (after[0] - v[0]))
+    C("sw:hi", st * f3[2] * (after[1] - v[1]))
+    # --- results of the register-writing instructions
+    C("lui:lo", opc["lui"] * (res[0] - immu[0]))
+    C("lui:hi", opc["lui"] * (res[1] - immu[1]))
+    and_ = [lin(b, [(1 << k, ub[16 * h + k] * vb[16 * h + k]) for k in range(16)]) for h in range(2)]
+    for h, nm in enumerate(("lo", "hi")):
+        C("auipc:res_" + nm, opc["auipc"] * (res[h] - z[h]))
+        C("link:res_" + nm, link * (res[h] - w[h]))
+        C("add:res_" + nm, alu * f3[0] * (res[h] - z[h]))
+        C("sll:res_" + nm, alu * f3[1] * (res[h] - z[h]))
+        C("srx:res_" + nm, alu * f3[5] * (res[h] - w[h]))
+        C("xor:res_" + nm, alu * f3[4] * (res[h] - (u[h] + v[h] - 2 * and_[h])))
+        C("or:res_" + nm, alu * f3[6] * (res[h] - (u[h] + v[h] - and_[h])))
+        C("and:res_" + nm, alu * f3[7] * (res[h] - and_[h]))
+        C("mul:res_" + nm, mext * f3[0] * (res[h] - z[h]))
+        C("mulh:res_" + nm, mext * (f3[1] + f3[2] + f3[3]) * (res[h] - w[h]))
+        C("div:res_" + nm, mext * bits[14] * (res[h] - z[h]))           # DIV / REM: range-checked, not yet constrained
+        C("ecall:res_" + nm, opc["system"] * (res[h] - z[h]))           # what an ecall writes to a0 / a1: range-checked only
+        C("ecall:word_" + nm, opc["system"] * (after[h] - w[h]))        # ... and to memory
+        C("bnd:word_" + nm, bnd * (after[h] - z[h]))                    # the first value of an address is a 32-bit word
+    C("slt:lo", alu * f3[2] * (res[0] - lt))
+    C("slt:hi", alu * f3[2] * res[1])
+    C("sltu:lo", alu * f3[3] * (res[0] - c1))
+    C("sltu:hi", alu * f3[3] * res[1])
+    # --- the multiplier: U (bytes) x M (byte limbs mb0..mb3) = Z + 2^32 W through four 16-bit positions; carries are range-checked
+    # (access 3's digits are free on these rows: no instruction multiplies and touches memory), the sign of a signed operand is
+    # folded in as -2^32 (sx M + sm U).  Shifts: M = 2^s (left) or 2^(32 - s) (right: the answer is the high word; s = 0 puts 256 in limb 3)
+    p8, sx, sm, c3 = d("p8"), d("sx"), d("sm"), d("c3")
+    mb = [d("mb%d" % k) for k in range(4)]
+    shl, shr, mulsel = alu * f3[1], alu * f3[5], mext * (1 - bits[14])
+    inv2 = lambda k: pow(pow(2, k, P), P - 2, P)
+    pow_l = (1 + vb[0]) * (1 + 3 * vb[1]) * (1 + 15 * vb[2])
+    pow_r = (1 + (inv2(1) - 1) * vb[0]) * (1 + (inv2(2) - 1) * vb[1]) * (1 + (inv2(4) - 1) * vb[2])
+    C("p8", p8 - (shl * pow_l + 256 * (shr * pow_r)))
+    q = [(1 - vb[3]) * (1 - vb[4]), vb[3] * (1 - vb[4]), (1 - vb[3]) * vb[4], vb[3] * vb[4]]
+    for j in range(4):
+        C("mb%d" % j, mb[j] - (mulsel * vbyte[j] + p8 * (shl * q[j] + shr * q[3 - j])))
+    C("sx", sx - ub[31] * (mext * (f3[1] + f3[2]) + shr * bits[30]))
+    C("sm", sm - vb[31] * (mext * f3[1]))
+    C("c3", c3 * (c3 + 1) * (c3 + 2))
+    dg = [d("d3_%d" % i) for i in range(12)] + [d("cx%d" % i) for i in range(4)]
+    for i in range(4):
+        digit(dg[12 + i], "cx%d" % i)
+    cm = [lin(b, [(4 ** i, dg[i]) for i in range(5)]), lin(b, [(4 ** i, dg[5 + i]) for i in range(6)]), lin(b, [(4 ** i, dg[11 + i]) for i in range(5)])]
+    s_ = [lin(b, [(1, ubyte[i] * mb[k - i]) for i in range(4) if 0 <= k - i < 4]) for k in range(7)]
+    m_lo, m_hi = mb[0] + 256 * mb[1], mb[2] + 256 * mb[3]
+    msel = mulsel + shl + shr
+    C("mul:t0", msel * (s_[0] + 256 * s_[1] - z[0] - 65536 * cm[0]))
+    C("mul:t1", msel * (s_[2] + 256 * s_[3] + cm[0] - z[1] - 65536 * cm[1]))
+    C("mul:t2", msel * (s_[4] + 256 * s_[5] + cm[1] - sx * m_lo - sm * u[0] - w[0] - 65536 * (cm[2] - 2)))
+    C("mul:t3", msel * (s_[6] + (cm[2] - 2) - sx * m_hi - sm * u[1] - w[1] - 65536 * c3))
+    # --- the five accesses.  Timestamp of access k of a cycle: 5 cycle + k + 1.  An access that does not happen leaves its read
+    # tuple equal to its written tuple (they cancel in the grand product); one that happens writes its own timestamp, larger than
+    # the one it read: own - previous - 1 is a sum of twelve radix-4 digits.
+    dig = [[d("d%d_%d" % (k, i)) for i in range(12)] for k in range(5)]
+    for k in range(5):
+        for i in range(12):
+            digit(dig[k][i], "d%d_%d" % (k, i))
+
+    def stamp(k):
+        return 5 * cycle + (k + 1)
+
+    def ordered(act, k):  # act * (tw_k - p_k - 1 - digits_k) = 0
+        C("ordered:%d" % k, act * (d("tw%d" % k) - d("p%d" % k) - 1 - lin(b, [(4 ** i, dig[k][i]) for i in range(12)])))
+
+    for k, (zn, invn, actn, lo_bit) in enumerate((("z1", "inv1", "act0", 15), ("z2", "inv2", "act1", 20))):
+        idx = lin(b, [(1 << i, bits[lo_bit + i]) for i in range(5)])
+        zk, act = d(zn), d(actn)
+        C("rs%d:zero" % (k + 1), zk * idx)                              # z = 1 iff the index is 0 ...
+        C("rs%d:inv" % (k + 1), idx * d(invn) - (1 - zk))
+        C("rs%d:act" % (k + 1), act - live * (1 - zk))                  # x0 is not memory: no access
+        for hf in ("lo", "hi"):
+            C("rs%d:x0_%s" % (k + 1, hf), zk * d("rs%d_%s" % (k + 1, hf)))  # ... and reads as zero
+        C("rs%d:addr" % (k + 1), act * (d("addr%d" % k) - REG_BASE - idx))  # the register the word names
+        C("rs%d:tw" % (k + 1), act * (d("tw%d" % k) - stamp(k)))
+        C("rs%d:idle" % (k + 1), (1 - act) * (d("tw%d" % k) - d("p%d" % k)))
+        ordered(act, k)
+    act2, zrd = d("act2"), d("zrd")
+    bit(act2, "act2")
+    idx_rd = lin(b, [(1 << i, bits[7 + i]) for i in range(5)])
+    C("rd:zero", zrd * idx_rd)
+    C("rd:inv", idx_rd * d("inv_rd") - (1 - zrd))
+    writes = opc["lui"] + opc["auipc"] + link + opc["load"] + opc["imm"] + opc["op"]
+    C("rd:act", (1 - opc["system"]) * (act2 - writes * (1 - zrd)))      # an instruction with a destination other than x0 writes it
+    C("rd:addr", act2 * (1 - opc["system"]) * (d("addr2") - REG_BASE - idx_rd))
+    C("rd:ecall", act2 * opc["system"] * (d("addr2") - (REG_BASE + 10)) * (d("addr2") - (REG_BASE + 11)))  # an ecall writes a0 or a1
+    C("rd:tw", act2 * (d("tw2") - stamp(2)))
+    for x_, y_ in (("tw2", "p2"), ("new_lo", "old_lo"), ("new_hi", "old_hi")):
+        C("rd:idle_" + x_, (1 - act2) * (d(x_) - d(y_)))
+    C("rd:lo", act2 * (d("new_lo") - res[0]))                           # ... with the result
+    C("rd:hi", act2 * (d("new_hi") - res[1]))
+    ordered(act2, 2)
+    mk = d("mem_kind")
+    C("mem:kinds", mk * (mk - 1) * (mk - 2))                            # none / read / write
+    half = (P + 1) // 2
+    mem_act = half * (mk * (3 - mk))                                    # 1 on reads and writes
+    is_write = half * (mk * (mk - 1))                                   # 1 on writes
+    keeps = 1 - is_write - bnd                                          # the word stays as it was unless written (or a boundary row)
+    C("mem:keeps_lo", keeps * (after[0] - before[0]))
+    C("mem:keeps_hi", keeps * (after[1] - before[1]))
+    C("mem:tw", mem_act * (d("tw3") - stamp(3)))
+    C("mem:idle", (1 - mem_act - bnd) * (d("tw3") - d("p3")))
+    C("bnd:tw", bnd * d("tw3"))                                         # a boundary row writes the first tuple: timestamp 0
+    ordered(mem_act, 3)
+    # boundary rows: one history per address.  The address is below 2^28 (memory, word index) or 2^28 + a register index (digits of
+    # accesses 0 / 1, free on these rows), and exceeds the previous boundary row's by 1 + fifteen digits: strictly increasing as integers
+    ad = dig[0] + dig[1][:2]
+    top = dig[1][2]
+    C("bnd:top", bnd * top * (top - 1))
+    for i in range(3, 14):
+        C("bnd:reg_%d" % i, bnd * top * ad[i])
+    C("bnd:addr", bnd * (d("addr3") - lin(b, [(4 ** i, ad[i]) for i in range(14)]) - (1 << 28) * top))
+    gap = d("addr3") - d("addr3", 1) - 1 - lin(b, [(4 ** i, dig[3][i]) for i in range(12)] + [(4 ** (12 + i), dig[2][i]) for i in range(3)])
+    C("bnd:order", bnd * prev_bnd * gap)
+    C("fetch:addr", live * (pc - 4 * d("addr4")))                       # the fetch reads the word at pc
+    C("fetch:tw", live * (d("tw4") - stamp(4)))
+    C("fetch:idle", not_live * (d("tw4") - d("p4")))
+    ordered(live, 4)
+    # --- public inputs: the run starts at pc0 in cycle 0; the row after the last cycle (or the last row itself) pins the end
+    G0 = 8
+    gl = lambda k: E(b, b.glob(0, k), 0)
+    C("first:live", first * (live - 1))
+    C("first:pc", first * (pc - gl(G0)))
+    C("first:cycle", first * cycle)
+    ended = not_first * (prev_live - live)                              # 1 on the first row that is not a cycle
+    C("end:pc", ended * (d("next_pc", 1) - gl(G0 + 1)))
+    C("end:cycles", ended * (d("cycle", 1) + 1 - gl(G0 + 2)))
+    full = last * live                                                  # a trace that fills every row
+    C("full:pc", full * (next_pc - gl(G0 + 1)))
+    C("full:cycles", full * (cycle + 1 - gl(G0 + 2)))
+    # --- the grand products: RS_A, RS_B over the tuples read, WS_A, WS_B over the tuples written
+    alpha = [b.glob(1, i) for i in range(4)]
+    beta = [[b.glob(1, 4 * (j + 1) + i) for i in range(4)] for j in range(3)]
+    dv = lambda name, back=0: b.get(G_DATA, col[name], back)
+
+    def fingerprint(addr, lo, hi, t):  # alpha - addr - b1 lo - b2 hi - b3 t as four base-field expressions
+        out = []
+        for i in range(4):
+            e = b.sub(alpha[i], b.add(b.add(b.mul(beta[0][i], dv(lo)), b.mul(beta[1][i], dv(hi))), b.mul(beta[2][i], dv(t))))
+            out.append(b.sub(e, dv(addr)) if i == 0 else e)
+        return out
+
+    products = [  # (ACCUM column block, the fingerprints it multiplies) -- mirrored in the SEC_ACCUM_FP records
+        [("addr0", "rs1_lo", "rs1_hi", "p0"), ("addr1", "rs2_lo", "rs2_hi", "p1"), ("addr2", "old_lo", "old_hi", "p2")],
+        [("addr3", "before_lo", "before_hi", "p3"), ("addr4", "insn_lo", "insn_hi", "p4")],
+        [("addr0", "rs1_lo", "rs1_hi", "tw0"), ("addr1", "rs2_lo", "rs2_hi", "tw1"), ("addr2", "new_lo", "new_hi", "tw2")],
+        [("addr3", "after_lo", "after_hi", "tw3"), ("addr4", "insn_lo", "insn_hi", "tw4")],
+    ]
+    one = b.const(1)
+    nf = b.sub(one, first.v)
+    for j, tuples in enumerate(products):
+        prev = [b.get(G_ACCUM, 4 * j + i, 1) for i in range(4)]
+        want = [b.mul(nf, prev[i]) for i in range(4)]
+        want[0] = b.add(want[0], first.v)
+        for t in tuples:
+            want = fp4_mul_sym(b, want, fingerprint(*t))
+        for i in range(4):
+            cons.append(("accum:%d_%d" % (j, i), b.sub(b.get(G_ACCUM, 4 * j + i, 0), want[i]), 2 + len(tuples), True))
+    acc = [[b.get(G_ACCUM, 4 * j + i, 0) for i in range(4)] for j in range(4)]
+    reads, writes_ = fp4_mul_sym(b, acc[0], acc[1]), fp4_mul_sym(b, acc[2], acc[3])
+    for i in range(4):
+        cons.append(("accum:equal_%d" % i, b.mul(last.v, b.sub(reads[i], writes_[i])), 3, True))  # every tuple read was written, once
+    assert max(c[2] for c in cons) <= 5
+    return b, cons, products
 
 
 def generate_trace():
@@ -279,166 +684,9 @@ def generate_trace():
     n_data, n_code, n_acc, n_global = len(TRACE_COLUMNS), 4, 4, TRACE_GLOBALS
     code_cols = [(0, 0), (1, 0), (2, 0), (3, 3)]  # first-row indicator, last-row indicator, row index, one seeded column
     data_cols = [(0, 0, 0, 0, 0)] * n_data        # all free: the witness is the execution's
-    b = Builder()
-    for g, size in ((G_ACCUM, 4 * n_acc), (G_CODE, n_code), (G_DATA, n_data)):
-        for c in range(size):
-            b.taps.add((g, c, 0))
-
-    def d(name, back=0):
-        return b.get(G_DATA, col[name], back)
-
-    one, two, three, four, five = (b.const(v) for v in (1, 2, 3, 4, 5))
-    half = b.const((P + 1) // 2)
-    first, last = b.get(G_CODE, 0, 0), b.get(G_CODE, 1, 0)
-    not_first = b.sub(one, first)
-    live, prev_live, bnd, prev_bnd = d("live"), d("live", 1), d("bnd"), d("bnd", 1)
-    not_live = b.sub(one, live)
-    cons = []  # (fp var that must vanish on every row, degree)
-
-    def bit(v):
-        cons.append((b.mul(v, b.sub(v, one)), 2))
-
-    def lin(terms):  # sum of coeff * var, coeff an integer (negative allowed)
-        acc = None
-        for coeff, v in terms:
-            t = v if coeff == 1 else b.mul(b.const(coeff % P), v)
-            acc = t if acc is None else b.add(acc, t)
-        return acc
-
-    # --- the run: live rows first, then boundary rows, then blank rows
-    bit(live)
-    bit(bnd)
-    cons.append((b.mul(live, bnd), 2))
-    bit(d("is_seq"))
-    cons.append((b.mul(b.mul(live, d("is_seq")), b.sub(d("next_pc"), b.add(d("pc"), four))), 3))        # sequential rows step by 4
-    gate = b.mul(not_first, live)                                                                       # a live row that has a predecessor
-    cons.append((b.mul(gate, b.sub(d("pc"), d("next_pc", 1))), 3))                                      # ... starts where that one went
-    cons.append((b.mul(gate, b.sub(d("cycle"), b.add(d("cycle", 1), one))), 3))                         # ... one cycle later
-    cons.append((b.mul(gate, b.sub(one, prev_live)), 3))                                                # ... and follows a live row
-    cons.append((b.mul(b.mul(not_first, bnd), b.sub(one, b.add(prev_live, prev_bnd))), 3))              # a boundary row follows a live or a boundary row
-    for name in ("pc", "next_pc", "cycle", "mem_kind", "act2"):                                         # rows that are not cycles carry none of these
-        cons.append((b.mul(not_live, d(name)), 2))
-    # --- the instruction word, its opcode class, control flow
-    bits = [d("bit%d" % k) for k in range(32)]
-    for bk in bits:
-        bit(bk)
-    cons.append((b.sub(d("insn_lo"), lin([(1 << k, bits[k]) for k in range(16)])), 1))
-    cons.append((b.sub(d("insn_hi"), lin([(1 << k, bits[16 + k]) for k in range(16)])), 1))
-    op = lin([(1 << k, bits[k]) for k in range(7)])
-    flags = {}
-    for name, code in (("jal", 0x6F), ("jalr", 0x67), ("branch", 0x63), ("ecall", 0x73)):
-        f, inv_ = d("is_" + name), d("inv_" + name)
-        diff = b.sub(op, b.const(code))
-        bit(f)
-        cons.append((b.mul(f, diff), 2))                                # flag = 1 only at this opcode ...
-        cons.append((b.sub(b.mul(diff, inv_), b.sub(one, f)), 2))       # ... and 0 only elsewhere
-        flags[name] = f
-    jumpy = b.add(b.add(flags["jal"], flags["jalr"]), b.add(flags["branch"], flags["ecall"]))
-    cons.append((b.mul(b.mul(live, b.sub(one, d("is_seq"))), b.sub(one, jumpy)), 3))
-    step = b.sub(d("next_pc"), d("pc"))
-    imm_j = lin([(-(1 << 20), bits[31])] + [(1 << k, bits[k]) for k in range(12, 20)] + [(1 << 11, bits[20])] + [(1 << (k - 20), bits[k]) for k in range(21, 31)])
-    imm_b = lin([(-(1 << 12), bits[31]), (1 << 11, bits[7])] + [(1 << (k - 20), bits[k]) for k in range(25, 31)] + [(1 << (k - 7), bits[k]) for k in range(8, 12)])
-    cons.append((b.mul(flags["jal"], b.sub(step, imm_j)), 2))
-    cons.append((b.mul(b.mul(flags["branch"], b.sub(step, four)), b.sub(step, imm_b)), 3))
-    cons.append((b.mul(b.mul(flags["ecall"], step), b.sub(step, four)), 3))                             # an I/O ecall repeats (pc) or completes (pc + 4)
-    # --- the five accesses.  Timestamp of access k of a cycle: 5 cycle + k + 1.  An access that does not happen leaves its read
-    # tuple equal to its written tuple (they cancel in the grand product); one that happens writes its own timestamp, larger than
-    # the one it read: own - previous - 1 is a sum of twelve radix-4 digits.
-    digit = [[d("d%d_%d" % (k, i)) for i in range(12)] for k in range(5)]
-    for k in range(5):
-        for dg in digit[k]:
-            cons.append((b.mul(b.mul(dg, b.sub(dg, one)), b.mul(b.sub(dg, two), b.sub(dg, three))), 4))
-
-    def stamp(k):
-        return b.add(b.mul(five, d("cycle")), b.const(k + 1))
-
-    def ordered(act, k, deg):  # act * (tw_k - p_k - 1 - digits_k) = 0
-        cons.append((b.mul(act, b.sub(b.sub(d("tw%d" % k), b.add(d("p%d" % k), one)), lin([(4 ** i, digit[k][i]) for i in range(12)]))), deg + 1))
-
-    reg_base = b.const(REG_BASE)
-    for k, (z, inv_, act, lo_bit) in enumerate((("z1", "inv1", "act0", 15), ("z2", "inv2", "act1", 20))):
-        idx = lin([(1 << i, bits[lo_bit + i]) for i in range(5)])
-        cons.append((b.mul(d(z), idx), 2))                                                             # z = 1 iff the index is 0 ...
-        cons.append((b.sub(b.mul(idx, d(inv_)), b.sub(one, d(z))), 2))
-        cons.append((b.sub(d(act), b.mul(live, b.sub(one, d(z)))), 2))                                 # x0 is not memory: no access
-        for half_ in ("lo", "hi"):
-            cons.append((b.mul(d(z), d("rs%d_%s" % (k + 1, half_))), 2))                               # ... and reads as zero
-        cons.append((b.mul(d(act), b.sub(d("addr%d" % k), b.add(reg_base, idx))), 2))                  # the register the word names
-        cons.append((b.mul(d(act), b.sub(d("tw%d" % k), stamp(k))), 2))
-        cons.append((b.mul(b.sub(one, d(act)), b.sub(d("tw%d" % k), d("p%d" % k))), 2))
-        ordered(d(act), k, 1)
-    act2 = d("act2")
-    bit(act2)
-    idx_rd = lin([(1 << i, bits[7 + i]) for i in range(5)])
-    plain = b.mul(act2, b.sub(one, flags["ecall"]))                                                     # a register write of an ordinary instruction
-    cons.append((b.mul(plain, b.sub(d("addr2"), b.add(reg_base, idx_rd))), 3))                          # ... goes to the register the word names,
-    cons.append((b.mul(plain, b.sub(b.mul(idx_rd, d("inv_rd")), one)), 4))                              # ... which is not x0
-    sys_wr = b.mul(act2, flags["ecall"])                                                                # an ecall writes a0 or a1
-    cons.append((b.mul(b.mul(sys_wr, b.sub(d("addr2"), b.const(REG_BASE + 10))), b.sub(d("addr2"), b.const(REG_BASE + 11))), 4))
-    cons.append((b.mul(act2, b.sub(d("tw2"), stamp(2))), 2))
-    not_act2 = b.sub(one, act2)
-    for a_, c_ in (("tw2", "p2"), ("new_lo", "old_lo"), ("new_hi", "old_hi")):
-        cons.append((b.mul(not_act2, b.sub(d(a_), d(c_))), 2))
-    ordered(act2, 2, 1)
-    mk = d("mem_kind")
-    cons.append((b.mul(b.mul(mk, b.sub(mk, one)), b.sub(mk, two)), 3))                                  # none / read / write
-    mem_act = b.mul(half, b.mul(mk, b.sub(three, mk)))                                                  # 1 on reads and writes
-    is_write = b.mul(half, b.mul(mk, b.sub(mk, one)))                                                   # 1 on writes
-    keeps = b.sub(one, b.add(is_write, bnd))                                                            # the word stays as it was unless written (or a boundary row)
-    cons.append((b.mul(keeps, b.sub(d("after_lo"), d("before_lo"))), 3))
-    cons.append((b.mul(keeps, b.sub(d("after_hi"), d("before_hi"))), 3))
-    cons.append((b.mul(mem_act, b.sub(d("tw3"), stamp(3))), 3))
-    cons.append((b.mul(b.sub(one, b.add(mem_act, bnd)), b.sub(d("tw3"), d("p3"))), 3))
-    cons.append((b.mul(bnd, d("tw3")), 2))                                                              # a boundary row writes the first tuple: timestamp 0
-    ordered(mem_act, 3, 2)
-    # boundary rows in strictly increasing address order: one history per address (16 digits: access 3's twelve, access 2's first four)
-    gap = b.sub(b.sub(d("addr3"), b.add(d("addr3", 1), one)), lin([(4 ** i, digit[3][i]) for i in range(12)] + [(4 ** (12 + i), digit[2][i]) for i in range(4)]))
-    cons.append((b.mul(b.mul(bnd, prev_bnd), gap), 3))
-    cons.append((b.mul(live, b.sub(d("pc"), b.mul(four, d("addr4")))), 2))                              # the fetch reads the word at pc
-    cons.append((b.mul(live, b.sub(d("tw4"), stamp(4))), 2))
-    cons.append((b.mul(not_live, b.sub(d("tw4"), d("p4"))), 2))
-    ordered(live, 4, 1)
-    # --- public inputs: the run starts at pc0 in cycle 0; the row after the last cycle (or the last row itself) pins the end
-    G0 = 8
-    cons.append((b.mul(first, b.sub(live, one)), 2))
-    cons.append((b.mul(first, b.sub(d("pc"), b.glob(0, G0))), 2))
-    cons.append((b.mul(first, d("cycle")), 2))
-    ended = b.mul(not_first, b.sub(prev_live, live))                                                    # 1 on the first row that is not a cycle
-    cons.append((b.mul(ended, b.sub(d("next_pc", 1), b.glob(0, G0 + 1))), 3))
-    cons.append((b.mul(ended, b.sub(b.add(d("cycle", 1), one), b.glob(0, G0 + 2))), 3))
-    full = b.mul(last, live)                                                                            # a trace that fills every row
-    cons.append((b.mul(full, b.sub(d("next_pc"), b.glob(0, G0 + 1))), 3))
-    cons.append((b.mul(full, b.sub(b.add(d("cycle"), one), b.glob(0, G0 + 2))), 3))
-    # --- the grand products: RS_A, RS_B over the tuples read, WS_A, WS_B over the tuples written
-    alpha = [b.glob(1, i) for i in range(4)]
-    beta = [[b.glob(1, 4 * (j + 1) + i) for i in range(4)] for j in range(3)]
-
-    def fingerprint(addr, lo, hi, t):  # alpha - addr - b1 lo - b2 hi - b3 t as four base-field expressions
-        out = []
-        for i in range(4):
-            e = b.sub(alpha[i], b.add(b.add(b.mul(beta[0][i], d(lo)), b.mul(beta[1][i], d(hi))), b.mul(beta[2][i], d(t))))
-            out.append(b.sub(e, d(addr)) if i == 0 else e)
-        return out
-
-    products = [  # (ACCUM column block, the fingerprints it multiplies) -- mirrored in the SEC_ACCUM_FP records below
-        [("addr0", "rs1_lo", "rs1_hi", "p0"), ("addr1", "rs2_lo", "rs2_hi", "p1"), ("addr2", "old_lo", "old_hi", "p2")],
-        [("addr3", "before_lo", "before_hi", "p3"), ("addr4", "insn_lo", "insn_hi", "p4")],
-        [("addr0", "rs1_lo", "rs1_hi", "tw0"), ("addr1", "rs2_lo", "rs2_hi", "tw1"), ("addr2", "new_lo", "new_hi", "tw2")],
-        [("addr3", "after_lo", "after_hi", "tw3"), ("addr4", "insn_lo", "insn_hi", "tw4")],
-    ]
-    for j, tuples in enumerate(products):
-        prev = [b.get(G_ACCUM, 4 * j + i, 1) for i in range(4)]
-        want = [b.mul(not_first, prev[i]) for i in range(4)]
-        want[0] = b.add(want[0], first)
-        for t in tuples:
-            want = fp4_mul_sym(b, want, fingerprint(*t))
-        cons.extend((b.sub(b.get(G_ACCUM, 4 * j + i, 0), want[i]), 2 + len(tuples)) for i in range(4))
-    acc = [[b.get(G_ACCUM, 4 * j + i, 0) for i in range(4)] for j in range(4)]
-    reads, writes = fp4_mul_sym(b, acc[0], acc[1]), fp4_mul_sym(b, acc[2], acc[3])
-    cons.extend((b.mul(last, b.sub(reads[i], writes[i])), 3) for i in range(4))                          # every tuple read was written, once
-    assert max(deg for _, deg in cons) <= 5
+    b, cons, products = trace_constraints()
     x = b.true()
-    for v, _ in cons:
+    for _, v, _, _ in cons:
         x = b.and_eqz(x, v)
     taps = sorted(b.taps)
     tap_index = {t: i for i, t in enumerate(taps)}
@@ -454,7 +702,7 @@ def generate_trace():
             rec += [col[name] for name in t]
         acc_records += rec
     words = [MAGIC, 1, 7]
-    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_TRACE:v2__")))
+    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_TRACE:v3__")))
     words += section(SEC_GROUPS, [4 * n_acc, n_code, n_data])
     words += section(SEC_TAPS, [len(taps)] + [w for t in taps for w in t])
     words += section(SEC_GLOBALS, [n_global, 16])
@@ -464,6 +712,47 @@ def generate_trace():
     info = {"taps": len(taps), "steps": len(steps), "constraints": len(cons), "mul_per_point": b.n_mul, "addsub_per_point": b.n_add,
             "groups": [4 * n_acc, n_code, n_data], "columns": len(TRACE_COLUMNS)}
     return words, info
+
+
+def check_trace_rows(data, globals_, first_only=True):
+    """Evaluate every DATA / CODE constraint of the trace circuit on a witness: data[column][row] canonical integers (numpy int64),
+    globals_ the eleven public inputs as canonical integers.  -> [(constraint name, rows where it does not vanish)].  A development
+    and test aid: tells WHICH constraint a witness breaks, where the prover only says that one does."""
+    import numpy as np
+    b, cons, _ = trace_constraints()
+    n = data.shape[1]
+    rows = np.arange(n)
+    code = [(rows == 0).astype(np.int64), (rows == n - 1).astype(np.int64), rows.astype(np.int64), np.zeros(n, dtype=np.int64)]
+    wanted = {v for _, v, _, accum in cons if not accum}
+    vals, fp = {}, 0
+    zero = np.zeros(n, dtype=np.int64)
+    for op, a_, b_, c_ in b.steps:
+        if op in (OP_TRUE, OP_AND_EQZ, OP_AND_COND):
+            continue
+        if op == OP_CONST:
+            r = np.full(n, a_, dtype=np.int64)
+        elif op == OP_GET:
+            _, g, c, back = a_
+            src = data[c] if g == G_DATA else code[c] if g == G_CODE else zero
+            r = np.roll(src, back)
+        elif op == OP_GET_GLOBAL:
+            r = np.full(n, int(globals_[b_]) if a_ == 0 else 0, dtype=np.int64)
+        elif op == OP_ADD:
+            r = (vals[a_] + vals[b_]) % P
+        elif op == OP_SUB:
+            r = (vals[a_] - vals[b_]) % P
+        else:
+            r = (vals[a_] * vals[b_]) % P
+        vals[fp] = r
+        fp += 1
+    bad = []
+    for name, v, _, accum in cons:
+        if accum:
+            continue
+        where = np.nonzero(vals[v])[0]
+        if len(where):
+            bad.append((name, where[:8].tolist() if first_only else where.tolist()))
+    return bad
 
 
 SHAPES = {

@@ -20,26 +20,38 @@ from test_rv32im import ADDI, A0, A7, B, ECALL, I, J, LI, R, S, U, flat
 
 
 def random_program(rng, n):
-    """n random instructions; branches and jumps only go forward (by 8 or 12 bytes), so the body terminates; x28 = scratch page,
-    x29 = loop counter (the body runs 1-6 times)."""
-    body = []
+    """n random instructions of every RV32IM kind; branches and jumps only go forward (by 8 to 16 bytes), so the body terminates;
+    x28 = scratch page, x29 = loop counter (the body runs 1-6 times), x30 = base of the JALRs."""
+    body, last_jump = [], -9
     regs = [r for r in range(1, 28)]
     for _ in range(n):
         k = int(rng.integers(0, 10))
         rd, rs1, rs2 = (int(rng.choice(regs)) for _ in range(3))
         if k < 3:
-            body.append(R(int(rng.choice([0, 1])), rs2, rs1, int(rng.integers(0, 8)), rd))
+            f3 = int(rng.integers(0, 8))
+            body.append(R(int(rng.choice([0, 1, 0x20] if f3 in (0, 5) else [0, 1])), rs2, rs1, f3, rd))       # base ISA, SUB / SRA, M extension
         elif k < 5:
-            body.append(I(int(rng.integers(0, 4096)), rs1, int(rng.choice([0, 2, 3, 4, 6, 7])), rd, 0x13))
+            f3 = int(rng.integers(0, 8))
+            imm = int(rng.integers(0, 4096)) if f3 not in (1, 5) else int(rng.integers(0, 32)) | (0x400 if f3 == 5 and rng.random() < 0.5 else 0)
+            body.append(I(imm, rs1, f3, rd, 0x13))                                                             # incl. SLLI / SRLI / SRAI
         elif k == 5:
-            body.append(U(int(rng.integers(0, 1 << 20)), rd, int(rng.choice([0x37, 0x17]))))
+            if rng.random() < 0.3 and len(body) - last_jump > 2:  # no forward jump may land on the JALR (x30 would be stale)
+                last_jump = len(body) + 1
+                body += [U(0, 30, 0x17), I(int(rng.choice([12, 13, 16, 17])), 30, 0, int(rng.choice([0, 1, 5])), 0x67)]  # auipc x30, 0; jalr rd, 12|16(x30), low bit dropped
+            else:
+                body.append(U(int(rng.integers(0, 1 << 20)), rd, int(rng.choice([0x37, 0x17]))))
         elif k == 6:
-            body.append(I(int(rng.integers(0, 255)) * 4, 28, 2, rd, 0x03))           # lw rd, off(x28)
+            f3 = int(rng.choice([0, 1, 2, 4, 5]))
+            width = 1 if f3 in (0, 4) else 2 if f3 in (1, 5) else 4
+            body.append(I(int(rng.integers(0, 1020 // width)) * width, 28, f3, rd, 0x03))                      # lb / lh / lw / lbu / lhu rd, off(x28)
         elif k == 7:
-            body.append(S(int(rng.integers(0, 255)) * 4, rs2, 28, 2))                # sw rs2, off(x28)
+            f3 = int(rng.integers(0, 3))
+            body.append(S(int(rng.integers(0, 1020 >> f3)) << f3, rs2, 28, f3))                                # sb / sh / sw rs2, off(x28)
         elif k == 8:
+            last_jump = len(body)
             body.append(B(int(rng.choice([8, 12])), rs2, rs1, int(rng.choice([0, 1, 4, 5, 6, 7]))))
         else:
+            last_jump = len(body)
             body.append(J(int(rng.choice([8, 12])), int(rng.choice([0, 1, 5]))))
     body += [ADDI(0, 0, 0)] * 3  # landing room for the last forward jumps
     loop = flat(body, ADDI(29, 29, -1), B(-4 * (len(body) + 1), 0, 29, 1))
