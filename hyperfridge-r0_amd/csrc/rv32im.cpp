@@ -543,6 +543,8 @@ const char* column_name(uint32_t column) {
     run("mb", 4);
     run("cx", 4);
     n.push_back("c3");
+    for (const char* s : {"dv", "ovf", "k0", "a31"}) n.push_back(s);
+    run("at", 8);
     return n;
   }();
   return column < names.size() ? names[column].c_str() : nullptr;

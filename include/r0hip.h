@@ -442,7 +442,7 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
  * risc0's rv32im circuit, not reproducible here), and that the first values of the boundary rows are the pre-state's memory
  * (risc0 pages memory in through in-circuit Merkle proofs).  Public inputs: 8 words naming the segment's ReceiptClaim
  * (r0h_claim_globals), first pc, pc after the last cycle, number of cycles.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
-#define R0H_TRACE_COLUMNS 276
+#define R0H_TRACE_COLUMNS 288
 #define R0H_TRACE_GLOBALS 11
 #define R0H_TRACE_MAX_PO2 21
 const char* r0h_trace_column_name(uint32_t column); /* static string; NULL past the last column */

@@ -2,7 +2,7 @@
 -- what the prover commits to comes from an execution, not from a synthetic column program.
 It constrains that the cycles form one contiguous run from the public first pc to the public last pc in the public number of
 cycles, WHAT EVERY INSTRUCTION DOES (decode, ALU / shifter / multiplier results, branch decisions, jump targets, load / store
-addresses and the narrow accesses' byte lanes -- DIV / REM results and what an ecall reads and writes are range-checked only) and
+addresses and the narrow accesses' byte lanes, quotients and remainders -- what an ecall reads and writes is range-checked only) and
 MEMORY CONSISTENCY over registers and memory as one address space (offline memory checking: a grand product over
 r0h_prefix_products in ACCUM, timestamps ordered through radix-4 digits in DATA): what is read from a register or a word -- an
 instruction word included -- is what was last written there.  It is this library's circuit for this library's executor, not
@@ -307,6 +307,8 @@ def forged_result(r, value, word="z"):
     range-checked word the result is read from (Z or W) with everything the always-on definitions derive from it"""
     lo, hi = value & 0xFFFF, value >> 16
     edits = [("new_lo", r, lo), ("new_hi", r, hi), ("res_lo", r, lo), ("res_hi", r, hi)]
+    if word == "u":
+        return edits + [("ub%d" % i, r, (value >> i) & 1) for i in range(32)]
     edits += [("%sd%d" % (word, i), r, (value >> (2 * i)) & 3) for i in range(16)]
     if word == "z":
         edits += [("ob0", r, value & 1), ("ob1", r, (value >> 1) & 1), ("eq", r, int(value == 0)), ("zinv", r, pow(lo + hi, P - 2, P) if value else 0)]
@@ -317,7 +319,7 @@ def test_what_an_instruction_computes_is_constrained_kind_by_kind(orc):
     """Random programs over every RV32IM instruction kind (tools/soak_trace.py): the genuine witness satisfies every constraint,
     and for each kind that writes a register the most careful lie available -- another value written, the result columns and the
     range-checked word changed with it -- breaks a constraint that belongs to that instruction's unit.  Stores: another word
-    written.  Branches: the other way taken.  (DIV / REM and ecall rows are the two kinds whose result is range-checked only.)"""
+    written.  Branches: the other way taken.  (An ecall row is the one kind whose result is range-checked only.)"""
     from soak_trace import random_program
     rng = np.random.default_rng(21)
     seen = {}
@@ -340,8 +342,9 @@ def test_what_an_instruction_computes_is_constrained_kind_by_kind(orc):
                 continue
             if w.rd:
                 from_w = op in (0x6F, 0x67) or (op in (0x13, 0x33) and f3 == 5 and f7 != 1) or (op == 0x33 and f7 == 1 and f3 in (1, 2, 3))
-                bad = broken(vm, 0, po2, forged_result(r, w.rd_after ^ 0x10, "w" if from_w else "z"))
-                free = op == 0x73 or (op == 0x33 and f7 == 1 and f3 >= 4)
+                from_u = op == 0x33 and f7 == 1 and f3 in (4, 5)  # a quotient
+                bad = broken(vm, 0, po2, forged_result(r, w.rd_after ^ 0x10, "u" if from_u else "w" if from_w else "z"))
+                free = op == 0x73
                 assert (bad == []) == free, (hex(w.insn), bad)
                 if not free:
                     assert not any(name.startswith(("rd:", "run:", "accum", "bit:", "digit:")) for name in bad), (hex(w.insn), bad)
@@ -359,6 +362,63 @@ def test_what_an_instruction_computes_is_constrained_kind_by_kind(orc):
     assert {0x37, 0x17, 0x6F, 0x67, 0x63, 0x03, 0x23, 0x13, 0x33, 0x73} <= ops and len(seen) >= 50, sorted(seen)
     assert {(0x33, f3, 1) for f3 in range(8)} <= set(seen) and {(0x33, 0, 0x20), (0x33, 5, 0x20), (0x13, 5, 0x20), (0x13, 1, 0)} <= set(seen)
     assert {(0x03, f3, 0) for f3 in (0, 1, 2, 4, 5)} | {(0x23, f3, 0) for f3 in range(3)} | {(0x63, f3, 0) for f3 in (0, 1, 4, 5, 6, 7)} <= set(seen)
+
+
+def test_division_in_all_its_corners(orc):
+    """DIV / DIVU / REM / REMU on operands of every sign, by zero, -2^31 / -1: the genuine rows satisfy the constraints; the other
+    quotient-remainder pair that also satisfies dividend = quotient x divisor + remainder (quotient + 1, remainder - divisor) does not."""
+    from test_rv32im import ADDI, A0, A7, ECALL, LI, R, flat
+    pairs = [(7, 2), (-7, 2), (7, -2), (-7, -2), (0, 5), (5, 0), (-5, 0), (0, 0), (-2**31, -1), (-2**31, 1), (2**31 - 1, -1), (1, -2**31), (-2**31, -2**31),
+             (0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 1), (123456789, 1000), (-123456789, 1000), (6, 3), (-6, 3), (0x80000000, 0x7FFFFFFF), (5, -2**31)]
+    body = []
+    for a_, b_ in pairs:
+        body += flat(LI(5, a_ & 0xFFFFFFFF), LI(6, b_ & 0xFFFFFFFF), [R(1, 6, 5, f3, 7 + f3) for f3 in (4, 5, 6, 7)])
+    vm = r0.Vm()
+    vm.load(0x1000, flat(body, ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL))
+    vm.set_pc(0x1000)
+    assert vm.run(segment_po2=20, keep_trace=True, boundary_rows=True) == (0, 0)
+    po2 = 10
+    assert broken(vm, 0, po2) == []
+    rows = vm.preflight(0)
+    data, glob = vm.trace_witness(0, po2)
+    m0, g = canonical(data, po2), [int(x) * R_INV % P for x in glob]
+    M32 = 0xFFFFFFFF
+    checked = 0
+    for r, w in enumerate(rows):
+        if (w.insn & 0x7F) != 0x33 or (w.insn >> 25) != 1 or ((w.insn >> 12) & 7) < 4:
+            continue
+        f3, a_, b_ = (w.insn >> 12) & 7, w.rs1_value, w.rs2_value
+        signed = f3 in (4, 6)
+        sx = lambda v: v - (1 << 32) if signed and v >> 31 else v
+        if b_ == 0:
+            q, rem = M32, a_
+        elif signed and a_ == 0x80000000 and b_ == M32:
+            q, rem = a_, 0
+        else:
+            qq = abs(sx(a_)) // abs(sx(b_)) * (1 if (sx(a_) < 0) == (sx(b_) < 0) else -1)  # truncating
+            q, rem = qq & M32, (sx(a_) - qq * sx(b_)) & M32
+        assert w.rd_after == (q if f3 in (4, 5) else rem), (hex(w.insn), a_, b_)
+        assert [int(m0[COL["ub%d" % i], r]) for i in range(32)] == [(q >> i) & 1 for i in range(32)]        # U: the quotient
+        assert sum(int(m0[COL["zd%d" % i], r]) << (2 * i) for i in range(16)) == rem                           # Z: the remainder
+        if b_ == 0 or (signed and a_ == 0x80000000 and b_ == M32):
+            continue
+        # the neighbouring solution of the division identity: quotient + 1, remainder - divisor (the row's other columns re-derived by
+        # hand would take a second witness generator; here the identity's own columns are edited and the comparison must object)
+        q2, rem2 = (q + 1) & M32, (rem - b_) & M32
+        m = m0.copy()
+        for i in range(32):
+            m[COL["ub%d" % i], r] = (q2 >> i) & 1
+        for i in range(16):
+            m[COL["zd%d" % i], r] = (rem2 >> (2 * i)) & 3
+        m[COL["ob0"], r], m[COL["ob1"], r] = rem2 & 1, (rem2 >> 1) & 1
+        m[COL["c1"], r], m[COL["c0"], r] = rem2 >> 31, (rem2 >> 30) & 1
+        lo, hi = (q2 if f3 in (4, 5) else rem2) & 0xFFFF, (q2 if f3 in (4, 5) else rem2) >> 16
+        for c, val in (("res_lo", lo), ("res_hi", hi), ("new_lo", lo), ("new_hi", hi)):
+            m[COL[c], r] = val
+        bad = [name for name, where in check_trace_rows(m, g) if r in where]
+        assert any(name.startswith("div:") for name in bad), (a_, b_, f3, bad)
+        checked += 1
+    assert checked >= 60
 
 
 def test_jumps_and_branches_of_every_kind_satisfy_the_control_flow_constraints(orc):

@@ -13,7 +13,7 @@ Shapes:
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
   recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
-  trace  W=(16, 4, 276)                     columns = the executor's preflight rows; one contiguous run, every instruction's semantics, memory consistency
+  trace  W=(16, 4, 288)                     columns = the executor's preflight rows; one contiguous run, every instruction's semantics, memory consistency
 """
 import argparse
 import struct
@@ -285,7 +285,8 @@ TRACE_COLUMNS = (["live", "bnd", "cycle", "pc", "next_pc", "insn_lo", "insn_hi"]
                  + ["wd%d" % k for k in range(16)]                                                    # word W: high product word, link, pc
                  + ["res_lo", "res_hi", "c0", "c1", "lt", "eq", "zinv", "ob0", "ob1", "sb", "sgn", "p8", "sx", "sm"]
                  + ["mb%d" % k for k in range(4)]                                                     # second multiplier operand, byte limbs
-                 + ["cx%d" % k for k in range(4)] + ["c3"])                                           # carry digits beyond access 3's twelve; top carry
+                 + ["cx%d" % k for k in range(4)] + ["c3"]                                            # carry digits beyond access 3's twelve; top carry
+                 + ["dv", "ovf", "k0", "a31"] + ["at%d" % k for k in range(8)])                       # division: active, the overflow case, a carry, the dividend's sign and the digits under it
 TRACE_GLOBALS = 11   # claim words 0..7, first pc, pc after the last cycle, cycles
 REG_BASE = 1 << 28   # registers sit above 2^28 words = 1 GiB of memory
 SEC_ACCUM_FP = 8
@@ -442,16 +443,18 @@ def trace_constraints():
     before, after = [d("before_lo"), d("before_hi")], [d("after_lo"), d("after_hi")]
     res = [d("res_lo"), d("res_hi")]
     is_mem = opc["load"] + opc["store"]
+    isdiv = mext * bits[14]
     use_b, use_i = opc["op"] + opc["branch"] + opc["store"], opc["imm"] + opc["load"] + opc["jalr"]
     for h, nm in enumerate(("lo", "hi")):
-        C("u:" + nm, u[h] - (is_mem * before[h] + (1 - is_mem) * a[h]))      # U: the word of a load / store, x[rs1] otherwise
+        C("u:" + nm, (1 - isdiv) * (u[h] - (is_mem * before[h] + (1 - is_mem) * a[h])))  # U: the word of a load / store, x[rs1] otherwise (a division row keeps its quotient there)
         C("v:" + nm, v[h] - (use_b * rs2[h] + use_i * immi[h]))               # V: x[rs2] or the I-immediate
     c0, c1, lt, eq, zinv, ob0, ob1 = d("c0"), d("c1"), d("lt"), d("eq"), d("zinv"), d("ob0"), d("ob1")
     for nm, x in (("c0", c0), ("c1", c1), ("lt", lt), ("eq", eq), ("ob0", ob0), ("ob1", ob1)):
         bit(x, nm)
     C("z:low_bits", zd[0] - ob0 - 2 * ob1)
-    C("eq:zero", eq * (z[0] + z[1]))                                    # eq = 1 iff Z = 0 (both halves are 16-bit: no wrap)
-    C("eq:inv", (z[0] + z[1]) * zinv - (1 - eq))
+    zero_of = z[0] + z[1] + isdiv * (v[0] + v[1] - z[0] - z[1])          # the zero test looks at Z; on a division row at the divisor
+    C("eq:zero", eq * zero_of)                                          # eq = 1 iff that word is 0 (both halves are 16-bit: no wrap)
+    C("eq:inv", zero_of * zinv - (1 - eq))
     differ = ub[31] + vb[31] - 2 * ub[31] * vb[31]
     C("lt", lt - (differ * ub[31] + (1 - differ) * c1))                 # signed U < V given the borrow c1 of U - V
     # --- the adder: X + Y = Z + 2^32 carry (halves, two carry bits), or backwards: Y + Z = X + 2^32 borrow
@@ -529,7 +532,7 @@ def trace_constraints():
         C("and:res_" + nm, alu * f3[7] * (res[h] - and_[h]))
         C("mul:res_" + nm, mext * f3[0] * (res[h] - z[h]))
         C("mulh:res_" + nm, mext * (f3[1] + f3[2] + f3[3]) * (res[h] - w[h]))
-        C("div:res_" + nm, mext * bits[14] * (res[h] - z[h]))           # DIV / REM: range-checked, not yet constrained
+        C("div:res_" + nm, isdiv * (res[h] - (bits[13] * z[h] + (1 - bits[13]) * u[h])))  # DIV[U]: the quotient (U); REM[U]: the remainder (Z)
         C("ecall:res_" + nm, opc["system"] * (res[h] - z[h]))           # what an ecall writes to a0 / a1: range-checked only
         C("ecall:word_" + nm, opc["system"] * (after[h] - w[h]))        # ... and to memory
         C("bnd:word_" + nm, bnd * (after[h] - z[h]))                    # the first value of an address is a 32-bit word
@@ -543,16 +546,17 @@ def trace_constraints():
     p8, sx, sm, c3 = d("p8"), d("sx"), d("sm"), d("c3")
     mb = [d("mb%d" % k) for k in range(4)]
     shl, shr, mulsel = alu * f3[1], alu * f3[5], mext * (1 - bits[14])
+    sgnd = 1 - bits[12]                                                 # DIV / REM are signed, DIVU / REMU are not
     inv2 = lambda k: pow(pow(2, k, P), P - 2, P)
     pow_l = (1 + vb[0]) * (1 + 3 * vb[1]) * (1 + 15 * vb[2])
     pow_r = (1 + (inv2(1) - 1) * vb[0]) * (1 + (inv2(2) - 1) * vb[1]) * (1 + (inv2(4) - 1) * vb[2])
     C("p8", p8 - (shl * pow_l + 256 * (shr * pow_r)))
     q = [(1 - vb[3]) * (1 - vb[4]), vb[3] * (1 - vb[4]), (1 - vb[3]) * vb[4], vb[3] * vb[4]]
     for j in range(4):
-        C("mb%d" % j, mb[j] - (mulsel * vbyte[j] + p8 * (shl * q[j] + shr * q[3 - j])))
-    C("sx", sx - ub[31] * (mext * (f3[1] + f3[2]) + shr * bits[30]))
-    C("sm", sm - vb[31] * (mext * f3[1]))
-    C("c3", c3 * (c3 + 1) * (c3 + 2))
+        C("mb%d" % j, mb[j] - (mext * vbyte[j] + p8 * (shl * q[j] + shr * q[3 - j])))
+    C("sx", sx - ub[31] * (mext * (f3[1] + f3[2]) + shr * bits[30] + isdiv * sgnd))
+    C("sm", sm - vb[31] * (mext * f3[1] + isdiv * sgnd))
+    C("c3", c3 * (c3 + 1) * ((c3 + 2) * (c3 - 1)))
     dg = [d("d3_%d" % i) for i in range(12)] + [d("cx%d" % i) for i in range(4)]
     for i in range(4):
         digit(dg[12 + i], "cx%d" % i)
@@ -562,8 +566,42 @@ def trace_constraints():
     msel = mulsel + shl + shr
     C("mul:t0", msel * (s_[0] + 256 * s_[1] - z[0] - 65536 * cm[0]))
     C("mul:t1", msel * (s_[2] + 256 * s_[3] + cm[0] - z[1] - 65536 * cm[1]))
-    C("mul:t2", msel * (s_[4] + 256 * s_[5] + cm[1] - sx * m_lo - sm * u[0] - w[0] - 65536 * (cm[2] - 2)))
-    C("mul:t3", msel * (s_[6] + (cm[2] - 2) - sx * m_hi - sm * u[1] - w[1] - 65536 * c3))
+    C("mul:t2", msel * (s_[4] + 256 * s_[5] + cm[1] - sx * m_lo - sm * u[0] - w[0] - 65536 * (cm[2] - 4)))
+    C("mul:t3", msel * (s_[6] + (cm[2] - 4) - sx * m_hi - sm * u[1] - w[1] - 65536 * c3))
+    # --- division: U = quotient, V = divisor, Z = remainder, x[rs1] = dividend.  The same chain proves quotient x divisor + remainder =
+    # dividend as 64-bit (sign-extended) integers; W = |divisor| - |remainder| - 1 is a range-checked word, so |remainder| < |divisor|;
+    # a remainder other than 0 has the dividend's sign.  Division by zero: quotient all ones, the chain then gives remainder = dividend.
+    # -2^31 / -1 (ovf): quotient = dividend, remainder 0.
+    dv, ovf, k0, a31 = d("dv"), d("ovf"), d("k0"), d("a31")
+    at = [d("at%d" % i) for i in range(8)]
+    for nm, x in (("ovf", ovf), ("a31", a31)):
+        bit(x, nm)
+    C("k0", (k0 + 1) * k0 * ((k0 - 1) * (k0 - 2)))                     # the carry between the halves of the comparison: -1 .. 2
+    for i in range(8):
+        digit(at[i], "at%d" % i)
+    C("dv", dv - isdiv * (1 - ovf))
+    C("ovf:div", ovf * (1 - isdiv))
+    C("ovf:signed", ovf * bits[12])
+    C("ovf:a_lo", ovf * a[0])
+    C("ovf:a_hi", ovf * (a[1] - 0x8000))
+    C("ovf:b_lo", ovf * (v[0] - 0xFFFF))
+    C("ovf:b_hi", ovf * (v[1] - 0xFFFF))
+    for h, nm in enumerate(("lo", "hi")):
+        C("ovf:q_" + nm, ovf * (u[h] - a[h]))
+        C("ovf:rem_" + nm, ovf * z[h])
+        C("div0:q_" + nm, dv * eq * (u[h] - 0xFFFF))
+    C("div:a31", isdiv * (a[1] - 32768 * a31 - lin(b, [(4 ** i, at[i]) for i in range(8)])))
+    C("div:a31_range", isdiv * at[7] * (at[7] - 1))
+    C("div:rem31", isdiv * (zd[15] - 2 * c1 - c0))                      # c1 / c0: the top two bits of the remainder
+    sr, sa, sb_ = c1 * sgnd, a31 * sgnd, vb[31] * sgnd
+    C("div:t0", dv * (s_[0] + 256 * s_[1] + z[0] - a[0] - 65536 * cm[0]))
+    C("div:t1", dv * (s_[2] + 256 * s_[3] + cm[0] + z[1] - a[1] - 65536 * cm[1]))
+    C("div:t2", dv * (s_[4] + 256 * s_[5] + cm[1] - sx * m_lo - sm * u[0] + 65535 * (sr - sa) - 65536 * (cm[2] - 4)))
+    C("div:t3", dv * (s_[6] + (cm[2] - 4) - sx * m_hi - sm * u[1] + 65535 * (sr - sa) - 65536 * c3))
+    C("div:rem_sign", dv * (sr - sa) * (z[0] + z[1]))
+    cmp = dv * (1 - eq)                                                 # ... unless the divisor is 0
+    C("div:less_lo", cmp * (w[0] + 1 + (1 - 2 * sr) * z[0] - (1 - 2 * sb_) * v[0] - 65536 * k0))
+    C("div:less_hi", cmp * (w[1] + (1 - 2 * sr) * z[1] - (1 - 2 * sb_) * v[1] - 65536 * (sb_ - sr) + k0))
     # --- the five accesses.  Timestamp of access k of a cycle: 5 cycle + k + 1.  An access that does not happen leaves its read
     # tuple equal to its written tuple (they cancel in the grand product); one that happens writes its own timestamp, larger than
     # the one it read: own - previous - 1 is a sum of twelve radix-4 digits.
