@@ -20,14 +20,16 @@
 // No guest ELF exists in the reference (only sources: methods/guest/src/main.rs; the ELF is built by `risc0_build::embed_methods()`,
 // methods/build.rs:2, which needs the Rust toolchain), so the camt53 trace itself still cannot be produced.
 //
-// ecall ABI (a7 = x17 selects; arguments a0.., result in a0):
+// ecall ABI (a7 = x17 selects; arguments a0, a1; every ecall cycle reads a7 and a0 -- they are the cycle's two register reads):
 //   0 HALT        a0 = exit code                        -- ends the run (ExitCode::Halted(a0))
-//   1 READ_WORDS  a0 = destination, a1 = word count     -- the next words of the input stream (ExecutorEnv frames), zero past its end;
-//                                                          one word per cycle, a1 counts down to 0
-//   2 COMMIT      a0 = source, a1 = byte count          -- appends bytes to the journal (`env::commit`); one memory word per cycle,
-//                                                          a1 counts down to 0
+//   1 READ_WORDS  a0 = destination, a1 = word count     -- the next words of the input stream (ExecutorEnv frames), zero past its end
+//   2 COMMIT      a0 = source, a1 = word count          -- appends words to the journal (`env::commit`: the journal is a word stream)
 //   3 CYCLES                                            -- a0 = cycles executed so far (`env::cycle_count()`)
 //   4 PAUSE       a0 = exit code                        -- ends the run resumably (ExitCode::Paused(a0))
+// The two transfers move one word per cycle and keep no state outside the registers, so that a cycle is a function of what it
+// reads (the trace circuit constrains it): while a1 = j > 0 the ecall re-executes -- it moves word j - 1 of the buffer (address
+// a0 + 4 (j - 1)) and writes a1 = j - 1 -- and with a1 = 0 it falls through to pc + 4; a transfer of n words takes n + 1 cycles.
+// The host hands out the stream words so that the buffer ends up in stream order.  a0 is word-aligned, buffers lie below 1 GiB.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -94,8 +96,9 @@ struct r0h_vm {
   std::vector<std::vector<r0h_preflight_row>> spare_rows;
   std::vector<std::vector<r0h_preflight_bound>> spare_bounds;
   // an I/O ecall in progress: the count it started with (a1 counts down from there)
-  bool io_active = false;
+  bool io_active = false;  // host-side bookkeeping of a transfer in progress: its length and where its words go in the stream
   uint32_t io_total = 0;
+  size_t io_base = 0;
   // hashing caches
   uint8_t zero_level[N_PAGE_BITS + 1][32];
   bool zero_ready = false;
@@ -316,14 +319,16 @@ struct Run {
     const uint32_t insn = fp->w[(m.pc & (PAGE_BYTES - 1)) >> 2];
     const uint32_t fetch_prev = touch_word(fp, m.pc, r0h::trace::stamp(cyc, 4));
     const uint32_t op = insn & 0x7f, rd = (insn >> 7) & 31, f3 = (insn >> 12) & 7, rs1 = (insn >> 15) & 31, rs2 = (insn >> 20) & 31, f7 = insn >> 25;
-    const uint32_t a = m.x[rs1], b = m.x[rs2];
+    const bool sys = op == 0x73;  // an ecall reads a7 and a0 where another instruction reads x[rs1] and x[rs2]
+    const uint32_t r1 = sys ? 17u : rs1, r2 = sys ? 10u : rs2;
+    const uint32_t a = m.x[r1], b = m.x[r2];
     const int32_t imm_i = (int32_t)insn >> 20;
     const int32_t imm_s = ((int32_t)(insn & 0xfe000000) >> 20) | (int32_t)((insn >> 7) & 31);
     const int32_t imm_b = ((int32_t)(insn & 0x80000000) >> 19) | (int32_t)((insn & 0x80) << 4) | (int32_t)((insn >> 20) & 0x7e0) | (int32_t)((insn >> 7) & 0x1e);
     const int32_t imm_j = ((int32_t)(insn & 0x80000000) >> 11) | (int32_t)(insn & 0xff000) | (int32_t)((insn >> 9) & 0x800) | (int32_t)((insn >> 20) & 0x7fe);
     uint32_t next = m.pc + 4, wr = 0, wr_reg = rd;
     bool has_wr = false;
-    const uint32_t p0 = rs1 ? touch_reg(rs1, r0h::trace::stamp(cyc, 0)) : 0, p1 = rs2 ? touch_reg(rs2, r0h::trace::stamp(cyc, 1)) : 0;
+    const uint32_t p0 = r1 ? touch_reg(r1, r0h::trace::stamp(cyc, 0)) : 0, p1 = r2 ? touch_reg(r2, r0h::trace::stamp(cyc, 1)) : 0;
     if (lim.keep_trace) {
       cur.rows.emplace_back();  // value-initialised: all zero
       row = &cur.rows.back();
@@ -429,40 +434,44 @@ struct Run {
       case 0x0f: break;  // FENCE: a no-op for a single hart
       case 0x73: {
         if (insn != 0x00000073u) { err = insn == 0x00100073u ? "ebreak" : "illegal instruction"; return false; }
-        const uint32_t fn = m.x[17], a0 = m.x[10], a1 = m.x[11];
+        const uint32_t fn = a, a0 = b, a1 = m.x[11];
         switch (fn) {
           case 0: exit_kind = R0H_VM_HALTED; exit_code = a0; running = false; break;
           case 4: exit_kind = R0H_VM_PAUSED; exit_code = a0; running = false; break;
           case 1:
           case 2: {
-            // one word per cycle; the ecall re-executes until a1 is 0 (io_total: the count the transfer started with)
-            if (fn == 1 && (a0 & 3)) { err = "READ_WORDS: misaligned destination"; return false; }
-            if (a1 == 0) { m.io_active = false; break; }
-            if (!m.io_active || a1 > m.io_total) {
-              if (fn == 1 && a1 > MAX_IO_WORDS) { err = "READ_WORDS: count too large"; return false; }
-              if (fn == 2 && (uint64_t)a1 > MAX_JOURNAL_BYTES) { err = "COMMIT: count too large"; return false; }
+            if (a0 & 3) { err = fn == 1 ? "READ_WORDS: misaligned destination" : "COMMIT: misaligned source"; return false; }
+            if (a0 >> ADDRESS_BITS) { err = "ecall buffer outside the 1 GiB address space"; return false; }
+            wr_reg = 11;
+            if (a1 == 0) {  // nothing (left) to move: fall through; a1 is written all the same (the cycle's register write)
+              if (m.io_active && fn == 1) m.input_pos = std::min(m.input.size(), m.io_base + m.io_total);
+              m.io_active = false;
+              set(0);
+              break;
+            }
+            if (!m.io_active) {
+              if (a1 > MAX_IO_WORDS) { err = fn == 1 ? "READ_WORDS: count too large" : "COMMIT: count too large"; return false; }
+              if (((uint64_t)a0 + 4ull * a1) >> ADDRESS_BITS) { err = "ecall buffer outside the 1 GiB address space"; return false; }
               m.io_active = true;
               m.io_total = a1;
+              m.io_base = fn == 1 ? m.input_pos : m.journal.size();
+              if (fn == 2) {
+                if (m.journal.size() + 4ull * a1 > MAX_JOURNAL_BYTES) { err = "COMMIT: the journal exceeds 2^28 bytes"; return false; }
+                m.journal.resize(m.journal.size() + 4 * (size_t)a1);
+              }
             }
-            const uint32_t off = m.io_total - a1;
-            uint32_t left;
-            if ((fn == 1 ? a0 + 4 * off : a0 + off) >> ADDRESS_BITS) { err = "ecall buffer outside the 1 GiB address space"; return false; }
+            if (a1 > m.io_total) { err = "ecall: a1 grew during a transfer"; return false; }
+            const uint32_t idx = a1 - 1;  // the words go from the back of the buffer to its front
             if (fn == 1) {
               uint32_t old;
-              mem_access(a0 + 4 * off, true, m.input_pos < m.input.size() ? m.input[m.input_pos] : 0u, &old);
-              if (m.input_pos < m.input.size()) m.input_pos++;
-              left = a1 - 1;
+              mem_access(a0 + 4 * idx, true, m.io_base + idx < m.input.size() ? m.input[m.io_base + idx] : 0u, &old);
             } else {
-              if (m.journal.size() + 4 > MAX_JOURNAL_BYTES) { err = "COMMIT: the journal exceeds 2^28 bytes"; return false; }
-              const uint32_t at = a0 + off, take = std::min(4 - (at & 3), a1);
               uint32_t w;
-              mem_access(at & ~3u, false, 0, &w);
-              for (uint32_t i = 0; i < take; i++) m.journal.push_back((uint8_t)(w >> (8 * ((at & 3) + i))));
-              left = a1 - take;
+              mem_access(a0 + 4 * idx, false, 0, &w);
+              for (uint32_t i = 0; i < 4; i++) m.journal[m.io_base + 4 * (size_t)idx + i] = (uint8_t)(w >> (8 * i));
             }
-            wr_reg = 11; set(left);
-            if (left) next = m.pc;
-            else m.io_active = false;
+            set(idx);
+            next = m.pc;
             break;
           }
           case 3: wr_reg = 10; set((uint32_t)m.cycles); break;
@@ -545,6 +554,7 @@ const char* column_name(uint32_t column) {
     n.push_back("c3");
     for (const char* s : {"dv", "ovf", "k0", "a31"}) n.push_back(s);
     run("at", 8);
+    n.push_back("io");
     return n;
   }();
   return column < names.size() ? names[column].c_str() : nullptr;

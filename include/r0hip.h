@@ -358,10 +358,14 @@ const char* r0h_zlib_inflate(const uint8_t* in, size_t n, uint8_t** out, size_t*
 /* ---- RV32IM executor, segmenter and preflight trace (csrc/rv32im.cpp): the part of `prover.prove(env, elf)`
  * that runs before prove_segment.  Pure host code.  Instruction semantics are the RISC-V specification's; the ecall ABI, the cycle
  * model and the page Merkle root are this library's own documented choices (risc0's are recalled in outline only: see the source).
- * ecall (a7): 0 HALT(a0) | 1 READ_WORDS(a0 = dst, a1 = n) | 2 COMMIT(a0 = src, a1 = n bytes) | 3 CYCLES -> a0 | 4 PAUSE(a0).
- * The two I/O ecalls move ONE word per cycle, the way `rep movs` does: the instruction re-executes (next pc = pc) with a1 counting
- * down until it is 0, so that every cycle has at most one memory access -- what the trace circuit's row has room for -- and a
- * transfer of any length can be cut between two segments.  a1 is 0 afterwards; a0 is left as it was. ---- */
+ * Guest memory is the low 1 GiB (an access or a pc above it traps).
+ * ecall (a7): 0 HALT(a0) | 1 READ_WORDS(a0 = dst, a1 = n words) | 2 COMMIT(a0 = src, a1 = n words) | 3 CYCLES -> a0 | 4 PAUSE(a0);
+ * every ecall cycle reads a7 and a0 (its two register reads).  The two transfers move ONE word per cycle and keep no state
+ * outside the registers: while a1 = j > 0 the instruction re-executes (next pc = pc) -- it moves word j - 1 of the buffer
+ * (address a0 + 4 (j - 1)) and writes a1 = j - 1 -- and with a1 = 0 it falls through to pc + 4 (n + 1 cycles for n words).  So
+ * every cycle has at most one memory access and is a function of what it reads -- what the trace circuit constrains -- and a
+ * transfer of any length can be cut between two segments.  The buffer ends up in stream order; a1 is 0 afterwards, a0 as it was;
+ * a0 is word-aligned. ---- */
 typedef struct r0h_vm r0h_vm;
 typedef struct {
   uint32_t segment_po2;     /* a segment holds at most 2^segment_po2 rows (cycles + paging + boundary rows) */
@@ -426,23 +430,33 @@ const char* r0h_vm_preflight(const r0h_vm* vm, size_t i, const r0h_preflight_row
 const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_bound** rows, size_t* n);
 /* ---- the trace circuit (circuits/trace.r0c, tools/gen_circuit.py): a circuit whose DATA group IS the preflight trace of a segment.
  * R0H_TRACE_COLUMNS columns of 2^po2 rows, column-major, Montgomery words: first the cycles (one row each), then the boundary rows
- * (one per register / word touched), then blank rows.  Per cycle: pc, next pc, the instruction word bit by bit, opcode-class flags,
- * and five accesses -- x[rs1], x[rs2], x[rd], the memory word, the fetched word -- each as (address, value, timestamp of the
- * previous access, own timestamp).  What the circuit constrains:
+ * (one per register / word touched), then blank rows.  Per cycle: pc, next pc, the instruction word bit by bit with its one-hot
+ * opcode and funct3, five accesses -- x[rs1], x[rs2], x[rd], the memory word, the fetched word -- each as (address, value, timestamp
+ * of the previous access, own timestamp), and the work words of the arithmetic units: two operands bit by bit (U, V), two words in
+ * radix-4 digits (Z, W), carries.  What the circuit constrains (tools/gen_circuit.py trace_constraints, 488 polynomials of
+ * degree <= 5; csrc/trace.hpp fills the columns):
  *   - the cycles form one contiguous run from the public first pc to the public last pc in the public number of cycles;
- *   - control flow follows the instruction words: a step leaves pc + 4 only at a JAL / JALR / branch / ecall word, JAL goes to
- *     pc + imm_J, a branch to pc + 4 or pc + imm_B, an ecall to pc or pc + 4;
+ *   - WHAT EVERY INSTRUCTION DOES: the word decodes to exactly one RV32IM instruction (an illegal encoding has no satisfying row);
+ *     the value written to rd, the word written to memory, the address of a load / store and the next pc are the ones the ISA
+ *     prescribes for the operands read -- a 32-bit adder over 16-bit halves (ADD[I], AUIPC, addresses, JALR; backwards for SUB,
+ *     SLT[I][U] and the branches), bit-sliced AND / OR / XOR, a byte-limb multiplier with a range-checked carry chain (MUL[H[S]U],
+ *     the shifts as products with 2^s or 2^(32-s), DIV[U] / REM[U] as quotient x divisor + remainder = dividend with
+ *     |remainder| < |divisor|), byte and half lanes of the narrow loads and stores; an ecall reads a7 and a0, and what it writes
+ *     (a1 counted down and one word of the buffer for the transfers, a0 for CYCLES, nothing for HALT / PAUSE) is where its
+ *     function says.  Every word written to a register or to memory is range-checked or composed of range-checked parts;
  *   - MEMORY CONSISTENCY over registers and memory as one address space (offline memory checking): every access reads the tuple
  *     (address, value, timestamp) the previous access to that address wrote and writes a new one with a larger timestamp; the
  *     boundary rows write each address's first tuple (timestamp 0) and read its last; the multiset of tuples read equals the
- *     multiset written, checked as a grand product over r0h_prefix_products in the ACCUM group; boundary addresses strictly
- *     increase, so an address has ONE history.  Hence a register or word read returns what was last written to it, the
- *     instruction word at a pc is the word in memory, x0 reads as zero, rs1 / rs2 / rd are the registers the word names.
- * What it does NOT constrain: what an instruction computes (ALU results, branch conditions, load/store addresses, JALR targets:
- * risc0's rv32im circuit, not reproducible here), and that the first values of the boundary rows are the pre-state's memory
- * (risc0 pages memory in through in-circuit Merkle proofs).  Public inputs: 8 words naming the segment's ReceiptClaim
- * (r0h_claim_globals), first pc, pc after the last cycle, number of cycles.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
-#define R0H_TRACE_COLUMNS 288
+ *     multiset written, checked as a grand product over r0h_prefix_products in the ACCUM group; boundary addresses (below
+ *     2^28 + 32) strictly increase, so an address has ONE history.  Hence a register or word read returns what was last written
+ *     to it, the instruction word at a pc is the word in memory, x0 reads as zero, rs1 / rs2 / rd are the registers the word names.
+ * What it does NOT constrain: the WORDS an I/O ecall moves (input words are the host's to choose, as in risc0; the journal is bound
+ * by the claim's output digest outside the circuit) and the value CYCLES returns; that the first values of the boundary rows
+ * are the pre-state's memory and the last ones the post-state's (risc0 pages memory in and out through in-circuit Merkle proofs:
+ * SHA-256 in the circuit); the exit code in the claim.  It is this library's circuit for this library's executor, not risc0's
+ * rv32im circuit.  Public inputs: 8 words naming the segment's ReceiptClaim (r0h_claim_globals), first pc, pc after the last
+ * cycle, number of cycles.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
+#define R0H_TRACE_COLUMNS 289
 #define R0H_TRACE_GLOBALS 11
 #define R0H_TRACE_MAX_PO2 21
 const char* r0h_trace_column_name(uint32_t column); /* static string; NULL past the last column */

@@ -42,7 +42,7 @@ def stand_in_guest_elf():
         # hexloop: top nibble of t1 -> ASCII
         I(28, T1, 5, T0, 0x13), I(4, T1, 1, T1, 0x13), ADDI(T5, T0, -10), B(8, 0, T5, 4), ADDI(T0, T0, 39), ADDI(T0, T0, 48), S(0, T0, S2, 0), ADDI(S2, S2, 1),
         ADDI(T3, T3, -1), B(-36, 0, T3, 1),
-        LI(A0, data), ADDI(A1, 0, len(frame)), ADDI(A7, 0, 2), ECALL,          # COMMIT(frame)
+        LI(A0, data), ADDI(A1, 0, len(frame) // 4), ADDI(A7, 0, 2), ECALL,     # COMMIT(frame), in words
         ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
     code = struct.pack("<%dI" % len(prog), *prog)
     ehdr = b"\x7fELF" + bytes([1, 1, 1, 0]) + bytes(8) + struct.pack("<HHIIIIIHHHHHH", 2, 243, 1, text, 52, 0, 0, 52, 32, 2, 0, 0, 0)

@@ -24,7 +24,7 @@ def _check_segment(vm, k, carried):
     rows = vm.preflight(k)
     for c, w in enumerate(rows):
         assert w.cycle == c and (c == 0 or w.pc == rows[c - 1].next_pc)
-        i1, i2 = (w.insn >> 15) & 31, (w.insn >> 20) & 31
+        i1, i2 = ((w.insn >> 15) & 31, (w.insn >> 20) & 31) if w.insn != 0x73 else (17, 10)  # an ecall reads a7 and a0
         acc = [(REG + i1, w.rs1_value, w.rs1_value) if i1 else None, (REG + i2, w.rs2_value, w.rs2_value) if i2 else None,
                (REG + w.rd, w.rd_before, w.rd_after) if w.rd else None, (w.mem_addr >> 2, w.mem_before, w.mem_after) if w.mem_kind else None,
                (w.pc >> 2, w.insn, w.insn)]

@@ -224,14 +224,14 @@ def test_loads_stores_branches_and_jumps():
 
 
 def _guest(n_loop):
-    """reads two input words, loops n_loop times doing memory traffic over several pages, commits 8 bytes, halts with 0"""
+    """reads two input words, loops n_loop times doing memory traffic over several pages, commits two words, halts with 0"""
     buf, scratch = 0x10000, 0x20000
     return flat(LI(A0, buf), ADDI(A1, 0, 2), ADDI(A7, 0, 1), ECALL,              # READ_WORDS(buf, 2)
                 LI(S0, scratch), LI(T2, n_loop), ADDI(T1, 0, 0),
                 # loop body: store counter at scratch + (t1 & 0xFFC) * 16 (walks pages), accumulate
                 I(0xFFC, T1, 7, T0, 0x13), I(4, T0, 1, T0, 0x13), R(0, S0, T0, 0, T0), S(0, T1, T0, 2), ADDI(T1, T1, 4), ADDI(T2, T2, -1), B(-24, 0, T2, 1),
                 LI(A0, buf), I(0, A0, 2, T0, 0x03), R(0, T1, T0, 0, T0), S(0, T0, A0, 2),   # buf[0] += t1
-                ADDI(A1, 0, 8), ADDI(A7, 0, 2), ECALL,                                      # COMMIT(buf, 8)
+                ADDI(A1, 0, 2), ADDI(A7, 0, 2), ECALL,                                      # COMMIT(buf, 2 words)
                 ADDI(A7, 0, 3), ECALL, ADDI(S1, A0, 0),                                     # CYCLES -> s1
                 ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
 
@@ -298,13 +298,15 @@ def test_segmenter_cuts_a_run_and_the_claims_chain_like_a_receipts(orc):
 
 def test_an_io_ecall_moves_one_word_per_cycle_and_can_be_cut_anywhere():
     """tools/fuzz (round 2) found that a READ_WORDS or COMMIT which touches every page of its buffer inside ONE cycle cannot be
-    priced like an ordinary instruction.  Since round 3 the two I/O ecalls re-execute once per word (a1 counts down to 0, the pc
-    stays put until then), so a cycle has one memory access, pays for at most its own pages, and a transfer of any length is cut
-    between two segments like any other stretch of the run; the journal and the memory come out the same."""
+    priced like an ordinary instruction.  Since round 3 the two I/O ecalls re-execute once per word: while a1 = j > 0 the cycle
+    moves word j - 1 of the buffer and writes a1 = j - 1, with a1 = 0 the ecall falls through (n + 1 cycles for n words, no state
+    outside the registers -- what the trace circuit constrains).  A cycle has one memory access, pays for at most its own pages,
+    and a transfer of any length is cut between two segments like any other stretch of the run; the journal and the memory come
+    out in stream order."""
     buf = 0x40000
     def prog(n_words):
         return flat([ADDI(T0, T0, 1)] * 40, LI(A0, buf), LI(A1, n_words), ADDI(A7, 0, 1), ECALL,   # 40 cheap cycles, then READ_WORDS(buf, n)
-                    LI(A0, buf + 1), LI(A1, 4 * n_words - 2), ADDI(A7, 0, 2), ECALL,                 # COMMIT(buf + 1, 4 n - 2): unaligned at both ends
+                    LI(A0, buf + 4), LI(A1, n_words - 2), ADDI(A7, 0, 2), ECALL,                     # COMMIT(buf + 4, n - 2 words)
                     ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
     def run(n_words, po2, cin, cout, **kw):
         vm = r0.Vm()
@@ -313,19 +315,24 @@ def test_an_io_ecall_moves_one_word_per_cycle_and_can_be_cut_anywhere():
         vm.set_input(list(range(1, n_words + 1)))
         return vm, vm.run(segment_po2=po2, page_in_cycles=cin, page_out_cycles=cout, **kw)
     n = 20 * 256  # 20 pages of 1 KiB
-    want = struct.pack("<%dI" % n, *range(1, n + 1))[1:-1]
+    want = struct.pack("<%dI" % n, *range(1, n + 1))[4:-4]
     for cin, cout in ((8, 8), (30, 30)):
         vm, (kind, code) = run(n, 9, cin, cout)
         segs = vm.segments()
         assert (kind, code) == (0, 0) and len(segs) >= 20 and vm.journal == want and vm.read(buf, n).tolist() == list(range(1, n + 1))
-        assert vm.reg(A1) == 0 and vm.cycles == 40 + 2 + 2 + 1 + n + 2 + 2 + 1 + n + 3  # one cycle per word moved (COMMIT: per word touched, n of them here)
+        assert vm.reg(A1) == 0 and vm.cycles == 40 + 2 + 2 + 1 + (n + 1) + 2 + 2 + 1 + (n - 2 + 1) + 3  # one cycle per word moved and one to fall through
         for s in segs:
             assert s.user_cycles + s.paging_cycles <= 1 << 9, (s.index, s.user_cycles, s.paging_cycles)
     # the rows of such a transfer: the ecall word at one pc, one memory word each, a1 written every time
     vm, _ = run(6, 20, 0, 0, keep_trace=True)
-    io = [w for w in vm.preflight(0) if w.insn == ECALL and w.mem_kind == r0.MEM_WRITE]
-    assert len(io) == 6 and len({w.pc for w in io}) == 1 and [w.next_pc - w.pc for w in io] == [0] * 5 + [4]
-    assert [w.mem_addr for w in io] == [buf + 4 * k for k in range(6)] and [(w.rd, w.rd_after) for w in io] == [(A1, 5 - k) for k in range(6)]
+    io = [w for w in vm.preflight(0) if w.insn == ECALL and w.rs1_value == 1]
+    assert len(io) == 7 and len({w.pc for w in io}) == 1 and [w.next_pc - w.pc for w in io] == [0] * 6 + [4]
+    assert [w.mem_kind for w in io] == [r0.MEM_WRITE] * 6 + [r0.MEM_NONE] and [w.mem_addr for w in io[:6]] == [buf + 4 * k for k in range(5, -1, -1)]  # back to front
+    assert [w.mem_after for w in io[:6]] == [6, 5, 4, 3, 2, 1] and vm.read(buf, 6).tolist() == [1, 2, 3, 4, 5, 6]                                  # ... in stream order
+    assert [(w.rd, w.rd_before, w.rd_after) for w in io] == [(A1, 6 - k, 5 - k) for k in range(6)] + [(A1, 0, 0)]
+    assert all(w.rs2_value == buf for w in io)                       # every ecall cycle reads a7 and a0
+    halt = vm.preflight(0)[-1]
+    assert (halt.insn, halt.rs1_value, halt.rs2_value, halt.rd, halt.mem_kind) == (ECALL, 0, 0, 0, r0.MEM_NONE)
     # a count in the millions (the fuzzer's input: 33 M words) costs cycles, not memory up front: the session limit ends it
     vm = r0.Vm()
     vm.load(0x1000, flat(LI(2, 0x02001000), ADDI(A1, 2, 4), ADDI(A7, 0, 1), ADDI(A0, 2, 0), ECALL))

@@ -55,7 +55,7 @@ def main():
         # reads two input words, then n_loop times: store the counter at scratch + ((t1 & 0x7fc) << 4) (a 32 KiB window, 32 pages), count
         prog = flat(LI(A0, buf), ADDI(A1, 0, 2), ADDI(A7, 0, 1), ECALL, LI(S0, scratch), LI(T2, n_loop), ADDI(T1, 0, 0),
                     I(0x7FC, T1, 7, T0, 0x13), I(4, T0, 1, T0, 0x13), R(0, S0, T0, 0, T0), S(0, T1, T0, 2), ADDI(T1, T1, 4), ADDI(T2, T2, -1), B(-24, 0, T2, 1),
-                    LI(A0, buf), I(0, A0, 2, T0, 0x03), R(0, T1, T0, 0, T0), S(0, T0, A0, 2), ADDI(A1, 0, 8), ADDI(A7, 0, 2), ECALL,
+                    LI(A0, buf), I(0, A0, 2, T0, 0x03), R(0, T1, T0, 0, T0), S(0, T0, A0, 2), ADDI(A1, 0, 2), ADDI(A7, 0, 2), ECALL,
                     ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
         elf, stream = elf_of(prog, 0x400), [7, 0x01020304]
         what = "store loop over a 32 KiB window (7 instructions per iteration, one store), about %d cycles" % args.cycles

@@ -13,7 +13,7 @@ Shapes:
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
   recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
-  trace  W=(16, 4, 288)                     columns = the executor's preflight rows; one contiguous run, every instruction's semantics, memory consistency
+  trace  W=(16, 4, 289)                     columns = the executor's preflight rows; one contiguous run, every instruction's semantics, memory consistency
 """
 import argparse
 import struct
@@ -286,7 +286,8 @@ TRACE_COLUMNS = (["live", "bnd", "cycle", "pc", "next_pc", "insn_lo", "insn_hi"]
                  + ["res_lo", "res_hi", "c0", "c1", "lt", "eq", "zinv", "ob0", "ob1", "sb", "sgn", "p8", "sx", "sm"]
                  + ["mb%d" % k for k in range(4)]                                                     # second multiplier operand, byte limbs
                  + ["cx%d" % k for k in range(4)] + ["c3"]                                            # carry digits beyond access 3's twelve; top carry
-                 + ["dv", "ovf", "k0", "a31"] + ["at%d" % k for k in range(8)])                       # division: active, the overflow case, a carry, the dividend's sign and the digits under it
+                 + ["dv", "ovf", "k0", "a31"] + ["at%d" % k for k in range(8)]                        # division: active, the overflow case, a carry, the dividend's sign and the digits under it
+                 + ["io"])                                                                            # an ecall that moves words
 TRACE_GLOBALS = 11   # claim words 0..7, first pc, pc after the last cycle, cycles
 REG_BASE = 1 << 28   # registers sit above 2^28 words = 1 GiB of memory
 SEC_ACCUM_FP = 8
@@ -444,7 +445,8 @@ def trace_constraints():
     res = [d("res_lo"), d("res_hi")]
     is_mem = opc["load"] + opc["store"]
     isdiv = mext * bits[14]
-    use_b, use_i = opc["op"] + opc["branch"] + opc["store"], opc["imm"] + opc["load"] + opc["jalr"]
+    sys_ = opc["system"]
+    use_b, use_i = opc["op"] + opc["branch"] + opc["store"] + sys_, opc["imm"] + opc["load"] + opc["jalr"]
     for h, nm in enumerate(("lo", "hi")):
         C("u:" + nm, (1 - isdiv) * (u[h] - (is_mem * before[h] + (1 - is_mem) * a[h])))  # U: the word of a load / store, x[rs1] otherwise (a division row keeps its quotient there)
         C("v:" + nm, v[h] - (use_b * rs2[h] + use_i * immi[h]))               # V: x[rs2] or the I-immediate
@@ -452,7 +454,9 @@ def trace_constraints():
     for nm, x in (("c0", c0), ("c1", c1), ("lt", lt), ("eq", eq), ("ob0", ob0), ("ob1", ob1)):
         bit(x, nm)
     C("z:low_bits", zd[0] - ob0 - 2 * ob1)
-    zero_of = z[0] + z[1] + isdiv * (v[0] + v[1] - z[0] - z[1])          # the zero test looks at Z; on a division row at the divisor
+    old = [d("old_lo"), d("old_hi")]
+    # the zero test looks at Z; on a division row at the divisor; on an ecall row at the register it counts down
+    zero_of = z[0] + z[1] + isdiv * (v[0] + v[1] - z[0] - z[1]) + sys_ * (old[0] + old[1] - z[0] - z[1])
     C("eq:zero", eq * zero_of)                                          # eq = 1 iff that word is 0 (both halves are 16-bit: no wrap)
     C("eq:inv", zero_of * zinv - (1 - eq))
     differ = ub[31] + vb[31] - 2 * ub[31] * vb[31]
@@ -466,6 +470,7 @@ def trace_constraints():
     C("store:addr_lo", opc["store"] * (a[0] + imms[0] - z[0] - 65536 * c0))
     C("store:addr_hi", opc["store"] * (a[1] + imms[1] + c0 - z[1] - 65536 * c1))
     C("auipc:pc", opc["auipc"] * (w[0] + 65536 * w[1] - pc))
+    C("auipc:range", opc["auipc"] * wd[15])                             # W is the pc itself, not pc + p
     C("auipc:lo", opc["auipc"] * (w[0] + immu[0] - z[0] - 65536 * c0))
     C("auipc:hi", opc["auipc"] * (w[1] + immu[1] + c0 - z[1] - 65536 * c1))
     C("sub:lo", sel_sub * (v[0] + z[0] - a[0] - 65536 * c0))
@@ -480,10 +485,10 @@ def trace_constraints():
     taken = f3[0] * eq + f3[1] * (1 - eq) + f3[4] * lt + f3[5] * (1 - lt) + f3[6] * c1 + f3[7] * (1 - c1)
     C("next:branch", opc["branch"] * (next_pc - pc - 4 - taken * (imm_b - 4)))
     step = next_pc - pc
-    C("next:ecall", opc["system"] * step * (step - 4))                  # an I/O ecall repeats (pc) or completes (pc + 4)
     C("link", link * (w[0] + 65536 * w[1] - pc - 4))
+    C("link:range", link * wd[15])
     # --- loads and stores
-    C("mem:kind", (1 - opc["system"]) * (d("mem_kind") - opc["load"] - 2 * opc["store"]))
+    C("mem:kind", (1 - sys_) * (d("mem_kind") - opc["load"] - 2 * opc["store"]))
     C("mem:addr", is_mem * (4 * d("addr3") + zd[0] - z[0] - 65536 * z[1]))
     C("mem:range", is_mem * zd[15])                                     # 1 GiB of memory
     narrow_h = opc["load"] * (f3[1] + f3[5]) + opc["store"] * f3[1]
@@ -621,10 +626,10 @@ def trace_constraints():
         zk, act = d(zn), d(actn)
         C("rs%d:zero" % (k + 1), zk * idx)                              # z = 1 iff the index is 0 ...
         C("rs%d:inv" % (k + 1), idx * d(invn) - (1 - zk))
-        C("rs%d:act" % (k + 1), act - live * (1 - zk))                  # x0 is not memory: no access
+        C("rs%d:act" % (k + 1), act - live * (1 - zk) - sys_)           # x0 is not memory: no access (an ecall reads a7 / a0 here)
         for hf in ("lo", "hi"):
-            C("rs%d:x0_%s" % (k + 1, hf), zk * d("rs%d_%s" % (k + 1, hf)))  # ... and reads as zero
-        C("rs%d:addr" % (k + 1), act * (d("addr%d" % k) - REG_BASE - idx))  # the register the word names
+            C("rs%d:x0_%s" % (k + 1, hf), zk * (1 - sys_) * d("rs%d_%s" % (k + 1, hf)))  # ... and reads as zero
+        C("rs%d:addr" % (k + 1), act * (d("addr%d" % k) - REG_BASE - idx - (17, 10)[k] * sys_))  # the register the word names
         C("rs%d:tw" % (k + 1), act * (d("tw%d" % k) - stamp(k)))
         C("rs%d:idle" % (k + 1), (1 - act) * (d("tw%d" % k) - d("p%d" % k)))
         ordered(act, k)
@@ -636,7 +641,26 @@ def trace_constraints():
     writes = opc["lui"] + opc["auipc"] + link + opc["load"] + opc["imm"] + opc["op"]
     C("rd:act", (1 - opc["system"]) * (act2 - writes * (1 - zrd)))      # an instruction with a destination other than x0 writes it
     C("rd:addr", act2 * (1 - opc["system"]) * (d("addr2") - REG_BASE - idx_rd))
-    C("rd:ecall", act2 * opc["system"] * (d("addr2") - (REG_BASE + 10)) * (d("addr2") - (REG_BASE + 11)))  # an ecall writes a0 or a1
+    # --- ecalls: U = a7 names the function (0 HALT, 1 READ_WORDS, 2 COMMIT, 3 CYCLES, 4 PAUSE), V = a0.  The two transfers count a1
+    # down: while a1 = j > 0 the cycle moves word j - 1 of the buffer at a0, writes a1 = j - 1 and repeats; with a1 = 0 it falls
+    # through.  What is moved -- input words in, journal words out -- is the host's to say (as the input is in risc0): the words read in
+    # are range-checked, the journal is bound by the claim's output digest outside the circuit.  CYCLES writes a0 (range-checked).
+    io = d("io")
+    fn_read_or_commit = ub[0] + ub[1] - 2 * ub[0] * ub[1]
+    C("ecall:fn_lo", sys_ * (a[0] - ub[0] - 2 * ub[1] - 4 * ub[2]))
+    C("ecall:fn_hi", sys_ * a[1])
+    C("ecall:fn_max", sys_ * ub[2] * (ub[0] + ub[1]))
+    C("ecall:io", io - sys_ * fn_read_or_commit * (1 - ub[2]))
+    active = io * (1 - eq)                                              # eq: a1 = 0
+    C("ecall:act2", sys_ * (act2 - io - ub[0] * ub[1]))                 # the transfers write a1, CYCLES writes a0, HALT / PAUSE nothing
+    C("ecall:rd", act2 * sys_ * (d("addr2") - (REG_BASE + 11) + ub[0] * ub[1]))
+    C("ecall:count", io * (d("new_lo") + 65536 * d("new_hi") - old[0] - 65536 * old[1] + 1 - eq))
+    for k in (13, 14, 15):
+        C("ecall:count_range_%d" % k, io * zd[k])                       # at most 2^26 words: the count is itself and not itself + p
+    C("next:ecall", sys_ * (next_pc - pc - 4 + 4 * active))             # repeats while it moves, then falls through
+    C("ecall:mem", sys_ * (d("mem_kind") - active * (2 * ub[0] + ub[1])))  # READ_WORDS writes memory, COMMIT reads it
+    C("ecall:addr", active * (4 * d("addr3") - rs2[0] - 65536 * rs2[1] - 4 * (z[0] + 65536 * z[1])))
+    C("ecall:buffer", io * (vb[0] + vb[1] + vb[30] + vb[31]))           # a0: word-aligned, below 1 GiB
     C("rd:tw", act2 * (d("tw2") - stamp(2)))
     for x_, y_ in (("tw2", "p2"), ("new_lo", "old_lo"), ("new_hi", "old_hi")):
         C("rd:idle_" + x_, (1 - act2) * (d(x_) - d(y_)))

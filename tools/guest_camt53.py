@@ -20,7 +20,7 @@ methods/guest/src/main.rs:719-756 (`decrypt_order_data`) and :836-981 (the camt5
   9. commits {"hostinfo":..,"iban":..,"pub_bank_pem":..,"pub_witness_pem":..,"pub_client_pem":..,"stmts":[{"elctrnc_seq_nb":..,
      "fr_dt_tm":..,"to_dt_tm":..,"amt":..,"ccy":..,"cd":..},..]} as a serde-framed string and halts with 0 -- exit 8 when no
      document matches.  The three keys are the moduli the RSA checks used, re-encoded by the guest as SubjectPublicKeyInfo PEM
-     (exponent 65537, DER, base64 in lines of 64, line ends escaped as the two characters \ n), as main.rs:237-243 does.
+     (exponent 65537, DER, base64 in lines of 64, line ends escaped as a backslash and an n), as main.rs:237-243 does.
 
 The reference holds two committed receipts for this fixture and the program's journal IS their `journal.bytes`, byte for byte
 (tests/test_guest_camt53.py): data/test/test.xml-Receipt-6bb958..-latest.json in the current form above (commitment form 1), and
@@ -408,8 +408,7 @@ class Camt53:
         a.addi(T2, T2, -4)           # length of the string
         a.sw(T2, 0, T1)
         a.addi(T2, T2, 7)            # 4 bytes of length + the string, zero-padded to a word boundary
-        a.srli(T2, T2, 2)
-        a.slli(A1, T2, 2)
+        a.srli(A1, T2, 2)            # COMMIT takes words
         a.mv(A0, T1)
         a.li(A7, 2)
         a.ecall()

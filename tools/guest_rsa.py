@@ -197,7 +197,7 @@ def emit_commit(a, L, frame, halt):
     a.la(A1, L["JSON"] + 4 + TEMPLATE.rindex(b"0" * 64))
     a.call("hex32")
     a.la(A0, L["JSON"])
-    a.li(A1, (len(frame) + 3) & ~3)
+    a.li(A1, (len(frame) + 3) >> 2)  # COMMIT takes words
     a.li(A7, 2)
     a.ecall()
     halt(0)
