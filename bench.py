@@ -502,7 +502,7 @@ def prove_elf_session(hal, entry):
                 "segments": n, "cycles": cycles, "wall_s": round(wall, 4), "guest": what,
                 "executor_MHz_with_trace_kept": round(cycles / st["executor_s"] / 1e6, 1), "executor_host_ms_per_segment": round(1e3 * st["executor_s"] / n, 2),
                 "witgen_ms_per_segment": round(st["witgen_ms"] / n, 2), "prove_ms_per_segment": round(st["prove_ms"] / n, 2),
-                "circuit": "trace.r0c W=(%d accum, %d code, %d data): contiguity, control flow and memory consistency of the run (not instruction semantics)" % tuple(gc.group_size),
+                "circuit": "trace.r0c W=(%d accum, %d code, %d data): one contiguous run, every instruction's semantics (RV32IM, the ecalls' register and memory effects), memory consistency" % tuple(gc.group_size),
                 "receipt_verified_against_image_id": verdict[:2] == (0, "ok"),
                 "journal_is_the_reference_receipt_fixtures": receipt.journal == want_journal,
                 "journal": r0.journal_commitment(receipt.journal).decode()[:80] + " ..."}
