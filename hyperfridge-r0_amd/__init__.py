@@ -557,7 +557,7 @@ class ReceiptClaim(ctypes.Structure):
         return claim_globals(self.digest())
 
 
-TRACE_COLUMNS = 289  # R0H_TRACE_COLUMNS
+TRACE_COLUMNS = 288  # R0H_TRACE_COLUMNS
 TRACE_GLOBALS = 11   # R0H_TRACE_GLOBALS: claim words 0..7, first pc, pc after the last cycle, cycles
 TRACE_MAX_PO2 = 21
 REG_BASE = 0x10000000  # R0H_REG_BASE: address of x[i] in the trace circuit's one address space (memory: word index)

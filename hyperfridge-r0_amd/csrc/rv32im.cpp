@@ -539,7 +539,7 @@ const char* column_name(uint32_t column) {
     run("bit", 32);
     for (const char* s : {"lui", "auipc", "jal", "jalr", "branch", "load", "store", "imm", "op", "fence", "system"}) n.push_back(std::string("opc_") + s);
     run("f3_", 8);
-    for (const char* s : {"alu", "mext", "z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0", "z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1",
+    for (const char* s : {"alu", "z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0", "z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1",
                           "zrd", "inv_rd", "act2", "addr2", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2",
                           "mem_kind", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "tw3", "addr4", "p4", "tw4"})
       n.push_back(s);

@@ -456,7 +456,7 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
  * SHA-256 in the circuit); the exit code in the claim.  It is this library's circuit for this library's executor, not risc0's
  * rv32im circuit.  Public inputs: 8 words naming the segment's ReceiptClaim (r0h_claim_globals), first pc, pc after the last
  * cycle, number of cycles.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
-#define R0H_TRACE_COLUMNS 289
+#define R0H_TRACE_COLUMNS 288
 #define R0H_TRACE_GLOBALS 11
 #define R0H_TRACE_MAX_PO2 21
 const char* r0h_trace_column_name(uint32_t column); /* static string; NULL past the last column */

@@ -13,7 +13,7 @@ Shapes:
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
   recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
-  trace  W=(16, 4, 289)                     columns = the executor's preflight rows; one contiguous run, every instruction's semantics, memory consistency
+  trace  W=(16, 4, 288)                     columns = the executor's preflight rows; one contiguous run, every instruction's semantics, memory consistency
 """
 import argparse
 import struct
@@ -272,7 +272,7 @@ TRACE_COLUMNS = (["live", "bnd", "cycle", "pc", "next_pc", "insn_lo", "insn_hi"]
                  + ["bit%d" % k for k in range(32)]                                                   # the instruction word, bit by bit
                  + ["opc_" + name for name, _ in OPCODES]                                             # one-hot opcode
                  + ["f3_%d" % k for k in range(8)]                                                    # one-hot funct3
-                 + ["alu", "mext"]                                                                    # OP-IMM or base-ISA OP; M-extension OP
+                 + ["alu"]                                                                            # OP-IMM or base-ISA OP (M-extension OP is opc_op * bit25)
                  + ["z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0"]                   # access 0: x[rs1] read
                  + ["z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1"]                   # access 1: x[rs2] read
                  + ["zrd", "inv_rd", "act2", "addr2", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2"]  # access 2: x[rd] write
@@ -403,9 +403,8 @@ def trace_constraints():
         bit(v, "f3_%d" % k)
     C("f3:one", lin(b, [(1, v) for v in f3]) - 1)
     C("f3:code", lin(b, [(k, f3[k]) for k in range(8)]) - (bits[12] + 2 * bits[13] + 4 * bits[14]))
-    alu, mext = d("alu"), d("mext")
+    alu, mext = d("alu"), opc["op"] * bits[25]
     C("alu", alu - (opc["imm"] + opc["op"] * (1 - bits[25])))
-    C("mext", mext - opc["op"] * bits[25])
     for k in (26, 27, 28, 29, 31):
         C("op:f7_%d" % k, opc["op"] * bits[k])
     C("op:f7_m_alt", opc["op"] * bits[25] * bits[30])
@@ -654,7 +653,8 @@ def trace_constraints():
     active = io * (1 - eq)                                              # eq: a1 = 0
     C("ecall:act2", sys_ * (act2 - io - ub[0] * ub[1]))                 # the transfers write a1, CYCLES writes a0, HALT / PAUSE nothing
     C("ecall:rd", act2 * sys_ * (d("addr2") - (REG_BASE + 11) + ub[0] * ub[1]))
-    C("ecall:count", io * (d("new_lo") + 65536 * d("new_hi") - old[0] - 65536 * old[1] + 1 - eq))
+    C("ecall:count_lo", io * (old[0] - (1 - eq) - d("new_lo") + 65536 * c0))  # a1 - 1 (a1 itself at 0) over the halves, c0 the borrow: exact in 32 bits
+    C("ecall:count_hi", io * (old[1] - c0 - d("new_hi")))
     for k in (13, 14, 15):
         C("ecall:count_range_%d" % k, io * zd[k])                       # at most 2^26 words: the count is itself and not itself + p
     C("next:ecall", sys_ * (next_pc - pc - 4 + 4 * active))             # repeats while it moves, then falls through
