@@ -346,6 +346,26 @@ def test_an_io_ecall_moves_one_word_per_cycle_and_can_be_cut_anywhere():
         vm.run()
 
 
+def test_guest_memory_is_the_low_gibibyte():
+    """Addresses at or above 2^30 trap -- loads, stores, jumps, ecall buffers: the trace circuit carries a pc as one field element and
+    keeps the registers right above 2^28 memory words (R0H_REG_BASE)."""
+    assert r0.REG_BASE == 1 << 28
+    top = 0x40000000
+    for prog, why in [(flat(LI(T0, top), I(0, T0, 2, T1, 0x03)), "load outside"), (flat(LI(T0, top - 4), S(8, T1, T0, 2)), "store outside"),
+                      (flat(LI(T0, top), I(0, T0, 0, 0, 0x67)), "pc outside"),
+                      (flat(LI(A0, top - 8), ADDI(A1, 0, 4), ADDI(A7, 0, 1), ECALL), "ecall buffer outside"),
+                      (flat(LI(A0, top), ADDI(A1, 0, 0), ADDI(A7, 0, 2), ECALL), "ecall buffer outside")]:
+        vm = r0.Vm()
+        vm.load(0x1000, prog)
+        vm.set_pc(0x1000)
+        with pytest.raises(r0.R0HipError, match=why):
+            vm.run()
+    vm = r0.Vm()  # the last word below the line is memory like any other
+    vm.load(0x1000, flat(LI(T0, top - 4), ADDI(T1, 0, 77), S(0, T1, T0, 2), I(0, T0, 2, T2, 0x03), ADDI(A0, T2, 0), ADDI(A7, 0, 0), ECALL))
+    vm.set_pc(0x1000)
+    assert vm.run() == (0, 77)
+
+
 def test_elf_loader():
     prog = flat(ADDI(A0, 0, 42), ADDI(A7, 0, 0), ECALL)
     code = struct.pack("<%dI" % len(prog), *prog)
