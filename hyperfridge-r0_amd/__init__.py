@@ -558,7 +558,7 @@ class ReceiptClaim(ctypes.Structure):
 
 
 TRACE_COLUMNS = 288  # R0H_TRACE_COLUMNS
-TRACE_GLOBALS = 11   # R0H_TRACE_GLOBALS: claim words 0..7, first pc, pc after the last cycle, cycles
+TRACE_GLOBALS = 15   # R0H_TRACE_GLOBALS: claim words 0..7, first pc, pc after the last cycle, cycles, end kind (0 cut / 1 HALT / 2 PAUSE), kind != 0, exit code halves
 TRACE_MAX_PO2 = 21
 REG_BASE = 0x10000000  # R0H_REG_BASE: address of x[i] in the trace circuit's one address space (memory: word index)
 MEM_NONE, MEM_READ, MEM_WRITE = 0, 1, 2  # r0h_preflight_row.mem_kind

@@ -263,7 +263,12 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
     claim_globals(cd, want);
     if (memcmp(want, g.seal.data(), 32) != 0) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
     // the trace circuit proves a run from its public first pc to its public last pc: they are the claim's
-    if (trace_circuit && (circ.n_global < R0H_TRACE_GLOBALS || g.seal[8] != enc(g.claim.pre.pc) || g.seal[9] != enc(g.claim.post.pc))) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
+    // ... and it ends in a HALT / PAUSE ecall exactly when its public inputs say so, with the exit code they carry: the claim's ExitCode
+    if (trace_circuit) {
+      if (circ.n_global < R0H_TRACE_GLOBALS || g.seal[8] != enc(g.claim.pre.pc) || g.seal[9] != enc(g.claim.post.pc)) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
+      const uint32_t kind = g.claim.exit_system == 0 ? 1u : g.claim.exit_system == 1 ? 2u : 0u, code = kind ? g.claim.exit_user : 0u;
+      if (g.seal[11] != enc(kind) || g.seal[12] != enc(kind ? 1u : 0u) || g.seal[13] != enc(code & 0xffffu) || g.seal[14] != enc(code >> 16)) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
+    }
     // composite.rs: indices count up, every segment but the last ends in SystemSplit with no output, and hands its post-state on
     if (g.index != i) return done(R0H_RECEIPT_V_CHAIN, i);
     if (i + 1 < n) {

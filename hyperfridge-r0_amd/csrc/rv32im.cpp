@@ -768,9 +768,7 @@ const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint3
       trace::blank_row(T, put, raw);
     }
   }
-  globals_out[8] = enc(rows.front().pc);
-  globals_out[9] = enc(rows.back().next_pc);
-  globals_out[10] = enc((uint32_t)rows.size());
+  trace::trace_globals(rows.data(), rows.size(), globals_out);
   return nullptr;
   R0H_GUARD_END
 }

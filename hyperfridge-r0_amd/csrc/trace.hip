@@ -65,9 +65,7 @@ const char* r0h_trace_witgen(r0h_ctx* ctx, const r0h_preflight_row* rows, size_t
                      (const r0h_preflight_bound*)(base + row_bytes), (uint32_t)n_bounds, (const trace::Tables*)(base + tab_off), po2);
   hipError_t e = hipGetLastError();
   R0H_REQUIRE(e == hipSuccess, "trace_witgen_kernel: %s", hipGetErrorString(e));
-  globals_out[8] = enc(rows[0].pc);
-  globals_out[9] = enc(rows[n_rows - 1].next_pc);
-  globals_out[10] = enc((uint32_t)n_rows);
+  trace::trace_globals(rows, n_rows, globals_out);
   R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // the staging block goes back to the pool and the caller may free its rows
   return nullptr;
   R0H_GUARD_END

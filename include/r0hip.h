@@ -433,7 +433,7 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
  * (one per register / word touched), then blank rows.  Per cycle: pc, next pc, the instruction word bit by bit with its one-hot
  * opcode and funct3, five accesses -- x[rs1], x[rs2], x[rd], the memory word, the fetched word -- each as (address, value, timestamp
  * of the previous access, own timestamp), and the work words of the arithmetic units: two operands bit by bit (U, V), two words in
- * radix-4 digits (Z, W), carries.  What the circuit constrains (tools/gen_circuit.py trace_constraints, 488 polynomials of
+ * radix-4 digits (Z, W), carries.  What the circuit constrains (tools/gen_circuit.py trace_constraints, 499 polynomials of
  * degree <= 5; csrc/trace.hpp fills the columns):
  *   - the cycles form one contiguous run from the public first pc to the public last pc in the public number of cycles;
  *   - WHAT EVERY INSTRUCTION DOES: the word decodes to exactly one RV32IM instruction (an illegal encoding has no satisfying row);
@@ -453,11 +453,12 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
  * What it does NOT constrain: the WORDS an I/O ecall moves (input words are the host's to choose, as in risc0; the journal is bound
  * by the claim's output digest outside the circuit) and the value CYCLES returns; that the first values of the boundary rows
  * are the pre-state's memory and the last ones the post-state's (risc0 pages memory in and out through in-circuit Merkle proofs:
- * SHA-256 in the circuit); the exit code in the claim.  It is this library's circuit for this library's executor, not risc0's
- * rv32im circuit.  Public inputs: 8 words naming the segment's ReceiptClaim (r0h_claim_globals), first pc, pc after the last
- * cycle, number of cycles.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
+ * SHA-256 in the circuit).  It is this library's circuit for this library's executor, not risc0's rv32im circuit.  Public inputs
+ * (R0H_TRACE_GLOBALS): 8 words naming the segment's ReceiptClaim (r0h_claim_globals), first pc, pc after the last cycle, number of
+ * cycles, how the segment ends (0: cut, 1: HALT, 2: PAUSE -- such an ecall is the last cycle of its segment), that being non-zero,
+ * the two halves of the exit code (a0); r0h_receipt_verify holds them against the claim's pcs and ExitCode.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
 #define R0H_TRACE_COLUMNS 288
-#define R0H_TRACE_GLOBALS 11
+#define R0H_TRACE_GLOBALS 15
 #define R0H_TRACE_MAX_PO2 21
 const char* r0h_trace_column_name(uint32_t column); /* static string; NULL past the last column */
 /* host reference of the witness (what tests compare the device kernel with): data_out = R0H_TRACE_COLUMNS * 2^po2 words;

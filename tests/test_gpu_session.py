@@ -156,8 +156,9 @@ def test_prove_elf_with_the_trace_circuit_proves_the_run_it_executed(hal, orc):
             roots[size], ocodes[size] = cc.root(), c.witgen(size, 0)[0]
             cc.free()
         assert c.verify(seal, code_root=roots[size]) == (0, "ok"), k
-        publics = [orc.dec(int(g)) for g in seal[8:11]]
-        assert publics == [s.pre.pc, s.post.pc, s.user_cycles] and np.array_equal(seal[:8], claims[k].globals())
+        publics = [orc.dec(int(g)) for g in seal[8:15]]
+        ends = [1, 1, 0, 0] if k == len(seals) - 1 else [0, 0, 0, 0]  # HALT(0) ends the last segment, the others are cut
+        assert publics == [s.pre.pc, s.post.pc, s.user_cycles] + ends and np.array_equal(seal[:8], claims[k].globals())
         rows, bounds = vm.preflight_arrays(k)
         data, glob = vm.trace_witness(k, size, claim_globals=claims[k].globals())
         dev, dglob = hal.trace_witgen(rows, bounds, size, claim_globals=claims[k].globals())
@@ -181,7 +182,19 @@ def test_prove_elf_with_the_trace_circuit_proves_the_run_it_executed(hal, orc):
     assert c.verify(seal, code_root=roots[size]) == (0, "ok")
     rc2 = r0.Receipt.new(receipt.journal, [seal] + [s for _, s in seals[1:]], [forged] + claims[1:])
     assert rc2.verify(blob, roots, forged.pre.digest())[:3] == (5, "a seal's public inputs do not name its claim", 0)
-    dev.free(); cc.free()
+    dev.free()
+    # the same for the way the run ends: a claim that says Halted(7) over a run whose last cycle is HALT with a0 = 0
+    k = len(segs) - 1
+    forged = r0.ReceiptClaim.make(segs[k].pre, segs[k].post, 0, 7, claims[k].output_digest)
+    rows, bounds = vm.preflight_arrays(k)
+    size = r0.verify_seal(blob, seals[k][1])[2]
+    dev, glob = hal.trace_witgen(rows, bounds, size, claim_globals=forged.globals())
+    cc2 = hal.code_commit(gc, size)
+    seal = hal.prove_segment(gc, size, cc2, dev, glob)
+    assert c.verify(seal, code_root=roots[size]) == (0, "ok") and [orc.dec(int(g)) for g in seal[11:15]] == [1, 1, 0, 0]
+    rc3 = r0.Receipt.new(receipt.journal, [s for _, s in seals[:-1]] + [seal], claims[:-1] + [forged])
+    assert rc3.verify(blob, roots, image_id)[:3] == (5, "a seal's public inputs do not name its claim", k)
+    dev.free(); cc.free(); cc2.free()
     # the number of prover lanes (contexts of the device that take segments as the executor cuts them) changes who proves what,
     # not what is proved: one lane and three lanes give the receipt of the default two, seal for seal
     for lanes in ("1", "3"):

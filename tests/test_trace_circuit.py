@@ -168,7 +168,7 @@ def test_the_witness_is_the_preflight_trace(orc):
     primary = [COL[c] for c in PRIMARY]
     assert np.array_equal(got[primary], want[primary]), [TRACE_COLUMNS[c] for c in primary if (got[c] != want[c]).any()]
     assert broken(vm, 0, po2) == []  # ... and the derived columns satisfy every constraint
-    assert [orc.dec(int(g)) for g in glob] == [0] * 8 + [base, int(rows[-1, F["next_pc"]]), n]
+    assert [orc.dec(int(g)) for g in glob] == [0] * 8 + [base, int(rows[-1, F["next_pc"]]), n, 1, 1, 0, 0]  # ... ends in HALT(0)
     # the rows themselves: timestamps name the previous access, boundary rows are each address once, in order, with what was found and left
     last, value = {}, {}
     for w in vm.preflight(0):
@@ -406,6 +406,20 @@ def test_an_ecall_row_does_what_its_function_says(orc):
     halt = sysrows[-1][0]
     assert "ecall:mem" in broken(vm, 0, po2, [("mem_kind", halt, 2)])                                            # HALT does not write memory
     assert "ecall:act2" in broken(vm, 0, po2, [("act2", halt, 1), ("addr2", halt, REG + 11), ("tw2", halt, 5 * halt + 3)])  # ... nor a register
+    # the public inputs say how the segment ends: HALT with exit code 5
+    data, glob = vm.trace_witness(0, po2)
+    g = [int(x) * R_INV % P for x in glob]
+    assert g[8:] == [0x1000, rows[-1].next_pc, len(rows), 1, 1, 5, 0]
+    m = canonical(data, po2)
+    for k, wrong, name in ((11, 2, "exit:end_kind"), (13, 6, "exit:end_lo"), (14, 1, "exit:end_hi"), (12, 0, "exit:end_is")):
+        bad = list(g)
+        bad[k] = wrong
+        assert name in [nm for nm, _ in check_trace_rows(m, bad)], name
+    cut = list(g)
+    cut[11:15] = [0, 0, 0, 0]                                                                                   # "this segment was merely cut"
+    assert "exit:end_is" in [nm for nm, _ in check_trace_rows(m, cut)]
+    # ... and a HALT is the last cycle of its segment: nothing runs after it
+    assert "exit:last_cycle" in broken(vm, 0, po2, [("live", len(rows), 1)])
     # an unknown function number has no satisfying row (the executor traps on it)
     assert "ecall:fn_max" in broken(vm, 0, po2, [("rs1_lo", halt, 5), ("ub0", halt, 1), ("ub2", halt, 1)])
 
@@ -512,7 +526,8 @@ def test_every_segment_of_a_cut_run_proves_and_the_boundary_values_chain(orc):
         data, glob = vm.trace_witness(k, 10, claim_globals=vm.claims()[k].globals())
         seal = c.prove(10, code, data, glob)
         assert c.verify(seal, code_root=root) == (0, "ok"), k
-        assert [orc.dec(int(g)) for g in glob[8:]] == [s.pre.pc, s.post.pc, s.user_cycles]
+        last = k == len(segs) - 1
+        assert [orc.dec(int(g)) for g in glob[8:]] == [s.pre.pc, s.post.pc, s.user_cycles] + ([1, 1, 0, 0] if last else [0, 0, 0, 0])  # HALT(0) ends the last one
         for b in vm.boundary(k):
             if b.addr in left:
                 assert left[b.addr] == b.first_value, (k, hex(b.addr))

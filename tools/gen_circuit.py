@@ -288,7 +288,7 @@ TRACE_COLUMNS = (["live", "bnd", "cycle", "pc", "next_pc", "insn_lo", "insn_hi"]
                  + ["cx%d" % k for k in range(4)] + ["c3"]                                            # carry digits beyond access 3's twelve; top carry
                  + ["dv", "ovf", "k0", "a31"] + ["at%d" % k for k in range(8)]                        # division: active, the overflow case, a carry, the dividend's sign and the digits under it
                  + ["io"])                                                                            # an ecall that moves words
-TRACE_GLOBALS = 11   # claim words 0..7, first pc, pc after the last cycle, cycles
+TRACE_GLOBALS = 15   # claim words 0..7, first pc, pc after the last cycle, cycles, how the segment ends (0 cut / 1 HALT / 2 PAUSE), that being non-zero, exit code halves
 REG_BASE = 1 << 28   # registers sit above 2^28 words = 1 GiB of memory
 SEC_ACCUM_FP = 8
 
@@ -705,6 +705,18 @@ def trace_constraints():
     full = last * live                                                  # a trace that fills every row
     C("full:pc", full * (next_pc - gl(G0 + 1)))
     C("full:cycles", full * (cycle + 1 - gl(G0 + 2)))
+    # --- how the segment ends: a HALT / PAUSE ecall is the last cycle of its segment, and the public inputs say which it was (0: the
+    # segment was cut, 1: HALT, 2: PAUSE; G0 + 4 is "not 0", checked against it by the verifier) and with which exit code (a0)
+    ub_p = [d("ub%d" % k, 1) for k in range(3)]
+    term_prev = d("opc_system", 1) * (1 - ub_p[0]) * (1 - ub_p[1])      # the row before was a HALT (a7 = 0) or a PAUSE (a7 = 4)
+    term_here = sys_ * (1 - ub[0]) * (1 - ub[1])
+    C("exit:last_cycle", not_first * term_prev * live)
+    for tag, gate, term, u2, lo, hi in (("end", ended, term_prev, ub_p[2], d("rs2_lo", 1), d("rs2_hi", 1)), ("full", full, term_here, ub[2], rs2[0], rs2[1])):
+        C("exit:%s_is" % tag, gate * (term - gl(G0 + 4)))
+        C("exit:%s_kind" % tag, gate * gl(G0 + 4) * (1 + u2 - gl(G0 + 3)))
+        C("exit:%s_none" % tag, gate * (1 - gl(G0 + 4)) * gl(G0 + 3))
+        C("exit:%s_lo" % tag, gate * (gl(G0 + 4) * lo - gl(G0 + 5)))
+        C("exit:%s_hi" % tag, gate * (gl(G0 + 4) * hi - gl(G0 + 6)))
     # --- the grand products: RS_A, RS_B over the tuples read, WS_A, WS_B over the tuples written
     alpha = [b.glob(1, i) for i in range(4)]
     beta = [[b.glob(1, 4 * (j + 1) + i) for i in range(4)] for j in range(3)]
