@@ -578,6 +578,14 @@ def test_the_device_expands_and_proves_an_execution_trace_word_for_word_like_the
     dev2, _ = hal.trace_witgen(bad, bounds, po2)
     seal = hal.prove_segment(gc, po2, cc, dev2, glob)
     assert c.verify(seal, code_root=root)[0] == 4 and r0.verify_seal(blob, seal, code_root=root)[0] == 4
+    # a wrong result in a register nobody looks at before it is overwritten: memory stays consistent, the instruction does not
+    from soak_trace import dead_write_lie
+    lie = dead_write_lie(rows, bounds, np.random.default_rng(po2))
+    assert lie is not None
+    dev2.free()
+    dev2, _ = hal.trace_witgen(lie[0], lie[1], po2)
+    seal = hal.prove_segment(gc, po2, cc, dev2, glob)
+    assert c.verify(seal, code_root=root)[0] == 4 and r0.verify_seal(blob, seal, code_root=root)[0] == 4
     with pytest.raises(r0.R0HipError, match="do not fit"):
         hal.trace_witgen(rows, bounds, 9 if po2 > 10 else 8)
     cc.free(); code.free(); dev.free(); dev2.free(); gc.free()

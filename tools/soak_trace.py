@@ -3,7 +3,8 @@
 every kind, forward JALs, a backward loop around everything, a READ_WORDS / COMMIT pair) are executed, the device expands their
 compact preflight rows into the trace circuit's witness (r0h_trace_witgen) -- which must equal the host reference word for word --
 and proves each; the seal must equal the CPU oracle's word for word and verify bound to the control root.  Every eighth run is also
-tampered with (one register value read back wrong): both verifiers must refuse it.
+tampered with (one register value read back wrong) and every other eighth carries a wrong result that keeps memory consistent (a dead
+write): both verifiers must refuse both.
 usage: python tools/soak_trace.py [minutes]"""
 import os
 import sys
@@ -61,6 +62,33 @@ def random_program(rng, n):
     return flat(LI(28, 0x40000), ADDI(29, 0, int(rng.integers(1, 7))), loop, io, ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
 
 
+def dead_write_lie(rows, bounds, rng):
+    """A lie that keeps memory consistent: an instruction's result changed in a register nobody reads before it is written again (or
+    never: then its boundary row's last value follows).  Only the constraints of the instruction's own unit can object.
+    -> (rows, bounds) or None when the run has no such write."""
+    F_INSN, F_RD, F_BEFORE, F_AFTER = 2, 6, 7, 8
+    reads = lambda w: ((17, 10) if w[F_INSN] == 0x73 else ((int(w[F_INSN]) >> 15) & 31, (int(w[F_INSN]) >> 20) & 31))
+    n = len(rows)
+    for r in rng.permutation(n - 1)[:200]:
+        w = rows[r]
+        reg = int(w[F_RD])
+        if not reg or w[F_INSN] == 0x73:
+            continue
+        nxt = next((q for q in range(r + 1, n) if reg in reads(rows[q]) or rows[q, F_RD] == reg), None)
+        if nxt is not None and reg in reads(rows[nxt]):
+            continue  # somebody looks at it
+        bad_rows, bad_bounds = rows.copy(), bounds.copy()
+        lie = int(w[F_AFTER]) ^ (1 << int(rng.integers(0, 32)))
+        bad_rows[r, F_AFTER] = lie
+        if nxt is not None:
+            bad_rows[nxt, F_BEFORE] = lie           # the next write overwrites the lie
+        else:
+            k = int(np.nonzero(bounds[:, 0] == r0.REG_BASE + reg)[0][0])
+            bad_bounds[k, 2] = lie                  # the value the segment leaves there
+        return bad_rows, bad_bounds
+    return None
+
+
 def main():
     budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 120.0
     orc, hal = orc_binding.load(), r0.Hal(0)
@@ -68,7 +96,7 @@ def main():
     oc, gc = orc.circuit(blob), hal.load_circuit(blob)
     rng = np.random.default_rng(2026)
     fixed = {}
-    t0, n, rows_total, taken, tampered = time.time(), 0, 0, 0, 0
+    t0, n, rows_total, taken, tampered, lied = time.time(), 0, 0, 0, 0, 0
     while time.time() - t0 < budget:
         prog = random_program(rng, int(rng.integers(40, 990)))  # the closing branch reaches back at most 4 KiB
         vm = r0.Vm()
@@ -107,6 +135,15 @@ def main():
                 print("FAILED on program %d: an inconsistent register read was accepted" % n)
                 sys.exit(1)
             tampered += 1
+        if n % 8 == 4:  # an instruction that computes something else, memory kept consistent around the lie: refused by both verifiers
+            lie = dead_write_lie(rows, bounds, rng)
+            if lie is not None:
+                hal.trace_witgen(lie[0], lie[1], po2, into=dev)
+                forged = hal.prove_segment(gc, po2, cc, dev, glob)
+                if oc.verify(forged, code_root=root)[0] != 4 or r0.verify_seal(blob, forged, code_root=root)[0] != 4:
+                    print("FAILED on program %d: a wrong result was accepted" % n)
+                    sys.exit(1)
+                lied += 1
         dev.free()
         n += 1
         rows_total += len(rows)
@@ -114,7 +151,8 @@ def main():
         if n % 50 == 0:
             print("%d executions proved (%d cycles, %d taken branches and jumps) after %.0f s" % (n, rows_total, taken, time.time() - t0), flush=True)
     print("soak ok: %d random executions (%d cycles, %d taken branches and jumps): device witness == host reference and device seal == oracle seal word for word, "
-          "both verifiers accept bound to the control root; %d tampered runs (a register read back wrong) refused by both" % (n, rows_total, taken, tampered))
+          "both verifiers accept bound to the control root; %d tampered runs (a register read back wrong) and %d runs with a wrong result in a dead register (memory consistent, "
+          "the instruction not) refused by both" % (n, rows_total, taken, tampered, lied))
 
 
 if __name__ == "__main__":
