@@ -579,12 +579,25 @@ def test_the_device_expands_and_proves_an_execution_trace_word_for_word_like_the
     seal = hal.prove_segment(gc, po2, cc, dev2, glob)
     assert c.verify(seal, code_root=root)[0] == 4 and r0.verify_seal(blob, seal, code_root=root)[0] == 4
     # a wrong result in a register nobody looks at before it is overwritten: memory stays consistent, the instruction does not
-    from soak_trace import dead_write_lie
-    lie = dead_write_lie(rows, bounds, np.random.default_rng(po2))
-    assert lie is not None
+    # (a random program: the loop above reads everything it writes)
+    from soak_trace import dead_write_lie, random_program
+    rng = np.random.default_rng(po2)
+    vm2 = r0.Vm()
+    vm2.load(0x1000, random_program(rng, 150))
+    vm2.set_pc(0x1000)
+    for i in range(1, 28):
+        vm2.set_reg(i, int(rng.integers(0, 1 << 32)))
+    vm2.set_input([1, 2, 3, 4, 5, 6, 7, 8])
+    assert vm2.run(segment_po2=20, keep_trace=True, boundary_rows=True, max_cycles=50_000) == (0, 0)
+    rows2, bounds2 = vm2.preflight_arrays(0)
+    assert len(rows2) + len(bounds2) <= 1 << po2
     dev2.free()
-    dev2, _ = hal.trace_witgen(lie[0], lie[1], po2)
-    seal = hal.prove_segment(gc, po2, cc, dev2, glob)
+    dev2, glob2 = hal.trace_witgen(rows2, bounds2, po2)
+    assert c.verify(hal.prove_segment(gc, po2, cc, dev2, glob2), code_root=root) == (0, "ok")
+    lie = dead_write_lie(rows2, bounds2, rng)
+    assert lie is not None
+    hal.trace_witgen(lie[0], lie[1], po2, into=dev2)
+    seal = hal.prove_segment(gc, po2, cc, dev2, glob2)
     assert c.verify(seal, code_root=root)[0] == 4 and r0.verify_seal(blob, seal, code_root=root)[0] == 4
     with pytest.raises(r0.R0HipError, match="do not fit"):
         hal.trace_witgen(rows, bounds, 9 if po2 > 10 else 8)
