@@ -665,9 +665,9 @@ class Vm:
         return out
 
     def trace_witness(self, i, po2, claim_globals=None):
-        """DATA group of the trace circuit (144 columns x 2^po2, Montgomery words, column-major) from segment i's preflight and
-        boundary rows on the HOST (r0h_vm_trace_witness: the reference the device kernel is compared with), and its eleven public
-        inputs: claim_globals (8 words, zeros when None), first pc, pc after the last cycle, cycles."""
+        """DATA group of the trace circuit (TRACE_COLUMNS x 2^po2, Montgomery words, column-major) from segment i's preflight and
+        boundary rows on the HOST (r0h_vm_trace_witness: the reference the device kernel is compared with), and its TRACE_GLOBALS
+        public inputs: claim_globals (8 words, zeros when None), first pc, pc after the last cycle, cycles, how it ends, exit code."""
         data = np.zeros(TRACE_COLUMNS << po2, dtype=np.uint32)
         glob = np.zeros(TRACE_GLOBALS, dtype=np.uint32)
         _check(lib().r0h_vm_trace_witness(self.handle, i, po2, data.ctypes.data_as(_vp), glob.ctypes.data_as(_vp)))

@@ -242,6 +242,38 @@ def test_what_the_guest_refuses(guest, toy_key):
     assert (kind, code) == (0, 11)
 
 
+def _last_segment(image, stream):
+    """the run executed with the trace kept one segment at a time (earlier segments' rows released): -> (vm, index of the last)"""
+    vm = r0.Vm()
+    vm.load_elf(image)
+    vm.set_input(stream)
+    while True:
+        finished, kind, code = vm.run_segment(segment_po2=20, keep_trace=True, boundary_rows=True)
+        k = len(vm.segments()) - 1
+        if finished:
+            assert (kind, code) == (0, 0)
+            return vm, k
+        vm.release_trace(k)
+
+
+def test_the_last_segment_of_the_real_run_proves_on_the_cpu(orc):
+    """What is left of the guest's 11.8 M cycles after eleven full segments (0.3 M cycles: the end of the camt.053 scan, the PEM
+    re-encoding, the COMMIT, the HALT) as a 2^19-row trace: the CPU oracle proves it with the trace circuit and both verifiers accept,
+    bound to the control root; the public inputs say HALT with exit code 0."""
+    image, stream, _ = guest_camt53.elf_and_input(form=1)
+    vm, k = _last_segment(image, stream)
+    seg = vm.segments()[k]
+    assert k == 11 and seg.user_cycles + seg.boundary_rows <= 1 << 19 and vm.journal == journal_of("reference_receipt_6bb95807_latest.json")
+    blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
+    oc = orc.circuit(blob)
+    data, glob = vm.trace_witness(k, 19, claim_globals=vm.claims()[k].globals())
+    assert [orc.dec(int(g)) for g in glob[8:]] == [seg.pre.pc, seg.post.pc, seg.user_cycles, 1, 1, 0, 0]
+    code = oc.witgen(19, 0)[0]
+    root = oc.code_root(code, 19)
+    seal = oc.prove(19, code, data, glob)
+    assert oc.verify(seal, code_root=root) == (0, "ok") and r0.verify_seal(blob, seal, code_root=root)[:2] == (0, "ok")
+
+
 @pytest.mark.gpu
 def test_the_proved_receipt_carries_the_references_journal(hal, orc):
     """`prove(env, elf)` over this guest with the trace circuit: twelve 2^20-row segments expanded and proved on the device; the
@@ -263,6 +295,17 @@ def test_the_proved_receipt_carries_the_references_journal(hal, orc):
     assert len(seals) >= 11 and receipt.verify(blob, roots, image_id)[:2] == (0, "ok")
     oc = orc.circuit(blob)
     assert oc.verify(seals[-1][1], code_root=roots[r0.verify_seal(blob, seals[-1][1])[2]]) == (0, "ok")
+    # parity at full size on the real workload: the run's last segment -- what is left of 11.8 M cycles after eleven full segments, and
+    # the HALT -- expanded on the host and proved by the CPU oracle gives the device's seal, word for word
+    vm, k = _last_segment(image, stream)
+    assert k == len(seals) - 1 and vm.journal == receipt.journal
+    size = r0.verify_seal(blob, seals[k][1])[2]
+    seg = vm.segments()[k]
+    assert seg.user_cycles + seg.boundary_rows <= 1 << size and size >= 17
+    data, glob = vm.trace_witness(k, size, claim_globals=vm.claims()[k].globals())
+    assert np.array_equal(glob, seals[k][1][:r0.TRACE_GLOBALS])
+    ocode = oc.witgen(size, 0)[0]
+    assert np.array_equal(oc.prove(size, ocode, data, glob), seals[k][1])
     # the reference's own envelope around it: a receipt file whose journal.bytes are the fixture's
     doc = json.loads(receipt.to_json())
     assert doc["journal"]["bytes"] == json.load(open(os.path.join(GOLDEN, "reference_receipt_6bb95807_latest.json")))["journal"]["bytes"]
