@@ -34,7 +34,7 @@ def elf_of(words, base, data=b"", data_addr=0):
     return ehdr + ph + code + data
 
 
-def commitment(journal):
+def commitment(r0, journal):
     try:
         return r0.journal_commitment(journal).decode("utf-8", "replace")[:160]
     except r0.R0HipError:
@@ -98,7 +98,7 @@ def main():
             "device": {"witgen_ms_per_segment": round(st["witgen_ms"] / n, 3), "prove_ms_per_segment": round(st["prove_ms"] / n, 3),
                        "note": "witgen = upload of 72 B/cycle + 16 B/boundary row and the expansion kernel; prove = r0h_prove_segment_committed (CODE committed once per trace size)"},
             "circuit": "trace.r0c W=(%d accum, %d code, %d data)" % tuple(gc.group_size), "seal_words": int(seals[0][1].size),
-            "receipt_verified": True, "journal_commitment": commitment(receipt.journal), "data": "synthetic guest; no guest ELF exists in the reference (needs the Rust toolchain)"}
+            "receipt_verified": True, "journal_commitment": commitment(r0, receipt.journal), "data": "synthetic guest; no guest ELF exists in the reference (needs the Rust toolchain)"}
     print(json.dumps(line))
     gc.free()
     hal.close()
