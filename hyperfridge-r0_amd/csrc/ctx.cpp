@@ -188,6 +188,7 @@ const char* ctx_helper(r0h_ctx* ctx, size_t k, r0h_ctx** out) {
 }
 void ctx_release(r0h_ctx* ctx) {
   if (--ctx->refs > 0) return;
+  session_rows_free(ctx);
   for (r0h_ctx* h : ctx->helpers) r0h_ctx_destroy(h);
   ctx->helpers.clear();
   (void)hipSetDevice(ctx->device);

@@ -106,6 +106,7 @@ struct r0h_ctx {
   size_t pool_bytes = 0;              // bytes parked in the pool; above POOL_LIMIT blocks are released instead
   r0h::Profile prof;
   r0h_session_stats session = {0, 0, 0, 0, 0, 0};  // stage timing of the last r0h_prove_elf
+  void* session_rows = nullptr;   // session.cpp: the preflight row buffers of r0h_prove_elf, page-locked, kept from one call to the next (session_rows_free)
   std::vector<r0h_ctx*> helpers;  // further contexts of the same device, made on demand by r0h_prove_elf for its extra prover lanes; they go with this one
   bool ktime_on = false;
   std::map<std::string, r0h::KTimer> ktimers;
@@ -168,6 +169,8 @@ const char* poly_divide_batch(r0h_ctx* ctx, r0h_buf* polys, uint32_t n, const ui
 // rv32im.cpp: the preflight rows of segment i are moved out of the machine (the session proves them while the guest runs on)
 void vm_take_trace(r0h_vm* vm, size_t i, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds);
 void vm_recycle_trace(r0h_vm* vm, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds);
+void vm_take_spares(r0h_vm* vm, std::vector<std::vector<r0h_preflight_row>>& rows, std::vector<std::vector<r0h_preflight_bound>>& bounds);
+void session_rows_free(r0h_ctx* ctx);  // session.cpp: unpins and frees the row buffers a context kept (ctx teardown, device still alive)
 // the k-th helper context of `ctx` (same device, same Poseidon2 table), created on first use and kept until ctx goes
 const char* ctx_helper(r0h_ctx* ctx, size_t k, r0h_ctx** out);
 void ctx_retain(r0h_ctx* ctx);

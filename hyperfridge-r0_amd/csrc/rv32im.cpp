@@ -704,6 +704,17 @@ void vm_recycle_trace(r0h_vm* vm, std::vector<r0h_preflight_row>& rows, std::vec
   if (rows.capacity()) { vm->spare_rows.emplace_back(); vm->spare_rows.back().swap(rows); }
   if (bounds.capacity()) { vm->spare_bounds.emplace_back(); vm->spare_bounds.back().swap(bounds); }
 }
+// the unused row buffers leave the machine (a session keeps them, page-locked, for its context's next run)
+void vm_take_spares(r0h_vm* vm, std::vector<std::vector<r0h_preflight_row>>& rows, std::vector<std::vector<r0h_preflight_bound>>& bounds) {
+  for (auto& r : vm->spare_rows) { r.clear(); rows.emplace_back(); rows.back().swap(r); }
+  for (auto& b : vm->spare_bounds) { b.clear(); bounds.emplace_back(); bounds.back().swap(b); }
+  vm->spare_rows.clear();
+  vm->spare_bounds.clear();
+  for (auto& s : vm->segments) {  // ... and those of segments nobody took
+    if (s.rows.capacity()) { s.rows.clear(); rows.emplace_back(); rows.back().swap(s.rows); }
+    if (s.bounds.capacity()) { s.bounds.clear(); bounds.emplace_back(); bounds.back().swap(s.bounds); }
+  }
+}
 }  // namespace r0h
 extern "C" {
 

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -70,7 +71,54 @@ uint32_t trace_size(uint64_t rows) {
   while (((uint64_t)1 << po2) < rows) po2++;
   return po2;
 }
+
+// Row buffers a context keeps between sessions (r0h_prove_elf): vectors with their heap blocks, some of them page-locked.
+struct RowPool {
+  std::mutex mu;
+  std::vector<std::vector<r0h_preflight_row>> rows;
+  std::vector<std::vector<r0h_preflight_bound>> bounds;
+  std::map<const void*, size_t> pinned;
+  void unpin(const void* p) {
+    auto it = pinned.find(p);
+    if (it == pinned.end()) return;
+    (void)hipHostUnregister(const_cast<void*>(p));
+    pinned.erase(it);
+  }
+  // keep at most `cap` row buffers (pinned ones first); a pinned block that is not among them is unpinned BEFORE its vector is freed
+  void settle(size_t cap) {
+    for (size_t k = 0; k < rows.size();)
+      if (!rows[k].capacity()) rows.erase(rows.begin() + k);
+      else k++;
+    std::stable_sort(rows.begin(), rows.end(), [&](const std::vector<r0h_preflight_row>& a, const std::vector<r0h_preflight_row>& b) {
+      return (pinned.count(a.data()) != 0) > (pinned.count(b.data()) != 0);
+    });
+    const size_t keep = std::min(cap, rows.size());
+    for (auto it = pinned.begin(); it != pinned.end();) {
+      bool alive = false;
+      for (size_t k = 0; k < keep; k++) alive = alive || rows[k].data() == it->first;
+      if (alive) { ++it; continue; }
+      (void)hipHostUnregister(const_cast<void*>(it->first));
+      it = pinned.erase(it);
+    }
+    rows.resize(keep);
+    if (bounds.size() > cap) bounds.resize(cap);
+  }
+};
+RowPool* pool_of(r0h_ctx* ctx) {
+  if (!ctx->session_rows) ctx->session_rows = new RowPool();
+  return (RowPool*)ctx->session_rows;
+}
 }  // namespace
+
+namespace r0h {
+void session_rows_free(r0h_ctx* ctx) {
+  RowPool* p = (RowPool*)ctx->session_rows;
+  if (!p) return;
+  p->settle(0);  // unpins every block, then frees them
+  delete p;
+  ctx->session_rows = nullptr;
+}
+}  // namespace r0h
 
 extern "C" {
 
@@ -151,20 +199,54 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
     producer_done = true;
     cv.notify_all();
   });
-  // the row buffers are recycled, so there are three or four of them in a run: each is page-locked the first time it is seen
-  // (hipHostRegister) and the 72 MiB of a segment then cross PCIe by DMA at the link's rate instead of through a staging copy
+  // The row buffers are recycled, so there are three or four of them in a run; each is page-locked the first time it is seen
+  // (hipHostRegister): the 72 MiB of a segment then cross PCIe by DMA at the link's rate instead of through a staging copy.  Pinning
+  // 72 MiB costs tens of milliseconds and a fresh buffer as much again in page faults, so the buffers stay with the context from one
+  // call to the next (RowPool): a second run starts with warm, pinned buffers.
+  RowPool* pool = trace_mode ? pool_of(ctx) : nullptr;
+  std::unique_lock<std::mutex> pool_lock;
+  if (pool) {
+    pool_lock = std::unique_lock<std::mutex>(pool->mu, std::try_to_lock);
+    if (!pool_lock.owns_lock()) pool = nullptr;  // another session on this context has them: this one pins its own
+  }
   struct Pins {
-    std::map<const void*, size_t> seen;
+    RowPool* pool;
+    std::map<const void*, size_t> local;
+    std::map<const void*, size_t>& seen() { return pool ? pool->pinned : local; }
     void pin(const void* p, size_t bytes) {
       if (!p || !bytes) return;
-      auto it = seen.find(p);
-      if (it != seen.end() && it->second >= bytes) return;
-      if (it != seen.end()) { (void)hipHostUnregister(const_cast<void*>(p)); seen.erase(it); }
-      if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) seen[p] = bytes;
+      auto& m = seen();
+      auto it = m.find(p);
+      if (it != m.end() && it->second >= bytes) return;
+      if (it != m.end()) { (void)hipHostUnregister(const_cast<void*>(p)); m.erase(it); }
+      if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) m[p] = bytes;
       else (void)hipGetLastError();  // pageable memory still works, only slower
     }
-    ~Pins() { for (auto& kv : seen) (void)hipHostUnregister(const_cast<void*>(kv.first)); }
-  } pins;
+    ~Pins() { for (auto& kv : local) (void)hipHostUnregister(const_cast<void*>(kv.first)); }
+  } pins{pool, {}};
+  if (pool) {  // last run's buffers, if they have this run's size (the executor reserves min(2^po2, 2^22) rows)
+    const size_t need = (size_t)std::min<uint64_t>((uint64_t)1 << segment_po2, (uint64_t)1 << 22);
+    for (size_t k = 0; k < pool->rows.size(); k++) {
+      std::vector<r0h_preflight_bound> b;
+      if (k < pool->bounds.size()) b.swap(pool->bounds[k]);
+      if (pool->rows[k].capacity() >= need && pool->rows[k].capacity() <= 2 * need) vm_recycle_trace(vm, pool->rows[k], b);
+      else pool->unpin(pool->rows[k].data());
+    }
+    pool->rows.clear();
+    pool->bounds.clear();
+  }
+  // whatever path leaves this function, after the executor thread is gone: the buffers go back to the pool, and what is pinned but
+  // no longer there is unpinned before its memory is freed
+  struct Collect {
+    RowPool* pool; r0h_vm* vm; std::deque<std::unique_ptr<Produced>>& queue; std::vector<std::unique_ptr<Produced>>& returned;
+    ~Collect() {
+      if (!pool) return;
+      for (auto& p : queue) if (p) { pool->rows.emplace_back(); pool->rows.back().swap(p->rows); pool->bounds.emplace_back(); pool->bounds.back().swap(p->bounds); }
+      for (auto& p : returned) if (p) { pool->rows.emplace_back(); pool->rows.back().swap(p->rows); pool->bounds.emplace_back(); pool->bounds.back().swap(p->bounds); }
+      vm_take_spares(vm, pool->rows, pool->bounds);
+      pool->settle(6);
+    }
+  } collect{pool, vm, queue, returned};
   struct Join {  // whatever path leaves this function: the executor thread is told to stop and joined first
     std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
     ~Join() {
