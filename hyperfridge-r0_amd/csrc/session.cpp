@@ -163,6 +163,39 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
   int exit_kind = R0H_VM_LIMIT;
   uint32_t exit_code = 0;
   double executor_s = 0;
+  // The row buffers are recycled, so there are three or four of them in a run; each is page-locked the first time it is seen
+  // (hipHostRegister): the 72 MiB of a segment then cross PCIe by DMA at the link's rate instead of through a staging copy.  Pinning
+  // 72 MiB costs tens of milliseconds and a fresh buffer as much again in page faults, so the buffers stay with the context from one
+  // call to the next (RowPool): a second run starts with warm, pinned buffers.
+  RowPool* pool = trace_mode ? pool_of(ctx) : nullptr;
+  std::unique_lock<std::mutex> pool_lock;
+  if (pool) {
+    pool_lock = std::unique_lock<std::mutex>(pool->mu, std::try_to_lock);
+    if (!pool_lock.owns_lock()) pool = nullptr;  // another session on this context has them: this one pins its own
+  }
+  if (pool) {  // (before the executor thread exists: the machine is still this thread's)  last run's buffers, if they have this run's size (the executor reserves min(2^po2, 2^22) rows)
+    const size_t need = (size_t)std::min<uint64_t>((uint64_t)1 << segment_po2, (uint64_t)1 << 22);
+    for (size_t k = 0; k < pool->rows.size(); k++) {
+      std::vector<r0h_preflight_bound> b;
+      if (k < pool->bounds.size()) b.swap(pool->bounds[k]);
+      if (pool->rows[k].capacity() >= need && pool->rows[k].capacity() <= 2 * need) vm_recycle_trace(vm, pool->rows[k], b);
+      else pool->unpin(pool->rows[k].data());
+    }
+    pool->rows.clear();
+    pool->bounds.clear();
+  }
+  // whatever path leaves this function, after the executor thread is gone: the buffers go back to the pool, and what is pinned but
+  // no longer there is unpinned before its memory is freed
+  struct Collect {
+    RowPool* pool; r0h_vm* vm; std::deque<std::unique_ptr<Produced>>& queue; std::vector<std::unique_ptr<Produced>>& returned;
+    ~Collect() {
+      if (!pool) return;
+      for (auto& p : queue) if (p) { pool->rows.emplace_back(); pool->rows.back().swap(p->rows); pool->bounds.emplace_back(); pool->bounds.back().swap(p->bounds); }
+      for (auto& p : returned) if (p) { pool->rows.emplace_back(); pool->rows.back().swap(p->rows); pool->bounds.emplace_back(); pool->bounds.back().swap(p->bounds); }
+      vm_take_spares(vm, pool->rows, pool->bounds);
+      pool->settle(6);
+    }
+  } collect{pool, vm, queue, returned};
   std::thread producer([&] {
     const char* err = nullptr;
     try {
@@ -199,16 +232,6 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
     producer_done = true;
     cv.notify_all();
   });
-  // The row buffers are recycled, so there are three or four of them in a run; each is page-locked the first time it is seen
-  // (hipHostRegister): the 72 MiB of a segment then cross PCIe by DMA at the link's rate instead of through a staging copy.  Pinning
-  // 72 MiB costs tens of milliseconds and a fresh buffer as much again in page faults, so the buffers stay with the context from one
-  // call to the next (RowPool): a second run starts with warm, pinned buffers.
-  RowPool* pool = trace_mode ? pool_of(ctx) : nullptr;
-  std::unique_lock<std::mutex> pool_lock;
-  if (pool) {
-    pool_lock = std::unique_lock<std::mutex>(pool->mu, std::try_to_lock);
-    if (!pool_lock.owns_lock()) pool = nullptr;  // another session on this context has them: this one pins its own
-  }
   struct Pins {
     RowPool* pool;
     std::map<const void*, size_t> local;
@@ -224,29 +247,6 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
     }
     ~Pins() { for (auto& kv : local) (void)hipHostUnregister(const_cast<void*>(kv.first)); }
   } pins{pool, {}};
-  if (pool) {  // last run's buffers, if they have this run's size (the executor reserves min(2^po2, 2^22) rows)
-    const size_t need = (size_t)std::min<uint64_t>((uint64_t)1 << segment_po2, (uint64_t)1 << 22);
-    for (size_t k = 0; k < pool->rows.size(); k++) {
-      std::vector<r0h_preflight_bound> b;
-      if (k < pool->bounds.size()) b.swap(pool->bounds[k]);
-      if (pool->rows[k].capacity() >= need && pool->rows[k].capacity() <= 2 * need) vm_recycle_trace(vm, pool->rows[k], b);
-      else pool->unpin(pool->rows[k].data());
-    }
-    pool->rows.clear();
-    pool->bounds.clear();
-  }
-  // whatever path leaves this function, after the executor thread is gone: the buffers go back to the pool, and what is pinned but
-  // no longer there is unpinned before its memory is freed
-  struct Collect {
-    RowPool* pool; r0h_vm* vm; std::deque<std::unique_ptr<Produced>>& queue; std::vector<std::unique_ptr<Produced>>& returned;
-    ~Collect() {
-      if (!pool) return;
-      for (auto& p : queue) if (p) { pool->rows.emplace_back(); pool->rows.back().swap(p->rows); pool->bounds.emplace_back(); pool->bounds.back().swap(p->bounds); }
-      for (auto& p : returned) if (p) { pool->rows.emplace_back(); pool->rows.back().swap(p->rows); pool->bounds.emplace_back(); pool->bounds.back().swap(p->bounds); }
-      vm_take_spares(vm, pool->rows, pool->bounds);
-      pool->settle(6);
-    }
-  } collect{pool, vm, queue, returned};
   struct Join {  // whatever path leaves this function: the executor thread is told to stop and joined first
     std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
     ~Join() {
