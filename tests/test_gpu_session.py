@@ -204,6 +204,12 @@ def test_prove_elf_with_the_trace_circuit_proves_the_run_it_executed(hal, orc):
         finally:
             del os.environ["R0H_SESSION_LANES"]
         assert image_again == image_id and again.to_json() == receipt.to_json(), lanes
+    # the page-locked row buffers stay with the context between calls: a run with another segment size in between (buffers of the wrong
+    # capacity are unpinned and dropped, new ones pinned) changes nothing about the next run of this size
+    other, _, _ = hal.prove_elf(gc, elf, stream, segment_po2=po2 + 1)
+    assert len(other.seals()) < len(seals)
+    again, _, _ = hal.prove_elf(gc, elf, stream, segment_po2=po2)
+    assert again.to_json() == receipt.to_json()
     # a guest that fails or never halts is an error, not a receipt
     with pytest.raises(r0.R0HipError, match="did not halt"):
         hal.prove_elf(gc, elf, stream, segment_po2=po2, max_cycles=100)
