@@ -337,8 +337,8 @@ const char* r0h_buf_free(r0h_buf* b) {
         b->ctx->pool_bytes += sz;
       }
     } else if (b->owned && b->ptr) {
-      hipSetDevice(b->ctx->device);
-      hipStreamSynchronize(b->ctx->stream);
+      (void)hipSetDevice(b->ctx->device);  // best effort before the free: a failure here shows up as the free's error
+      (void)hipStreamSynchronize(b->ctx->stream);
       hipError_t e = hipFree(b->ptr);
       if (e != hipSuccess) return make_error("r0h_buf_free: %s", hipGetErrorString(e));
     }
