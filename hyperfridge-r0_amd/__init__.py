@@ -1022,7 +1022,7 @@ class Hal:
 
     def trace_witgen(self, rows, bounds, po2, claim_globals=None, into=None):
         """DATA group of the trace circuit expanded ON THE DEVICE from the compact preflight rows (r0h_trace_witgen): rows [n, 18]
-        and bounds [m, 4] uint32 (Vm.preflight_arrays).  Returns (Buf of TRACE_COLUMNS * 2^po2 words, the eleven public inputs)."""
+        and bounds [m, 4] uint32 (Vm.preflight_arrays).  Returns (Buf of TRACE_COLUMNS * 2^po2 words, the TRACE_GLOBALS public inputs)."""
         rows = np.ascontiguousarray(rows, dtype=np.uint32).reshape(-1, 18)
         bounds = np.ascontiguousarray(bounds, dtype=np.uint32).reshape(-1, 4)
         data = into if into is not None else self.alloc(TRACE_COLUMNS << po2)

@@ -790,7 +790,7 @@ def generate_trace():
 
 def check_trace_rows(data, globals_, first_only=True):
     """Evaluate every DATA / CODE constraint of the trace circuit on a witness: data[column][row] canonical integers (numpy int64),
-    globals_ the eleven public inputs as canonical integers.  -> [(constraint name, rows where it does not vanish)].  A development
+    globals_ the TRACE_GLOBALS public inputs as canonical integers.  -> [(constraint name, rows where it does not vanish)].  A development
     and test aid: tells WHICH constraint a witness breaks, where the prover only says that one does."""
     import numpy as np
     b, cons, _ = trace_constraints()
