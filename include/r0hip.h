@@ -462,7 +462,7 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
 #define R0H_TRACE_MAX_PO2 21
 const char* r0h_trace_column_name(uint32_t column); /* static string; NULL past the last column */
 /* host reference of the witness (what tests compare the device kernel with): data_out = R0H_TRACE_COLUMNS * 2^po2 words;
- * globals_out[8..11) = first pc, pc after the last cycle, cycles (globals_out[0..8) are left to the caller: the claim) */
+ * globals_out[8..15) = first pc, pc after the last cycle, cycles, how the segment ends, that being non-zero, exit code halves (globals_out[0..8) are left to the caller: the claim) */
 const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint32_t* data_out, uint32_t globals_out[R0H_TRACE_GLOBALS]);
 /* the same on the device: the compact rows (72 B per cycle, 16 B per boundary row) are uploaded and one thread per row expands
  * them into the column-major Montgomery DATA group in `data` (R0H_TRACE_COLUMNS * 2^po2 words).  Stream-ordered; the host arrays
