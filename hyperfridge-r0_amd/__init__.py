@@ -149,6 +149,8 @@ _SIGNATURES = {
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
     "r0h_prove_elf": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _pp, _vp, _c.POINTER(_u64)],
+    "r0h_prove_elf_part": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _u32, _u32, _pp, _vp, _c.POINTER(_u64)],
+    "r0h_receipt_merge": [_pp, _sz, _pp],
     "r0h_recursor_new": [_vp, _vp, _sz, _cp, _u32, _vp, _sz, _vp, _sz, _pp],
     "r0h_recursor_free": [_vp],
     "r0h_recursor_control_root": [_vp, _vp],
@@ -787,6 +789,14 @@ class Receipt:
         self.handle = handle
 
     @classmethod
+    def merge(cls, receipts):
+        """r0h_receipt_merge: composite receipts that each hold some segments of one session -> the receipt of the session"""
+        arr = (_vp * len(receipts))(*[r.handle for r in receipts])
+        h = _vp()
+        _check(lib().r0h_receipt_merge(arr, len(receipts), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
     def parse(cls, text):
         raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
         h = _vp()
@@ -794,17 +804,20 @@ class Receipt:
         return cls(h)
 
     @classmethod
-    def new(cls, journal, seals=None, claims=None):
+    def new(cls, journal, seals=None, claims=None, indices=None):
+        """a Fake receipt (seals None) or a composite one of the given seals (and claims); indices: the segments' indices when the
+        receipt holds only some segments of a session (a rank's share: Receipt.merge)"""
         journal = bytes(journal)
         h = _vp()
         _check(lib().r0h_receipt_new(0 if seals is None else 1, journal, len(journal), ctypes.byref(h)))
         rc = cls(h)
-        for i, seal in enumerate(seals or []):
+        for k, seal in enumerate(seals or []):
             a, pa = _u32arr(seal)
+            i = k if indices is None else indices[k]
             if claims is None:
                 _check(lib().r0h_receipt_add_segment(h, pa, a.size, i))
             else:
-                _check(lib().r0h_receipt_add_segment_claim(h, pa, a.size, i, ctypes.byref(claims[i]), None))
+                _check(lib().r0h_receipt_add_segment_claim(h, pa, a.size, i, ctypes.byref(claims[k]), None))
         return rc
 
     def claims(self):
@@ -1099,14 +1112,16 @@ class Hal:
                 code.free()
         return out
 
-    def prove_elf(self, circuit, elf, input_words, segment_po2=20, max_cycles=0):
+    def prove_elf(self, circuit, elf, input_words, segment_po2=20, max_cycles=0, part=0, parts=1):
         """`default_prover().prove(env, elf)` (r0h_prove_elf): returns (Receipt, image id, guest cycles).  max_cycles = 0 selects the
-        library's session limit (2^32 cycles); with circuits/trace.r0c every seal attests the segment it stands for."""
+        library's session limit (2^32 cycles); with circuits/trace.r0c every seal attests the segment it stands for.  parts > 1
+        (r0h_prove_elf_part): this rank's share of a session proved on several GPUs -- segments part, part + parts, ...; the receipt
+        holds those only (Receipt.merge puts the ranks' receipts together)."""
         elf = bytes(elf)
         w, pw = _u32arr(input_words if len(input_words) else [0])
         h, image_id, cycles = _vp(), (ctypes.c_uint8 * 32)(), _u64(0)
-        _check(lib().r0h_prove_elf(self.ctx, circuit.handle, elf, len(elf), pw, len(input_words), segment_po2, max_cycles, ctypes.byref(h), image_id,
-                                   ctypes.byref(cycles)))
+        _check(lib().r0h_prove_elf_part(self.ctx, circuit.handle, elf, len(elf), pw, len(input_words), segment_po2, max_cycles, part, parts, ctypes.byref(h),
+                                        image_id, ctypes.byref(cycles)))
         return Receipt(h), bytes(image_id), cycles.value
 
     def last_session_stats(self):

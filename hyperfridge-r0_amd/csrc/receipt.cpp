@@ -525,6 +525,30 @@ const char* r0h_receipt_add_segment_claim(r0h_receipt* rc, const uint32_t* seal,
   R0H_GUARD_END
 }
 
+const char* r0h_receipt_merge(const r0h_receipt* const* parts, size_t n, r0h_receipt** out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(parts && n && out, "r0h_receipt_merge: NULL argument");
+  size_t total = 0;
+  for (size_t k = 0; k < n; k++) {
+    R0H_REQUIRE(parts[k] && parts[k]->kind == R0H_RECEIPT_COMPOSITE, "r0h_receipt_merge: receipt %zu is not a composite receipt", k);
+    R0H_REQUIRE(parts[k]->journal == parts[0]->journal, "r0h_receipt_merge: receipt %zu carries another journal", k);
+    total += parts[k]->segments.size();
+  }
+  std::vector<const r0h_receipt::Segment*> at(total, nullptr);
+  for (size_t k = 0; k < n; k++)
+    for (const r0h_receipt::Segment& s : parts[k]->segments) {
+      R0H_REQUIRE(s.index < total, "r0h_receipt_merge: segment index %u with %zu segments in all: one is missing", s.index, total);
+      R0H_REQUIRE(!at[s.index], "r0h_receipt_merge: segment %u is there twice", s.index);
+      at[s.index] = &s;
+    }
+  std::unique_ptr<r0h_receipt> rc(new r0h_receipt(*parts[0]));
+  rc->segments.clear();
+  for (size_t i = 0; i < total; i++) rc->segments.push_back(*at[i]);  // (every slot is filled: total indices below total, none twice)
+  *out = rc.release();
+  return nullptr;
+  R0H_GUARD_END
+}
+
 const char* r0h_receipt_segment_claim(const r0h_receipt* rc, size_t i, r0h_receipt_claim* claim_out, int* has_claim_out) {
   R0H_REQUIRE(rc && claim_out && has_claim_out, "r0h_receipt_segment_claim: NULL argument");
   R0H_REQUIRE(i < rc->segments.size(), "r0h_receipt_segment_claim: segment %zu of %zu", i, rc->segments.size());

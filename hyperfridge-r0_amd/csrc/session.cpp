@@ -60,6 +60,7 @@ struct CodeCommits {  // one committed CODE group per trace size met in the run
 };
 
 struct Produced {  // a segment as the executor thread hands it over
+  size_t index = 0;
   r0h_vm_segment info;
   r0h_receipt_claim claim;
   std::vector<r0h_preflight_row> rows;
@@ -130,8 +131,17 @@ const char* r0h_last_session_stats(r0h_ctx* ctx, r0h_session_stats* out) {
 
 const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words, size_t n_input, uint32_t segment_po2,
                           uint64_t max_cycles, r0h_receipt** receipt_out, uint8_t image_id_out[32], uint64_t* cycles_out) {
+  return r0h_prove_elf_part(ctx, c, elf, elf_len, input_words, n_input, segment_po2, max_cycles, 0, 1, receipt_out, image_id_out, cycles_out);
+}
+
+// One rank's share of a session: the guest is executed in full (it is deterministic and takes a tenth of a second per ten million
+// cycles -- cheaper than shipping 72 MiB of rows per segment to another GPU), segments part, part + parts, ... are proved; the
+// receipt carries those segments only (r0h_receipt_merge puts the ranks' receipts together).
+const char* r0h_prove_elf_part(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words, size_t n_input, uint32_t segment_po2,
+                               uint64_t max_cycles, uint32_t part, uint32_t parts, r0h_receipt** receipt_out, uint8_t image_id_out[32], uint64_t* cycles_out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && c && elf && receipt_out && (input_words || !n_input), "r0h_prove_elf: NULL argument");
+  R0H_REQUIRE(parts >= 1 && part < parts, "r0h_prove_elf_part: part %u of %u", part, parts);
   const bool trace_mode = !memcmp(c->info, "R0HIP_TRACE:v3__", 16);
   R0H_REQUIRE(segment_po2 >= 9 && segment_po2 <= (trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2), "r0h_prove_elf: segment_po2 %u outside [9, %u]", segment_po2,
               (unsigned)(trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2));
@@ -196,6 +206,8 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
       pool->settle(6);
     }
   } collect{pool, vm, queue, returned};
+  r0h_system_state first_pre;  // of segment 0: the image id (written by the executor thread, read after it is joined)
+  memset(&first_pre, 0, sizeof first_pre);
   std::thread producer([&] {
     const char* err = nullptr;
     try {
@@ -217,6 +229,12 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
         err = r0h_vm_segment_info(vm, i, &p->info);
         if (!err) err = r0h_vm_segment_claim(vm, i, &p->claim);
         if (err) break;
+        p->index = i;
+        if (i == 0) first_pre = p->info.pre;
+        if (i % parts != part) {  // another rank's segment: its row buffers go straight back to the machine
+          if (trace_mode) { vm_take_trace(vm, i, p->rows, p->bounds); vm_recycle_trace(vm, p->rows, p->bounds); }
+          continue;
+        }
         if (trace_mode) vm_take_trace(vm, i, p->rows, p->bounds);
         std::lock_guard<std::mutex> lk(mu);
         queue.push_back(std::move(p));
@@ -274,9 +292,6 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
   std::vector<Proved> proved;
   std::mutex commit_mu, result_mu;
   CodeCommits commits;
-  r0h_system_state first_pre;
-  memset(&first_pre, 0, sizeof first_pre);
-  size_t next_index = 0;
   const char* lane_err = nullptr;
 
   auto lane_body = [&](r0h_ctx* lctx) -> const char* {
@@ -294,8 +309,7 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
         }
         seg = std::move(queue.front());
         queue.pop_front();
-        i = next_index++;
-        if (i == 0) first_pre = seg->info.pre;
+        i = seg->index;
         cv.notify_all();
       }
       const uint64_t rows_needed = trace_mode ? seg->rows.size() + seg->bounds.size() : seg->info.user_cycles + seg->info.paging_cycles;
@@ -375,11 +389,12 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
   r0h_receipt* rc = nullptr;
   R0H_TRY(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, nullptr, 0, &rc));
   std::unique_ptr<r0h_receipt, const char* (*)(r0h_receipt*)> rc_guard(rc, r0h_receipt_free);
-  for (size_t i = 0; i < proved.size(); i++) {
-    R0H_REQUIRE(proved[i].done, "r0h_prove_elf: segment %zu was never proved", i);
+  producer.join();  // finished: the machine is this thread's again
+  const size_t n_segments = r0h_vm_n_segments(vm);
+  for (size_t i = part; i < n_segments; i += parts) {
+    R0H_REQUIRE(i < proved.size() && proved[i].done, "r0h_prove_elf: segment %zu was never proved", i);
     R0H_TRY(r0h_receipt_add_segment_claim(rc, proved[i].seal.data(), proved[i].seal.size(), (uint32_t)i, &proved[i].claim, nullptr));
   }
-  producer.join();  // finished: the machine is this thread's again
   R0H_REQUIRE(exit_kind != R0H_VM_LIMIT, "r0h_prove_elf: the guest did not halt within %llu cycles (session limit)", (unsigned long long)max_cycles);
   R0H_REQUIRE(exit_code == 0, "r0h_prove_elf: the guest exited with code %u", exit_code);  // `prove` is an Err for a failed guest
   if (cycles_out) *cycles_out = r0h_vm_cycles(vm);

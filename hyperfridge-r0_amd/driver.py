@@ -92,3 +92,29 @@ def run_timed(env, step_fn, steps, warmup, device_sync=lambda: None, many_fn=Non
     env.barrier()
     elapsed = time.perf_counter() - t0
     return env.max(elapsed), env.sum(units)
+
+
+def prove_elf_sharded(env, hal, circuit, elf, input_words, segment_po2=20, max_cycles=0):
+    """`prove(env, elf)` on env.world GPUs: every rank executes the guest (deterministic, a tenth of a second per ten million cycles)
+    and proves segments rank, rank + world, ... (r0h_prove_elf_part); the ranks' receipts travel to rank 0 as JSON over point-to-point
+    send / recv (hyperfridge-r0_amd/recursion.py torch_transport: RCCL under "nccl", gloo otherwise) and are merged there
+    (r0h_receipt_merge).  No collective on the data path; the merged receipt is the one a single GPU would have produced, seal for
+    seal.  Returns (Receipt on rank 0 / None elsewhere, image id, cycles)."""
+    import numpy as np
+    import hyperfridge_r0_amd as r0
+    mine, image_id, cycles = hal.prove_elf(circuit, elf, input_words, segment_po2=segment_po2, max_cycles=max_cycles, part=env.rank, parts=env.world)
+    if env.world == 1:
+        return mine, image_id, cycles
+    from .recursion import torch_transport
+    send, recv = torch_transport(env.device)
+    if env.rank != 0:
+        text = mine.to_json().encode()
+        send(np.frombuffer(text + bytes(-len(text) % 4), dtype=np.uint32), 0)
+        send(np.array([len(text)], dtype=np.uint32), 0)
+        return None, image_id, cycles
+    parts = [mine]
+    for src in range(1, env.world):
+        words = recv(src)
+        n = int(recv(src)[0])
+        parts.append(r0.Receipt.parse(words.tobytes()[:n].decode()))
+    return r0.Receipt.merge(parts), image_id, cycles

@@ -486,6 +486,17 @@ const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* 
 const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words,
                           size_t n_input, uint32_t segment_po2, uint64_t max_cycles, r0h_receipt** receipt_out,
                           uint8_t image_id_out[32], uint64_t* cycles_out);
+/* One rank's share of a session that is proved on several GPUs: the guest is executed in full on every rank (it is deterministic and
+ * costs a tenth of a second per ten million cycles -- less than moving 72 MiB of rows per segment between GPUs), segments part,
+ * part + parts, ... are proved.  The receipt holds those segments only; r0h_receipt_merge puts the ranks' receipts together into the
+ * receipt r0h_prove_elf would have returned (same seals: a segment's proof does not depend on who makes it).  No collective is
+ * involved: the receipts travel as JSON (hyperfridge-r0_amd/driver.py: prove_elf_sharded over torch.distributed). */
+const char* r0h_prove_elf_part(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words,
+                               size_t n_input, uint32_t segment_po2, uint64_t max_cycles, uint32_t part, uint32_t parts,
+                               r0h_receipt** receipt_out, uint8_t image_id_out[32], uint64_t* cycles_out);
+/* composite receipts that each hold some segments of one session -> one receipt with all of them in index order.  Refused: a
+ * segment index missing or present twice, journals that differ, a receipt that is not composite. */
+const char* r0h_receipt_merge(const r0h_receipt* const* parts, size_t n, r0h_receipt** out);
 /* per-stage timing of the last r0h_prove_elf on this context (for tools/bench_session.py): names are static strings */
 typedef struct { uint32_t segments; uint64_t cycles; double executor_s, witgen_ms, prove_ms, wall_s; } r0h_session_stats;
 const char* r0h_last_session_stats(r0h_ctx* ctx, r0h_session_stats* out);

@@ -177,3 +177,26 @@ def test_image_id_text_follows_the_reference_fixture():
     for bad in (text[:-1], text + "0", " " + text[1:], "-" + text[1:], text[:10] + "g" + text[11:]):  # strict: no signs, blanks or short reads
         with pytest.raises(r0.R0HipError, match="hex"):
             r0.image_id_from_hex(bad)
+
+
+def test_the_receipts_of_several_ranks_merge_into_the_sessions_receipt():
+    """r0h_receipt_merge: each rank of a multi-GPU session proves segments rank, rank + world, ... (r0h_prove_elf_part) and holds a
+    composite receipt of just those; merged they are the receipt one prover would have made, whatever the order they arrive in."""
+    states = [r0.SystemState.make(0x1000 + 4 * i, bytes([i + 1]) * 32) for i in range(8)]
+    claims = [r0.ReceiptClaim.make(states[i], states[i + 1], 2 if i < 6 else 0, 0, None) for i in range(7)]
+    seals = [np.arange(40, dtype=np.uint32) * (i + 3) for i in range(7)]
+    journal = r0.serde_encode_str('{"iban":"X"}')
+    whole = r0.Receipt.new(journal, seals, claims)
+    for world in (1, 2, 3, 7):
+        shares = [r0.Receipt.new(journal, seals[r::world], claims[r::world], indices=list(range(r, 7, world))) for r in range(world)]
+        assert r0.Receipt.merge(shares).to_json() == whole.to_json() and r0.Receipt.merge(shares[::-1]).to_json() == whole.to_json(), world
+    a = r0.Receipt.new(journal, seals[0::2], claims[0::2], indices=[0, 2, 4, 6])
+    b = r0.Receipt.new(journal, seals[1::2], claims[1::2], indices=[1, 3, 5])
+    with pytest.raises(r0.R0HipError, match="one is missing"):
+        r0.Receipt.merge([a, r0.Receipt.new(journal, seals[1:4:2], claims[1:4:2], indices=[1, 3])])
+    with pytest.raises(r0.R0HipError, match="there twice"):
+        r0.Receipt.merge([a, b, r0.Receipt.new(journal, seals[1:2], claims[1:2], indices=[1])])
+    with pytest.raises(r0.R0HipError, match="another journal"):
+        r0.Receipt.merge([a, r0.Receipt.new(journal + b"\0\0\0\0", seals[1::2], claims[1::2], indices=[1, 3, 5])])
+    with pytest.raises(r0.R0HipError, match="not a composite"):
+        r0.Receipt.merge([a, r0.Receipt.new(journal)])

@@ -42,6 +42,52 @@ def _worker(rank, world, port, total_segments, out):
     env.close()
 
 
+def _session(n=7):
+    """seven segments of a made-up session: (journal, seals, claims)"""
+    import numpy as np
+    import hyperfridge_r0_amd as r0
+    states = [r0.SystemState.make(0x1000 + 4 * i, bytes([i + 1]) * 32) for i in range(n + 1)]
+    claims = [r0.ReceiptClaim.make(states[i], states[i + 1], 2 if i < n - 1 else 0, 0, None) for i in range(n)]
+    return r0.serde_encode_str('{"iban":"X"}'), [np.arange(300, dtype=np.uint32) * (i + 3) for i in range(n)], claims
+
+
+class _ShareOnlyHal:
+    """stands where Hal.prove_elf stands (the proofs need a GPU): hands out this rank's share of the made-up session"""
+    def prove_elf(self, circuit, elf, input_words, segment_po2=20, max_cycles=0, part=0, parts=1):
+        import hyperfridge_r0_amd as r0
+        journal, seals, claims = _session()
+        return r0.Receipt.new(journal, seals[part::parts], claims[part::parts], indices=list(range(part, len(seals), parts))), bytes(32), 123
+
+
+def _sharded_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from hyperfridge_r0_amd import driver
+    env = driver.DistEnv(backend="gloo")
+    receipt, _, cycles = driver.prove_elf_sharded(env, _ShareOnlyHal(), None, b"elf", [1, 2, 3])
+    out.put((rank, None if receipt is None else receipt.to_json(), cycles))
+    env.close()
+
+
+def test_a_session_sharded_over_two_ranks_arrives_whole_on_rank_zero():
+    """driver.prove_elf_sharded over gloo, world_size 2: rank r holds segments r, r + 2, ...; rank 1's receipt travels to rank 0 as
+    JSON over send / recv and the merged receipt is the whole session's (the proofs themselves are stood in for: they need a GPU)."""
+    import hyperfridge_r0_amd as r0
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    journal, seals, claims = _session()
+    assert results[0][1] == r0.Receipt.new(journal, seals, claims).to_json() and results[1][1] is None and results[0][2] == results[1][2] == 123
+
+
 def test_shard_segments_partitions_exactly():
     sys.path.insert(0, ROOT)
     from hyperfridge_r0_amd import driver

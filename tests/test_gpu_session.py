@@ -210,6 +210,13 @@ def test_prove_elf_with_the_trace_circuit_proves_the_run_it_executed(hal, orc):
     assert len(other.seals()) < len(seals)
     again, _, _ = hal.prove_elf(gc, elf, stream, segment_po2=po2)
     assert again.to_json() == receipt.to_json()
+    # a session proved in shares (what each GPU of a multi-GPU run does: segments part, part + parts, ...): the shares hold their
+    # own segments only, and merged -- in any order -- they are the receipt above, seal for seal
+    for parts in (2, 3):
+        shares = [hal.prove_elf(gc, elf, stream, segment_po2=po2, part=k, parts=parts)[0] for k in range(parts)]
+        assert [[i for i, _ in sh.seals()] for sh in shares] == [list(range(k, len(seals), parts)) for k in range(parts)]
+        assert shares[1].verify(blob, roots, image_id)[0] != 0  # a share alone is not the session
+        assert r0.Receipt.merge(shares[::-1]).to_json() == receipt.to_json(), parts
     # a guest that fails or never halts is an error, not a receipt
     with pytest.raises(r0.R0HipError, match="did not halt"):
         hal.prove_elf(gc, elf, stream, segment_po2=po2, max_cycles=100)

@@ -8,7 +8,11 @@ own inputs); with --guest camt53 the whole pipeline of tools/guest_camt53.py (RS
 whose journal is the reference's committed receipt's.  What is reported: segments per second of the whole pipeline, the executor's rate,
 host milliseconds per segment (executor thread; it overlaps the device), device-side milliseconds per segment for witness
 generation and proof.  The receipt is verified against the image id before the line is printed.
-usage: python tools/bench_session.py [--po2 20] [--cycles 8000000] [--guest loop|rsa|camt53] [--repeat 2]"""
+usage: python tools/bench_session.py [--po2 20] [--cycles 8000000] [--guest loop|rsa|camt53] [--repeat 2]
+Several GPUs: launch it under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... tools/bench_session.py ...`:
+every rank executes the guest and proves segments rank, rank + N, ... (r0h_prove_elf_part); rank 0 collects the receipts
+(driver.prove_elf_sharded: point-to-point, no collective on the data path), merges and verifies them and prints the line.
+--backend gloo --share-device rehearses that on one GPU."""
 import argparse
 import json
 import os
@@ -48,7 +52,10 @@ def main():
     ap.add_argument("--guest", default="loop")
     ap.add_argument("--repeat", type=int, default=2, help="runs; the last one is reported (the first pays for code objects, pools, CODE commitments)")
     ap.add_argument("--oracle-check", type=int, default=1, help="verify this many seals with the CPU oracle's verifier as well")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks on GPU 0 (rehearsal on a one-GPU box)")
     args = ap.parse_args()
+    world, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     import __graft_entry__ as entry
     entry.ensure_built()
     import hyperfridge_r0_amd as r0
@@ -67,13 +74,33 @@ def main():
         elf, stream = elf_of(prog, 0x400), [7, 0x01020304]
         what = "store loop over a 32 KiB window (7 instructions per iteration, one store), about %d cycles" % args.cycles
     blob = np.fromfile(entry.circuit_blob_path("trace"), dtype=np.uint32)
-    hal = r0.Hal(0)
+    env = None
+    if world > 1:
+        import torch
+        from hyperfridge_r0_amd import driver
+        index = 0 if args.share_device else local
+        torch.cuda.set_device(index)
+        env = driver.DistEnv(backend=args.backend, device=torch.device("cuda", index))
+        hal = r0.Hal(index)
+    else:
+        hal = r0.Hal(0)
     gc = hal.load_circuit(blob, entry.code_object_path("trace"))
     for _ in range(max(1, args.repeat)):
+        if env is not None:
+            env.barrier()
         t0 = time.perf_counter()
-        receipt, image_id, cycles = hal.prove_elf(gc, elf, stream, segment_po2=args.po2)
+        if env is None:
+            receipt, image_id, cycles = hal.prove_elf(gc, elf, stream, segment_po2=args.po2)
+        else:
+            receipt, image_id, cycles = driver.prove_elf_sharded(env, hal, gc, elf, stream, segment_po2=args.po2)
+            env.barrier()
         wall = time.perf_counter() - t0
         st = hal.last_session_stats()
+    if env is not None and env.rank != 0:
+        gc.free()
+        hal.close()
+        env.close()
+        return
     seals = receipt.seals()
     roots = {}
     for _, seal in seals:
@@ -89,19 +116,21 @@ def main():
         oc = orc_binding.load().circuit(blob)
         for _, seal in seals[:args.oracle_check]:
             assert oc.verify(seal, code_root=roots[r0.verify_seal(blob, seal)[2]]) == (0, "ok")
-    n = st["segments"]
+    n = len(seals)
     line = {"metric": "segments/s of prove(env, elf) with the trace circuit: executor + device witgen + proof, all inside the timed region",
-            "value": round(n / wall, 4), "unit": "segments/s", "n_gpus": 1, "segment_po2": args.po2, "segments": n, "cycles": cycles,
+            "value": round(n / wall, 4), "unit": "segments/s", "n_gpus": world, "sharding": None if env is None else "segments rank, rank + %d, ... per rank (%s%s); receipts merged on rank 0" % (world, args.backend, ", all ranks on one GPU" if args.share_device else ""), "segment_po2": args.po2, "segments": n, "cycles": cycles,
             "wall_s": round(wall, 4), "guest": what,
-            "executor": {"host_s": round(st["executor_s"], 4), "MHz_with_trace_kept": round(cycles / st["executor_s"] / 1e6, 2), "host_ms_per_segment": round(1e3 * st["executor_s"] / n, 3),
+            "executor": {"host_s": round(st["executor_s"], 4), "MHz_with_trace_kept": round(cycles / st["executor_s"] / 1e6, 2), "host_ms_per_segment": round(1e3 * st["executor_s"] / max(1, st["segments"]), 3),
                          "note": "own host thread, overlaps the device work of the previous segment"},
-            "device": {"witgen_ms_per_segment": round(st["witgen_ms"] / n, 3), "prove_ms_per_segment": round(st["prove_ms"] / n, 3),
+            "device": {"witgen_ms_per_segment": round(st["witgen_ms"] / max(1, st["segments"]), 3), "prove_ms_per_segment": round(st["prove_ms"] / max(1, st["segments"]), 3),
                        "note": "witgen = upload of 72 B/cycle + 16 B/boundary row and the expansion kernel; prove = r0h_prove_segment_committed (CODE committed once per trace size)"},
             "circuit": "trace.r0c W=(%d accum, %d code, %d data)" % tuple(gc.group_size), "seal_words": int(seals[0][1].size),
             "receipt_verified": True, "journal_commitment": commitment(r0, receipt.journal), "data": "synthetic guest; no guest ELF exists in the reference (needs the Rust toolchain)"}
     print(json.dumps(line))
     gc.free()
     hal.close()
+    if env is not None:
+        env.close()
 
 
 if __name__ == "__main__":
