@@ -57,7 +57,18 @@ def main():
     args = ap.parse_args()
     world, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     import __graft_entry__ as entry
-    entry.ensure_built()
+    env = None
+    if world > 1:  # the order bench.py keeps: torch and the process group first, local rank 0 builds, the library is loaded after the barrier
+        import torch
+        from hyperfridge_r0_amd import driver
+        if local == 0:
+            entry.ensure_built()
+        index = 0 if args.share_device else local
+        torch.cuda.set_device(index)
+        env = driver.DistEnv(backend=args.backend, device=torch.device("cuda", index))
+        env.barrier()
+    else:
+        entry.ensure_built()
     import hyperfridge_r0_amd as r0
     if args.guest in ("rsa", "camt53"):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -74,16 +85,7 @@ def main():
         elf, stream = elf_of(prog, 0x400), [7, 0x01020304]
         what = "store loop over a 32 KiB window (7 instructions per iteration, one store), about %d cycles" % args.cycles
     blob = np.fromfile(entry.circuit_blob_path("trace"), dtype=np.uint32)
-    env = None
-    if world > 1:
-        import torch
-        from hyperfridge_r0_amd import driver
-        index = 0 if args.share_device else local
-        torch.cuda.set_device(index)
-        env = driver.DistEnv(backend=args.backend, device=torch.device("cuda", index))
-        hal = r0.Hal(index)
-    else:
-        hal = r0.Hal(0)
+    hal = r0.Hal(0 if (env is None or args.share_device) else local)
     gc = hal.load_circuit(blob, entry.code_object_path("trace"))
     for _ in range(max(1, args.repeat)):
         if env is not None:
