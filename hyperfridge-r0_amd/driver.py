@@ -2,7 +2,12 @@
 
 Segments are independent units: rank r proves segments r, r + world, r + 2*world, ...  The only
 communication is the barrier around the timed region and the MAX / SUM reductions of the per-rank results, over
-torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
+torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
+
+Order matters in a process that uses both: import torch (and set the device, build the process group) BEFORE libr0hip.so is first
+used -- the library then binds to the HIP runtime torch has loaded; the other way round the process holds two HIP runtimes and the
+second one to initialise finds no device (seen on the GPU box under torch.distributed.run; bench.py and tools/bench_session.py keep
+this order)."""
 import os
 import time
 
