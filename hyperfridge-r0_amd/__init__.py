@@ -9,6 +9,7 @@ There is NO CPU fallback: importing works without a GPU (so the ABI can be inspe
 needs a device and raises R0HipError otherwise.
 """
 import ctypes
+import sys
 import os
 
 import numpy as np
@@ -884,7 +885,14 @@ class Hal:
 
     def __init__(self, device=0):
         self.ctx = _vp()
-        _check(lib().r0h_ctx_create(device, ctypes.byref(self.ctx)))
+        try:
+            _check(lib().r0h_ctx_create(device, ctypes.byref(self.ctx)))
+        except R0HipError as exc:
+            if "no ROCm-capable device" in str(exc) and "torch" in sys.modules:
+                # torch brings its own HIP runtime: loaded AFTER libr0hip.so the process holds two, and the second to initialise finds no
+                # device (hyperfridge-r0_amd/driver.py).  Import torch before the first call into this library.
+                raise R0HipError(str(exc) + "  [torch was imported after libr0hip.so was first used: import torch first]") from None
+            raise
 
     def close(self):
         if self.ctx:
