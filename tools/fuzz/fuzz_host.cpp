@@ -158,6 +158,17 @@ extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
         uint32_t roots[9] = {9, 1, 2, 3, 4, 5, 6, 7, 8};
         uint8_t image[32] = {0};
         drop(r0h_receipt_verify(rc, fx().blob.data(), fx().blob.size(), roots, 1, image, &verdict, &seg, &sv));
+        {  // a receipt merged with itself (segments twice: refused for a composite one) and on its own (complete or not)
+          const r0h_receipt* twice[2] = {rc, rc};
+          r0h_receipt* merged = nullptr;
+          if (good(r0h_receipt_merge(twice, 2, &merged))) r0h_receipt_free(merged);
+          merged = nullptr;
+          if (good(r0h_receipt_merge(twice, 1, &merged))) {
+            char* js2 = nullptr;
+            if (good(r0h_receipt_to_json(merged, &js2))) r0h_free_error(js2);
+            r0h_receipt_free(merged);
+          }
+        }
         r0h_receipt_free(rc);
       }
       break;

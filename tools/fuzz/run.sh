@@ -24,7 +24,7 @@ done
 cat > "$WORK/stubs.cpp" <<'STUB'
 #include <stdint.h>
 struct r0h_ctx; struct r0h_buf;
-namespace r0h { const char* ntt_init_device() { return nullptr; } }
+namespace r0h { const char* ntt_init_device() { return nullptr; } void session_rows_free(r0h_ctx*) {} }  // (session.cpp needs a device)
 extern "C" const char* r0h_prefix_products(r0h_ctx*, r0h_buf*, uint32_t) { __builtin_trap(); }
 STUB
 $CLANG $FLAGS -c "$WORK/stubs.cpp" -o "$WORK/obj/stubs.o"
