@@ -149,6 +149,7 @@ _SIGNATURES = {
     "r0h_last_session_stats": [_vp, _vp],
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
+    "r0h_compute_image_id": [_vp, _sz, _vp],
     "r0h_prove_elf": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _pp, _vp, _c.POINTER(_u64)],
     "r0h_prove_elf_part": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _u32, _u32, _pp, _vp, _c.POINTER(_u64)],
     "r0h_receipt_merge": [_pp, _sz, _pp],
@@ -726,6 +727,14 @@ class Vm:
             self.close()
         except Exception:
             pass
+
+
+def compute_image_id(elf):
+    """r0h_compute_image_id: the 32-byte image id of an ELF (risc0-binfmt `compute_image_id`; what prove_elf returns beside the receipt)"""
+    elf = bytes(elf)
+    out = (ctypes.c_uint8 * 32)()
+    _check(lib().r0h_compute_image_id(elf, len(elf), out))
+    return bytes(out)
 
 
 def image_id_from_hex(text):

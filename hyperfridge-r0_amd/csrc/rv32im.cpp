@@ -631,6 +631,24 @@ const char* r0h_vm_load_elf(r0h_vm* vm, const uint8_t* elf, size_t n) {
   R0H_GUARD_END
 }
 
+// risc0-binfmt `compute_image_id(elf)` in this library's terms: the digest of the SystemState a run of this ELF starts from (entry pc,
+// Merkle root of the loaded pages) -- what r0h_prove_elf returns as image id and r0h_receipt_verify holds a receipt against
+const char* r0h_compute_image_id(const uint8_t* elf, size_t n, uint8_t image_id_out[32]) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(elf && image_id_out, "r0h_compute_image_id: NULL argument");
+  r0h_vm* vm = nullptr;
+  R0H_TRY(r0h_vm_new(&vm));
+  struct Guard { r0h_vm* v; ~Guard() { r0h_vm_free(v); } } guard{vm};
+  R0H_TRY(r0h_vm_load_elf(vm, elf, n));
+  r0h_system_state st;
+  memset(&st, 0, sizeof st);
+  st.pc = vm->pc;
+  memory_root(*vm, st.merkle_root);
+  system_state_digest(st, image_id_out);
+  return nullptr;
+  R0H_GUARD_END
+}
+
 const char* r0h_vm_set_input(r0h_vm* vm, const uint32_t* words, size_t n) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(vm && (words || !n), "r0h_vm_set_input: NULL argument");

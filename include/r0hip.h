@@ -409,6 +409,9 @@ const char* r0h_vm_new(r0h_vm** out);
 const char* r0h_vm_free(r0h_vm* vm);
 const char* r0h_vm_load(r0h_vm* vm, uint32_t addr, const uint32_t* words, size_t n);
 const char* r0h_vm_load_elf(r0h_vm* vm, const uint8_t* elf, size_t n); /* ELF32 LE RISC-V executable: PT_LOAD segments + entry */
+/* the image id of an ELF -- risc0-binfmt `compute_image_id`, what `methods/build.rs` embeds as HYPERFRIDGE_ID: the digest of the
+ * SystemState a run starts from (r0h_prove_elf returns the same 32 bytes).  Pure host code. */
+const char* r0h_compute_image_id(const uint8_t* elf, size_t n, uint8_t image_id_out[32]);
 const char* r0h_vm_set_input(r0h_vm* vm, const uint32_t* words, size_t n); /* the ExecutorEnv word stream (r0h_env_words) */
 const char* r0h_vm_set_pc(r0h_vm* vm, uint32_t pc);
 const char* r0h_vm_set_reg(r0h_vm* vm, uint32_t i, uint32_t value);

@@ -263,6 +263,7 @@ def test_the_last_segment_of_the_real_run_proves_on_the_cpu(orc):
     image, stream, _ = guest_camt53.elf_and_input(form=1)
     vm, k = _last_segment(image, stream)
     seg = vm.segments()[k]
+    assert r0.compute_image_id(image) == bytes(vm.segments()[0].pre.digest()) != r0.compute_image_id(image[:-4] + bytes(4))
     assert k == 11 and seg.user_cycles + seg.boundary_rows <= 1 << 19 and vm.journal == journal_of("reference_receipt_6bb95807_latest.json")
     blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
     oc = orc.circuit(blob)
@@ -284,6 +285,7 @@ def test_the_proved_receipt_carries_the_references_journal(hal, orc):
     gc = hal.load_circuit(blob, entry.code_object_path("trace"))
     receipt, image_id, cycles = hal.prove_elf(gc, image, stream, segment_po2=20)
     assert receipt.journal == journal_of("reference_receipt_6bb95807_latest.json") and cycles > 11_000_000
+    assert image_id == r0.compute_image_id(image)  # what a verifier derives from the ELF alone (risc0: compute_image_id / HYPERFRIDGE_ID)
     seals = receipt.seals()
     roots = {}
     for _, seal in seals:
