@@ -3,6 +3,8 @@
 // Needs no GPU.  Exit status: 0 accepted, 1 rejected (reason on stdout), 2 unusable input.
 //   usage: r0h_verify <circuit.r0c> <seal.bin>
 //          r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --control-root <po2>:<w0,..,w7> [--control-root ..]
+//          r0h_verify --receipt <receipt.json> <circuit.r0c> --elf <guest.elf> --control-root ...   (the image id computed from the ELF:
+//                     r0h_compute_image_id, what risc0_build embeds as HYPERFRIDGE_ID)
 //                     `receipt.verify(image_id)` for a composite receipt (r0h_receipt_verify): seals against the control roots, claims
 //                     named by the seals, segment chain, journal digest, image id; then the commitment (verifier/src/main.rs:124-128).
 //                     Without --image-id / --control-root the seals alone are checked and the result is reported as NOT accepted
@@ -39,7 +41,7 @@ static void print_json_string(const uint8_t* p, size_t n) {
 }
 
 // verifier/src/main.rs:114-128: read the receipt JSON, verify it against the image id, print the commitment
-static int verify_receipt(const char* receipt_path, const char* blob_path, const char* image_hex, const std::vector<uint32_t>& roots) {
+static int verify_receipt(const char* receipt_path, const char* blob_path, const char* image_hex, const std::vector<uint32_t>& roots, const char* elf_path = nullptr) {
   std::vector<uint32_t> blob;
   if (!read_words(blob_path, &blob)) { fprintf(stderr, "r0h_verify: cannot read %s as 32-bit words\n", blob_path); return 2; }
   FILE* f = fopen(receipt_path, "rb");
@@ -52,6 +54,18 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
   const char* err = r0h_receipt_parse(text.data(), text.size(), &rc);
   if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); return 2; }
   uint8_t image_id[32];
+  char hex_of_elf[65];
+  if (elf_path && !image_hex) {
+    FILE* e = fopen(elf_path, "rb");
+    if (!e) { fprintf(stderr, "r0h_verify: cannot open %s\n", elf_path); r0h_receipt_free(rc); return 2; }
+    std::vector<uint8_t> elf;
+    for (size_t got; (got = fread(buf, 1, sizeof buf, e)) > 0;) elf.insert(elf.end(), buf, buf + got);
+    fclose(e);
+    err = r0h_compute_image_id(elf.data(), elf.size(), image_id);
+    if (!err) err = r0h_image_id_to_hex(image_id, hex_of_elf);
+    if (err) { fprintf(stderr, "r0h_verify: --elf: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
+    image_hex = hex_of_elf;
+  }
   if (image_hex) {
     // eight {:08x} words, each little-endian in the digest: the reference's IMAGE_ID.hex convention (r0h_image_id_from_hex)
     err = r0h_image_id_from_hex(image_hex, image_id);
@@ -96,9 +110,11 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
 int main(int argc, char** argv) {
   if (argc >= 4 && !strcmp(argv[1], "--receipt")) {
     const char* image_hex = nullptr;
+    const char* elf_path = nullptr;
     std::vector<uint32_t> roots;  // records of [po2, root[8]]
     for (int i = 4; i + 1 < argc; i += 2) {
       if (!strcmp(argv[i], "--image-id")) image_hex = argv[i + 1];
+      else if (!strcmp(argv[i], "--elf")) elf_path = argv[i + 1];
       else if (!strcmp(argv[i], "--control-root")) {
         unsigned v[9];
         if (sscanf(argv[i + 1], "%u:%u,%u,%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) != 9) {
@@ -108,7 +124,7 @@ int main(int argc, char** argv) {
         roots.insert(roots.end(), v, v + 9);
       } else { fprintf(stderr, "r0h_verify: unknown option %s\n", argv[i]); return 2; }
     }
-    return verify_receipt(argv[2], argv[3], image_hex, roots);
+    return verify_receipt(argv[2], argv[3], image_hex, roots, elf_path);
   }
   if (argc != 3) {
     printf("usage: r0h_verify <circuit.r0c> <seal.bin>\n       r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --control-root <po2>:<w0,..,w7>\n%s\n", r0h_version());
