@@ -150,6 +150,7 @@ _SIGNATURES = {
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
     "r0h_compute_image_id": [_vp, _sz, _vp],
+    "r0h_control_root_host": [_vp, _sz, _vp, _vp, _u32, _vp],
     "r0h_prove_elf": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _pp, _vp, _c.POINTER(_u64)],
     "r0h_prove_elf_part": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _u32, _u32, _pp, _vp, _c.POINTER(_u64)],
     "r0h_receipt_merge": [_pp, _sz, _pp],
@@ -727,6 +728,20 @@ class Vm:
             self.close()
         except Exception:
             pass
+
+
+def control_root_host(blob, po2, round_constants=None, diag_m1=None):
+    """r0h_control_root_host: the control root of the circuit's own CODE columns at trace size 2^po2, computed on the host from the blob
+    (the 8 words Hal.code_commit(...).root() gives on the device)"""
+    blob, pb = _u32arr(blob)
+    out = np.zeros(8, dtype=np.uint32)
+    rc = dg = None
+    prc = pdg = None
+    if round_constants is not None:
+        rc, prc = _u32arr(round_constants)
+        dg, pdg = _u32arr(diag_m1)
+    _check(lib().r0h_control_root_host(pb, blob.size, prc, pdg, po2, out.ctypes.data_as(_vp)))
+    return out
 
 
 def compute_image_id(elf):

@@ -7,7 +7,8 @@
 //                     r0h_compute_image_id, what risc0_build embeds as HYPERFRIDGE_ID)
 //                     `receipt.verify(image_id)` for a composite receipt (r0h_receipt_verify): seals against the control roots, claims
 //                     named by the seals, segment chain, journal digest, image id; then the commitment (verifier/src/main.rs:124-128).
-//                     Without --image-id / --control-root the seals alone are checked and the result is reported as NOT accepted
+//                     Without --control-root the roots are derived from the circuit itself (r0h_control_root_host; a circuit with a
+//                     column program); without --image-id / --elf the seals alone are checked and the result is reported as NOT accepted
 //                     ("journal_bound": false, exit status 1): valid seals plus any journal would otherwise pass.
 #include <stdint.h>
 #include <stdio.h>
@@ -41,7 +42,7 @@ static void print_json_string(const uint8_t* p, size_t n) {
 }
 
 // verifier/src/main.rs:114-128: read the receipt JSON, verify it against the image id, print the commitment
-static int verify_receipt(const char* receipt_path, const char* blob_path, const char* image_hex, const std::vector<uint32_t>& roots, const char* elf_path = nullptr) {
+static int verify_receipt(const char* receipt_path, const char* blob_path, const char* image_hex, std::vector<uint32_t> roots, const char* elf_path = nullptr) {
   std::vector<uint32_t> blob;
   if (!read_words(blob_path, &blob)) { fprintf(stderr, "r0h_verify: cannot read %s as 32-bit words\n", blob_path); return 2; }
   FILE* f = fopen(receipt_path, "rb");
@@ -72,6 +73,26 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
     if (err) { fprintf(stderr, "r0h_verify: --image-id: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
   }
   const size_t n_seg = r0h_receipt_n_segments(rc);
+  bool derived_roots = false;
+  if (image_hex && roots.empty()) {
+    // no control roots given: derive them from the circuit itself (r0h_control_root_host: the CODE columns of its column program,
+    // committed on the host), one per trace size that occurs in the receipt -- as risc0's verifier looks them up in its own table
+    for (size_t i = 0; i < n_seg; i++) {
+      const uint32_t* seal; size_t words; uint32_t po2 = 0; int sv = 0;
+      err = r0h_receipt_segment(rc, i, &seal, &words, nullptr);
+      if (!err) err = r0h_verify_seal(blob.data(), blob.size(), nullptr, nullptr, seal, words, &sv, &po2);
+      if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
+      bool have = false;
+      for (size_t k = 0; k + 9 <= roots.size(); k += 9) have = have || roots[k] == po2;
+      if (have || po2 == 0) continue;
+      uint32_t root[8];
+      err = r0h_control_root_host(blob.data(), blob.size(), nullptr, nullptr, po2, root);
+      if (err) { fprintf(stderr, "r0h_verify: no --control-root given and none can be derived: %s\n", err); r0h_free_error(err); roots.clear(); break; }
+      roots.push_back(po2);
+      roots.insert(roots.end(), root, root + 8);
+      derived_roots = true;
+    }
+  }
   const bool bound = image_hex && !roots.empty();
   int verdict = -1, seal_verdict = R0H_VERIFY_OK;
   size_t at = 0;
@@ -99,8 +120,9 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
   (void)r0h_receipt_journal(rc, &journal, &jn);
   err = r0h_journal_commitment_span(journal, jn, &off, &len);
   if (err) { r0h_free_error(err); len = 0; }
-  printf("{\"accepted\": %s, \"seals_valid\": %s, \"journal_bound\": %s, \"segments\": %zu, \"segment_at_fault\": %zu, \"reason\": \"%s\", \"commitment\": ",
-         accepted ? "true" : "false", seals_valid ? "true" : "false", accepted ? "true" : "false", n_seg, at, accepted ? "ok" : reason);
+  printf("{\"accepted\": %s, \"seals_valid\": %s, \"journal_bound\": %s, \"segments\": %zu, \"segment_at_fault\": %zu, \"reason\": \"%s\", \"control_roots\": \"%s\", \"commitment\": ",
+         accepted ? "true" : "false", seals_valid ? "true" : "false", accepted ? "true" : "false", n_seg, at, accepted ? "ok" : reason,
+         derived_roots ? "derived from the circuit" : roots.empty() ? "none" : "given");
   print_json_string(journal + off, len);
   printf("}\n");
   r0h_receipt_free(rc);

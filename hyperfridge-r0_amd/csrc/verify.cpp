@@ -430,4 +430,100 @@ const char* r0h_verify_seal_bound(const uint32_t* blob, size_t blob_words, const
   return verify_entry(blob, blob_words, p2_round_constants, p2_diag_m1, seal, seal_words, expected_code_root, verdict_out, po2_out, code_root_out);
 }
 
+// ---- the control root of a circuit's own CODE columns, on the host.  A verifier is handed control roots (risc0's has a table of
+// them compiled in); this lets it derive them from the circuit blob alone instead of trusting the prover's word: the CODE columns of
+// the blob's column program (first-row / last-row indicator, row index, seeded column -- what r0h_witgen generates on the device),
+// interpolated, shifted by 3, evaluated on the 4N coset, rows hashed, folded.  Plain radix-2 transforms and one Poseidon2 permutation
+// per row and node: seconds at 2^20 rows, spread over the host's threads.
+}  // extern "C"
+namespace {
+uint64_t splitmix64_h(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// in place, natural order in and out; w = a primitive 2^log_n-th root of unity (Montgomery words throughout)
+void ntt_host(uint32_t* a, uint32_t log_n, uint32_t w) {
+  const size_t n = (size_t)1 << log_n;
+  for (size_t i = 0; i < n; i++) {
+    const size_t j = bitrev((uint32_t)i, log_n);
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  std::vector<uint32_t> tw(n / 2);
+  uint32_t x = ONE;
+  for (size_t i = 0; i < n / 2; i++) { tw[i] = x; x = mul(x, w); }
+  for (uint32_t s = 1; s <= log_n; s++) {
+    const size_t half = (size_t)1 << (s - 1), step = n >> s;
+    for (size_t base = 0; base < n; base += 2 * half)
+      for (size_t k = 0; k < half; k++) {
+        const uint32_t u = a[base + k], v = mul(a[base + k + half], tw[k * step]);
+        a[base + k] = add(u, v);
+        a[base + k + half] = sub(u, v);
+      }
+  }
+}
+template <class F>
+void in_parallel(size_t n, F f) {
+  const size_t workers = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 16));
+  std::vector<std::thread> ts;
+  for (size_t t = 0; t < workers; t++) ts.emplace_back([=] { for (size_t i = n * t / workers; i < n * (t + 1) / workers; i++) f(i); });
+  for (auto& t : ts) t.join();
+}
+}  // namespace
+extern "C" {
+
+const char* r0h_control_root_host(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
+                                  uint32_t po2, uint32_t root_out[8]) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(blob && root_out, "r0h_control_root_host: NULL argument");
+  R0H_REQUIRE((p2_round_constants == nullptr) == (p2_diag_m1 == nullptr), "r0h_control_root_host: pass both Poseidon2 tables or neither");
+  R0H_REQUIRE(po2 >= 4 && po2 <= R0H_MAX_PO2, "r0h_control_root_host: po2 %u outside [4, %u]", po2, (unsigned)R0H_MAX_PO2);
+  r0h_circuit c;
+  R0H_TRY(parse_blob(&c, blob, blob_words));
+  R0H_REQUIRE(c.has_column_program, "r0h_control_root_host: the circuit has no column program: its CODE columns come from elsewhere");
+  std::unique_ptr<P2Consts> k(new P2Consts);
+  if (p2_round_constants) fill_p2(*k, p2_round_constants, p2_diag_m1);
+  else p2_default_host(*k);
+  const uint32_t count = c.group_size[R0H_GROUP_CODE];
+  const size_t n = (size_t)1 << po2, m = 4 * n;
+  R0H_REQUIRE(c.code_cols.size() == count && count >= 1, "r0h_control_root_host: %zu CODE columns described, %u in the group", c.code_cols.size(), count);
+  const uint64_t seed = splitmix64_h(0xC0DEull);  // the seed r0h_witgen gives the CODE group
+  const uint32_t w_n_inv = rou_rev(po2), w_m = rou_fwd(po2 + 2), n_inv = inv(enc((uint32_t)n)), three = enc(3);
+  std::vector<uint32_t> evals((size_t)count * m);
+  for (uint32_t col = 0; col < count; col++) {
+    uint32_t* a = &evals[(size_t)col * m];
+    const uint32_t kind = c.code_cols[col].kind, stream = (1u << 16) | col;  // the stream r0h_witgen draws CODE column `col` from
+    R0H_REQUIRE(kind <= 3, "r0h_control_root_host: CODE column %u has kind %u", col, kind);
+    for (size_t r = 0; r < n; r++) {
+      if (kind == 0) a[r] = r == 0 ? ONE : 0u;
+      else if (kind == 1) a[r] = r == n - 1 ? ONE : 0u;
+      else if (kind == 2) a[r] = enc((uint32_t)r);
+      else {
+        const uint64_t h = splitmix64_h(seed ^ (((uint64_t)stream << 32) | (uint32_t)r));
+        a[r] = (uint32_t)(((h >> 32) * (uint64_t)P) >> 32);
+      }
+    }
+    ntt_host(a, po2, w_n_inv);  // values on the 2^po2 subgroup -> coefficients (times n)
+    uint32_t shift = n_inv;     // ... scaled back and moved to the coset 3 <w>: coefficient i times 3^i
+    for (size_t i = 0; i < n; i++) { a[i] = mul(a[i], shift); shift = mul(shift, three); }
+    std::fill(a + n, a + m, 0u);
+    ntt_host(a, po2 + 2, w_m);  // evaluations on the 4N coset, natural order
+  }
+  std::vector<uint32_t> nodes(2 * m * 8);
+  in_parallel(m, [&](size_t r) {
+    uint32_t row[64];
+    std::vector<uint32_t> wide;
+    uint32_t* v = row;
+    if (count > 64) { wide.resize(count); v = wide.data(); }
+    for (uint32_t col = 0; col < count; col++) v[col] = evals[(size_t)col * m + r];
+    p2_hash_elems_host(*k, v, count, &nodes[(m + r) * 8]);
+  });
+  for (size_t level = m / 2; level >= 1; level /= 2)
+    in_parallel(level, [&](size_t i) { hash_pair(*k, &nodes[2 * (level + i) * 8], &nodes[(2 * (level + i) + 1) * 8], &nodes[(level + i) * 8]); });
+  memcpy(root_out, &nodes[8], 32);
+  return nullptr;
+  R0H_GUARD_END
+}
+
 }  // extern "C"

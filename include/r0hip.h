@@ -209,6 +209,11 @@ const char* r0h_verify_seal_bound(const uint32_t* blob, size_t blob_words, const
                                   const uint32_t* p2_diag_m1, const uint32_t* seal, size_t seal_words,
                                   const uint32_t* expected_code_root, int* verdict_out, uint32_t* po2_out,
                                   uint32_t* code_root_out);
+/* The control root of a circuit's own CODE columns at trace size 2^po2, computed on the HOST from the blob alone (circuits with a
+ * column program: the CODE columns r0h_witgen generates) -- the same 8 words as r0h_code_root / r0h_code_commit_root on the device.
+ * A verifier that has the circuit need not be told its control roots (risc0's verifier has them compiled in).  Seconds at po2 = 20. */
+const char* r0h_control_root_host(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
+                                  uint32_t po2, uint32_t root_out[8]);
 const char* r0h_verify_reason(int verdict); /* static string, do not free */
 /* Poseidon2 sponge (compiled-in table) over a seal's words (all canonical field elements, else an error): the 8-word name a
  * recursion step commits to */

@@ -200,3 +200,17 @@ def test_the_receipts_of_several_ranks_merge_into_the_sessions_receipt():
         r0.Receipt.merge([a, r0.Receipt.new(journal + b"\0\0\0\0", seals[1::2], claims[1::2], indices=[1, 3, 5])])
     with pytest.raises(r0.R0HipError, match="not a composite"):
         r0.Receipt.merge([a, r0.Receipt.new(journal)])
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "recursion", "trace", "bench"])
+def test_the_verifier_can_derive_a_circuits_control_roots_itself(orc, name):
+    """r0h_control_root_host: the CODE columns of the circuit's column program committed on the host -- interpolate, shift by 3,
+    evaluate on the 4N coset, hash rows, fold -- give the control root the oracle computes from the CODE group it generates (and, on
+    the GPU, the root of r0h_code_commit: tests/test_gpu_code_commit.py).  A verifier with the blob needs no table of roots."""
+    blob = np.fromfile(circuit_path(name), dtype=np.uint32)
+    c = orc.circuit(blob)
+    for po2 in (9, 10, 13):
+        assert np.array_equal(r0.control_root_host(blob, po2), c.code_root(c.witgen(po2, 0)[0], po2)), po2
+    assert not np.array_equal(r0.control_root_host(blob, 9), r0.control_root_host(blob, 10))
+    with pytest.raises(r0.R0HipError, match="po2"):
+        r0.control_root_host(blob, 3)

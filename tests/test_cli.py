@@ -131,6 +131,10 @@ def test_compiled_hosts_prove_the_guest_and_verify_the_receipt_like_host_and_ver
     other = "0" * 64
     out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", other] + bind[2:], capture_output=True, text=True, timeout=600)
     assert out.returncode == 1 and "image id" in json.loads(out.stdout)["reason"]
+    # no control roots given: the verifier derives them from the circuit blob itself (r0h_control_root_host, seconds per trace size)
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", info["image_id"]], capture_output=True, text=True, timeout=900)
+    report = json.loads(out.stdout)
+    assert out.returncode == 0 and report["accepted"] is True and report["control_roots"] == "derived from the circuit"
     # the verifier given the ELF instead of the id (what `methods/build.rs` embeds as HYPERFRIDGE_ID): the same verdict; another ELF: refused
     out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--elf", elf_path] + bind[2:], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and json.loads(out.stdout)["accepted"] is True

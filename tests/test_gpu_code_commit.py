@@ -20,6 +20,7 @@ def test_committed_code_gives_the_same_seal_as_the_oracle(hal, orc, name, po2):
     oc = orc.circuit(blob)
     cc = hal.code_commit(gc, po2)
     assert np.array_equal(cc.root(), hal.code_root(gc, po2))
+    assert np.array_equal(cc.root(), r0.control_root_host(blob, po2))  # what a verifier derives from the blob alone, on the host
     for seed in (7, 8):
         code, data, glob_ = hal.witgen(gc, po2, seed)
         plain = hal.prove_segment(gc, po2, code, data, glob_)
