@@ -132,6 +132,7 @@ extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
       r0h_vm* vm = nullptr;
       if (!good(r0h_vm_new(&vm))) break;
       if (good(r0h_vm_load_elf(vm, d, n))) run_vm(vm);
+      { uint8_t id[32]; drop(r0h_compute_image_id(d, n, id)); }
       r0h_vm_free(vm);
       break;
     }
@@ -189,6 +190,7 @@ extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
       drop(r0h_verify_seal(w.data(), w.size(), nullptr, nullptr, fx().seal.data(), fx().seal.size(), &verdict, &po2));
       char* src = nullptr;
       if (good(r0h_circuit_emit_hip(w.data(), w.size(), &src))) r0h_free_error(src);
+      { uint32_t root[8]; drop(r0h_control_root_host(w.data(), w.size(), nullptr, nullptr, 4 + (w.empty() ? 0 : w[0] % 3), root)); }  // the blob as a verifier meets it
       break;
     }
     default: {  // a genuine seal with a few words replaced: reaches the deep checks (Merkle paths, FRI) that random words never do
