@@ -150,6 +150,7 @@ _SIGNATURES = {
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
     "r0h_compute_image_id": [_vp, _sz, _vp],
+    "r0h_camt53_guest_input": [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _c.c_char_p, _c.c_char_p, _u32, _pp, _c.POINTER(_sz)],
     "r0h_control_root_host": [_vp, _sz, _vp, _vp, _u32, _vp],
     "r0h_prove_elf": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _pp, _vp, _c.POINTER(_u64)],
     "r0h_prove_elf_part": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _u32, _u32, _pp, _vp, _c.POINTER(_u64)],
@@ -416,6 +417,19 @@ class Ebics:
         p, n = _vp(), _sz(0)
         _check(lib().r0h_ebics_part(self.handle, which, ctypes.byref(p), ctypes.byref(n)))
         return ctypes.string_at(p, n.value) if n.value else b""
+
+    def camt53_guest_input(self, pub_bank_pem, pub_client_pem, pub_witness_pem, tx_key_block, witness_hex, iban, host_info, form=1):
+        """r0h_camt53_guest_input: the input word stream of this library's camt53 guest (tools/guest_camt53.py input_stream) -> uint32 array"""
+        pems = [p.encode() if isinstance(p, str) else bytes(p) for p in (pub_bank_pem, pub_client_pem, pub_witness_pem)]
+        block = bytes(tx_key_block)
+        hx = witness_hex.encode() if isinstance(witness_hex, str) else bytes(witness_hex)
+        words, n = _vp(), _sz(0)
+        _check(lib().r0h_camt53_guest_input(self.handle, pems[0], len(pems[0]), pems[1], len(pems[1]), pems[2], len(pems[2]), block, len(block), hx, len(hx),
+                                            iban.encode(), host_info.encode(), form, ctypes.byref(words), ctypes.byref(n)))
+        try:
+            return np.frombuffer(ctypes.string_at(words, 4 * n.value), dtype=np.uint32).copy()
+        finally:
+            lib().r0h_free_error(words)
 
     def _flag(self, fn, *args):
         ok = _c.c_int(-1)

@@ -1027,6 +1027,57 @@ const char* r0h_ebics_env_inputs(const r0h_ebics* e, const char* pub_bank_pem, s
 }
 
 // FIPS-197 known-answer hook for the tests: one AES-128 block, either direction
+// The input word stream of THIS library's hand-assembled camt53 guest (tools/guest_camt53.py: input_stream is the same list in
+// Python), from what the reference's host hands its guest (host/src/main.rs:389-417): length-prefixed byte frames, 2048-bit numbers as
+// 64 little-endian words, the public exponent.  Order = the order the guest reads: SignedInfo, the authenticated part, bank signature
+// / bank modulus / e, decrypted transaction key block / client modulus / encrypted transaction key / e, OrderData (binary), witness
+// signature / witness modulus / e, iban, host info, the commitment form.
+const char* r0h_camt53_guest_input(const r0h_ebics* e, const char* pub_bank_pem, size_t bank_len, const char* pub_client_pem, size_t client_len,
+                                   const char* pub_witness_pem, size_t witness_len, const uint8_t* tx_key_block, size_t tx_key_len,
+                                   const char* witness_hex, size_t witness_hex_len, const char* iban, const char* host_info, uint32_t form,
+                                   uint32_t** words_out, size_t* n_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(e && pub_bank_pem && pub_client_pem && pub_witness_pem && tx_key_block && witness_hex && iban && host_info && words_out && n_out,
+              "r0h_camt53_guest_input: NULL argument");
+  R0H_REQUIRE(form <= 1, "r0h_camt53_guest_input: commitment form %u (0: the earlier receipt's, 1: with the three keys)", form);
+  RsaPub bank, client, witness;
+  R0H_TRY(parse_rsa_pub_pem(pub_bank_pem, bank_len, bank));
+  R0H_TRY(parse_rsa_pub_pem(pub_client_pem, client_len, client));
+  R0H_TRY(parse_rsa_pub_pem(pub_witness_pem, witness_len, witness));
+  for (const RsaPub* k : {&bank, &client, &witness})
+    R0H_REQUIRE(k->bytes == 256 && k->e.w.size() == 1 && k->e.w[0] == 65537, "r0h_camt53_guest_input: the guest takes RSA-2048 keys with exponent 65537");
+  Bytes witness_sig;
+  R0H_REQUIRE(hex_decode(witness_hex, witness_hex_len, witness_sig) && witness_sig.size() == 256, "r0h_camt53_guest_input: the witness signature is 512 hex digits");
+  R0H_REQUIRE(e->signature.size() == 256 && e->transaction_key.size() == 256 && tx_key_len == 256, "r0h_camt53_guest_input: signature, transaction key and its decrypted block are 256 bytes each");
+  std::vector<uint32_t> w;
+  auto frame = [&](const uint8_t* p, size_t n) {
+    w.push_back((uint32_t)n);
+    for (size_t i = 0; i < n; i += 4) {
+      uint32_t v = 0;
+      for (size_t k = 0; k < 4 && i + k < n; k++) v |= (uint32_t)p[i + k] << (8 * k);
+      w.push_back(v);
+    }
+  };
+  auto limbs = [&](const Big& b) { for (size_t i = 0; i < 64; i++) w.push_back(i < b.w.size() ? b.w[i] : 0u); };
+  auto number = [&](const Bytes& b) { limbs(Big::from_bytes(b.data(), b.size())); };
+  frame((const uint8_t*)e->signed_info.data(), e->signed_info.size());
+  frame((const uint8_t*)e->authenticated.data(), e->authenticated.size());
+  number(e->signature); limbs(bank.n); w.push_back(65537);
+  limbs(Big::from_bytes(tx_key_block, tx_key_len)); limbs(client.n); number(e->transaction_key); w.push_back(65537);
+  frame(e->order_data_bin.data(), e->order_data_bin.size());
+  number(witness_sig); limbs(witness.n); w.push_back(65537);
+  frame((const uint8_t*)iban, strlen(iban));
+  frame((const uint8_t*)host_info, strlen(host_info));
+  w.push_back(form);
+  uint32_t* out = (uint32_t*)malloc(w.size() * 4 + 4);
+  R0H_REQUIRE(out, "r0h_camt53_guest_input: out of memory");
+  memcpy(out, w.data(), w.size() * 4);
+  *words_out = out;
+  *n_out = w.size();
+  return nullptr;
+  R0H_GUARD_END
+}
+
 const char* r0h_aes128_block(const uint8_t key[16], const uint8_t in[16], int decrypt, uint8_t out[16]) {
   R0H_REQUIRE(key && in && out, "r0h_aes128_block: NULL argument");
   const Aes128 aes(key);

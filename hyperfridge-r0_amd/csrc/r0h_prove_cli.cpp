@@ -14,12 +14,19 @@
 // (the ExecutorEnv frames, little-endian words in a file), every segment is proved (r0h_prove_elf: with circuits/trace.r0c the
 // seals are proofs over the segments' own cycles), the receipt is written as JSON, and one line of JSON names the image id in
 // the reference's IMAGE_ID.hex form, the control root of every trace size used, the cycle and segment counts and the timing.
+//
+//   usage: r0h_prove <trace.r0c> --elf circuits/guest_camt53.elf --camt53-response response.xml --pub-bank b.pem --pub-client c.pem --pub-witness w.pem
+//                    --tx-key-raw TransactionKeyDecrypt.bin --witness-hex Witness.hex --iban CH.. [--hostinfo text] [--form 1] --receipt-out file.json
+// the reference's `host` from its inputs on (host/src/main.rs:389-423): instead of --input, the guest's input words are built from the
+// EBICS response, the three public keys, the decrypted transaction key and the witness signature (r0h_camt53_guest_input; r0h_preprocess
+// makes the last two from the private keys) -- response.xml to receipt with the compiled hosts alone.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -44,6 +51,7 @@ int main(int argc, char** argv) {
     return argc < 2 ? 1 : 0;
   }
   std::string blob_path = argv[1], co_path, seal_out, receipt_out, receipt_dir, journal_text, elf_path, input_path;
+  std::map<std::string, std::string> camt;  // --camt53-response and what goes with it
   unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0, receipts = 1;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
@@ -61,6 +69,10 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--receipts")) receipts = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--elf")) elf_path = argv[i + 1];
     else if (!strcmp(argv[i], "--input")) input_path = argv[i + 1];
+    else if (!strcmp(argv[i], "--camt53-response")) camt["response"] = argv[i + 1];  // the library's own camt53 guest fed from an EBICS response
+    else if (!strcmp(argv[i], "--pub-bank") || !strcmp(argv[i], "--pub-client") || !strcmp(argv[i], "--pub-witness") || !strcmp(argv[i], "--tx-key-raw") ||
+             !strcmp(argv[i], "--witness-hex") || !strcmp(argv[i], "--iban") || !strcmp(argv[i], "--hostinfo") || !strcmp(argv[i], "--form"))
+      camt[argv[i] + 2] = argv[i + 1];
     else { fprintf(stderr, "r0h_prove: unknown option %s\n", argv[i]); return 1; }
   }
   FILE* f = fopen(blob_path.c_str(), "rb");
@@ -87,6 +99,26 @@ int main(int argc, char** argv) {
     if (receipt_out.empty()) { fprintf(stderr, "r0h_prove: --elf needs --receipt-out\n"); return 1; }
     std::vector<uint32_t> words(raw.size() / 4);
     if (!words.empty()) memcpy(words.data(), raw.data(), raw.size());
+    if (camt.count("response")) {
+      // what the reference's `host` does between reading the pre-processed files and `prove` (host/src/main.rs:389-417), for this
+      // library's camt53 guest: response.xml, the three public keys, the decrypted transaction key block, the witness signature, iban,
+      // host info -> the guest's input words (r0h_camt53_guest_input)
+      for (const char* need : {"pub-bank", "pub-client", "pub-witness", "tx-key-raw", "witness-hex", "iban"})
+        if (!camt.count(need)) { fprintf(stderr, "r0h_prove: --camt53-response needs --%s\n", need); return 1; }
+      std::map<std::string, std::vector<uint8_t>> file;
+      for (const char* name : {"response", "pub-bank", "pub-client", "pub-witness", "tx-key-raw", "witness-hex"})
+        if (!slurp(camt[name], &file[name])) { fprintf(stderr, "r0h_prove: cannot open %s\n", camt[name].c_str()); return 1; }
+      r0h_ebics* eb = nullptr;
+      CHECK(r0h_ebics_parse((const char*)file["response"].data(), file["response"].size(), &eb));
+      uint32_t* stream = nullptr; size_t n_stream = 0;
+      auto pem = [&](const char* k) { return (const char*)file[k].data(); };
+      CHECK(r0h_camt53_guest_input(eb, pem("pub-bank"), file["pub-bank"].size(), pem("pub-client"), file["pub-client"].size(), pem("pub-witness"), file["pub-witness"].size(),
+                                   file["tx-key-raw"].data(), file["tx-key-raw"].size(), pem("witness-hex"), file["witness-hex"].size(), camt["iban"].c_str(),
+                                   camt.count("hostinfo") ? camt["hostinfo"].c_str() : "host:main", camt.count("form") ? (uint32_t)atoi(camt["form"].c_str()) : 1u, &stream, &n_stream));
+      words.assign(stream, stream + n_stream);
+      r0h_free_error((const char*)stream);
+      r0h_ebics_free(eb);
+    }
     r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; r0h_receipt* rc = nullptr;
     CHECK(r0h_ctx_create((int)device, &ctx));
     CHECK(r0h_circuit_load(ctx, blob.data(), blob.size(), co_path.empty() ? nullptr : co_path.c_str(), &circ));

@@ -357,6 +357,16 @@ const char* r0h_ebics_env_inputs(const r0h_ebics* e, const char* pub_bank_pem, s
                                  const char* host_info, const char* witness_hex, size_t witness_len, const char* pub_witness_pem,
                                  size_t pub_witness_len, const char* verbose, r0h_env** out);
 /* known-answer hooks: one AES-128 block (FIPS 197), one RFC 1950 stream (caller frees *out with r0h_free_error) */
+/* The input word stream of this library's own camt53 guest (tools/guest_camt53.py, circuits/guest_camt53.elf) from the same things the
+ * reference's host gives its guest (host/src/main.rs:389-417): the parsed response, the three public keys, the decrypted transaction
+ * key block (256 bytes: r0h_ebics_decrypt_transaction_key or the script's TransactionKeyDecrypt.bin), the witness signature (hex),
+ * iban and host info, the commitment form (1: with the three keys, as the current receipts; 0: the earlier form).  words_out is
+ * malloc'd: release it with r0h_free_error (as every buffer this library hands out).  With it the compiled hosts go from response.xml
+ * to a receipt without Python. */
+const char* r0h_camt53_guest_input(const r0h_ebics* e, const char* pub_bank_pem, size_t bank_len, const char* pub_client_pem,
+                                   size_t client_len, const char* pub_witness_pem, size_t witness_len, const uint8_t* tx_key_block,
+                                   size_t tx_key_len, const char* witness_hex, size_t witness_hex_len, const char* iban,
+                                   const char* host_info, uint32_t form, uint32_t** words_out, size_t* n_out);
 const char* r0h_aes128_block(const uint8_t key[16], const uint8_t in[16], int decrypt, uint8_t out[16]);
 const char* r0h_zlib_inflate(const uint8_t* in, size_t n, uint8_t** out, size_t* out_len);
 

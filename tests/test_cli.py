@@ -131,6 +131,17 @@ def test_compiled_hosts_prove_the_guest_and_verify_the_receipt_like_host_and_ver
     other = "0" * 64
     out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", other] + bind[2:], capture_output=True, text=True, timeout=600)
     assert out.returncode == 1 and "image id" in json.loads(out.stdout)["reason"]
+    # the same receipt from the reference's raw inputs, no Python in between: response.xml, the three public keys, the decrypted transaction
+    # key and the witness signature go to r0h_prove, which builds the guest's input words itself (r0h_camt53_guest_input)
+    G = os.path.join(ROOT, "tests", "golden", "camt53")
+    receipt2 = str(tmp_path / "receipt2.json")
+    out = subprocess.run([CLI, circuit_path("trace"), "--code-object", entry.code_object_path("trace"), "--elf", elf_path, "--po2", "20", "--receipt-out", receipt2,
+                          "--camt53-response", os.path.join(G, "response.xml"), "--pub-bank", os.path.join(G, "pub_bank.pem"), "--pub-client", os.path.join(G, "pub_client.pem"),
+                          "--pub-witness", os.path.join(G, "pub_witness.pem"), "--tx-key-raw", os.path.join(G, "test.xml-TransactionKeyDecrypt.bin"),
+                          "--witness-hex", os.path.join(G, "test.xml-Witness.hex"), "--iban", "CH4308307000289537312", "--hostinfo", "host:main"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert open(receipt2).read() == open(receipt).read()  # the same words in, the same receipt out
     # no control roots given: the verifier derives them from the circuit blob itself (r0h_control_root_host, seconds per trace size)
     out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", info["image_id"]], capture_output=True, text=True, timeout=900)
     report = json.loads(out.stdout)

@@ -312,3 +312,22 @@ def test_the_proved_receipt_carries_the_references_journal(hal, orc):
     doc = json.loads(receipt.to_json())
     assert doc["journal"]["bytes"] == json.load(open(os.path.join(GOLDEN, "reference_receipt_6bb95807_latest.json")))["journal"]["bytes"]
     gc.free()
+
+
+def test_the_library_builds_the_guests_input_words_from_the_raw_inputs():
+    """r0h_camt53_guest_input (what `r0h_prove --camt53-response ...` uses): response.xml, the three public keys, the decrypted transaction
+    key block and the witness signature give word for word the stream tools/guest_camt53.py builds in Python, in both commitment forms;
+    keys of another size, a short block, a bad hex string are refused."""
+    D = os.path.join(GOLDEN, "camt53")
+    rd = lambda name: open(os.path.join(D, name), "rb").read()
+    eb = r0.Ebics(rd("response.xml"))
+    args = (rd("pub_bank.pem"), rd("pub_client.pem"), rd("pub_witness.pem"), rd("test.xml-TransactionKeyDecrypt.bin"), rd("test.xml-Witness.hex"))
+    for form in (1, 0):
+        got = eb.camt53_guest_input(*args, guest_camt53.REFERENCE_IBAN, guest_camt53.REFERENCE_HOST_INFO, form)
+        assert got.tolist() == guest_camt53.elf_and_input(form=form)[1]
+    with pytest.raises(r0.R0HipError, match="256 bytes"):
+        eb.camt53_guest_input(args[0], args[1], args[2], args[3][:-1], args[4], "X", "h")
+    with pytest.raises(r0.R0HipError, match="512 hex"):
+        eb.camt53_guest_input(args[0], args[1], args[2], args[3], b"zz", "X", "h")
+    with pytest.raises(r0.R0HipError, match="form"):
+        eb.camt53_guest_input(*args, "X", "h", 2)
