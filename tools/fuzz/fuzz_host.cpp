@@ -125,6 +125,13 @@ extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
       uint8_t raw[512], key[16]; size_t rn = 0;
       drop(r0h_ebics_decrypt_transaction_key(e, (const char*)d, n, raw, sizeof raw, &rn, key, &ok));
       drop(r0h_ebics_check_transaction_key(e, (const char*)fx().pub_client.data(), fx().pub_client.size(), d, n, key, &ok));
+      {  // the guest's input words with the fuzzed bytes in each role in turn: a key, the decrypted block, the witness signature
+        uint32_t* words = nullptr; size_t nw = 0;
+        const char *wk = (const char*)fx().pub_witness.data(), *ck = (const char*)fx().pub_client.data();
+        const size_t wn = fx().pub_witness.size(), cn = fx().pub_client.size();
+        if (good(r0h_camt53_guest_input(e, (const char*)d, n, ck, cn, wk, wn, raw, 256, (const char*)d, n, "CH00", "h", 1, &words, &nw))) r0h_free_error((const char*)words);
+        if (good(r0h_camt53_guest_input(e, ck, cn, ck, cn, wk, wn, d, n, (const char*)d, n, "CH00", "h", 0, &words, &nw))) r0h_free_error((const char*)words);
+      }
       r0h_ebics_free(e);
       break;
     }
