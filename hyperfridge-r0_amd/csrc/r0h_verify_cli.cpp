@@ -3,6 +3,7 @@
 // Needs no GPU.  Exit status: 0 accepted, 1 rejected (reason on stdout), 2 unusable input.
 //   usage: r0h_verify <circuit.r0c> <seal.bin>
 //          r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --control-root <po2>:<w0,..,w7> [--control-root ..]
+//          r0h_verify --image-id-of <guest.elf>          prints the image id in the reference's IMAGE_ID.hex form (`host show-image-id`)
 //          r0h_verify --receipt <receipt.json> <circuit.r0c> --elf <guest.elf> --control-root ...   (the image id computed from the ELF:
 //                     r0h_compute_image_id, what risc0_build embeds as HYPERFRIDGE_ID)
 //                     `receipt.verify(image_id)` for a composite receipt (r0h_receipt_verify): seals against the control roots, claims
@@ -130,6 +131,21 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
 }
 
 int main(int argc, char** argv) {
+  if (argc == 3 && !strcmp(argv[1], "--image-id-of")) {  // `host show-image-id` (host/src/main.rs): the id a verifier holds a receipt against
+    FILE* e = fopen(argv[2], "rb");
+    if (!e) { fprintf(stderr, "r0h_verify: cannot open %s\n", argv[2]); return 2; }
+    std::vector<uint8_t> elf;
+    char buf[65536];
+    for (size_t got; (got = fread(buf, 1, sizeof buf, e)) > 0;) elf.insert(elf.end(), buf, buf + got);
+    fclose(e);
+    uint8_t id[32];
+    char hex[65];
+    const char* err = r0h_compute_image_id(elf.data(), elf.size(), id);
+    if (!err) err = r0h_image_id_to_hex(id, hex);
+    if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); return 2; }
+    printf("%s\n", hex);
+    return 0;
+  }
   if (argc >= 4 && !strcmp(argv[1], "--receipt")) {
     const char* image_hex = nullptr;
     const char* elf_path = nullptr;

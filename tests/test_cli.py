@@ -86,6 +86,15 @@ def test_prove_to_receipt_json_then_verify_like_the_reference_verifier(tmp_path)
     assert out.returncode == 1 and json.loads(out.stdout)["seals_valid"] is True and json.loads(out.stdout)["journal_bound"] is False
 
 
+def test_the_verifier_prints_the_image_id_of_an_elf():
+    """`host show-image-id` (host/src/main.rs:178): the id of the guest ELF in the reference's IMAGE_ID.hex form, without running anything"""
+    import hyperfridge_r0_amd as r0
+    elf_path = os.path.join(ROOT, "circuits", "guest_camt53.elf")
+    out = subprocess.run([VERIFY, "--image-id-of", elf_path], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip() == r0.image_id_to_hex(r0.compute_image_id(open(elf_path, "rb").read()))
+    assert subprocess.run([VERIFY, "--image-id-of", os.path.join(ROOT, "README.md")], capture_output=True, text=True).returncode == 2
+
+
 @pytest.mark.gpu
 def test_batch_of_receipts_on_a_work_queue(tmp_path):
     """BASELINE.json configs[3] in small: receipts x segments units, lanes take the next unit when free; every seal kept for a
