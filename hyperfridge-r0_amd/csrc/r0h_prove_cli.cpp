@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
   }
   std::string blob_path = argv[1], co_path, seal_out, receipt_out, receipt_dir, journal_text, elf_path, input_path;
   std::map<std::string, std::string> camt;  // --camt53-response and what goes with it
+  std::string receipt_prefix;               // --receipt-prefix P: the reference's file name, P-Receipt-<image id>-latest.json (host/src/main.rs:312-316)
   unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0, receipts = 1;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
@@ -69,6 +70,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--receipts")) receipts = (unsigned)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--elf")) elf_path = argv[i + 1];
     else if (!strcmp(argv[i], "--input")) input_path = argv[i + 1];
+    else if (!strcmp(argv[i], "--receipt-prefix")) receipt_prefix = argv[i + 1];
     else if (!strcmp(argv[i], "--camt53-response")) camt["response"] = argv[i + 1];  // the library's own camt53 guest fed from an EBICS response
     else if (!strcmp(argv[i], "--pub-bank") || !strcmp(argv[i], "--pub-client") || !strcmp(argv[i], "--pub-witness") || !strcmp(argv[i], "--tx-key-raw") ||
              !strcmp(argv[i], "--witness-hex") || !strcmp(argv[i], "--iban") || !strcmp(argv[i], "--hostinfo") || !strcmp(argv[i], "--form"))
@@ -96,7 +98,7 @@ int main(int argc, char** argv) {
     if (!slurp(elf_path, &elf)) { fprintf(stderr, "r0h_prove: cannot open %s\n", elf_path.c_str()); return 1; }
     if (!input_path.empty() && !slurp(input_path, &raw)) { fprintf(stderr, "r0h_prove: cannot open %s\n", input_path.c_str()); return 1; }
     if (raw.size() % 4) { fprintf(stderr, "r0h_prove: --input is a stream of 32-bit words\n"); return 1; }
-    if (receipt_out.empty()) { fprintf(stderr, "r0h_prove: --elf needs --receipt-out\n"); return 1; }
+    if (receipt_out.empty() && receipt_prefix.empty()) { fprintf(stderr, "r0h_prove: --elf needs --receipt-out or --receipt-prefix\n"); return 1; }
     std::vector<uint32_t> words(raw.size() / 4);
     if (!words.empty()) memcpy(words.data(), raw.data(), raw.size());
     if (camt.count("response")) {
@@ -129,6 +131,11 @@ int main(int argc, char** argv) {
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     char* text = nullptr;
     CHECK(r0h_receipt_to_json(rc, &text));
+    if (receipt_out.empty()) {  // where the reference's verifier looks: <camt53 file>-Receipt-<image id>-latest.json
+      char id_hex[65];
+      CHECK(r0h_image_id_to_hex(image_id, id_hex));
+      receipt_out = receipt_prefix + "-Receipt-" + id_hex + "-latest.json";
+    }
     FILE* o = fopen(receipt_out.c_str(), "wb");
     if (!o || fwrite(text, 1, strlen(text), o) != strlen(text)) { fprintf(stderr, "r0h_prove: cannot write %s\n", receipt_out.c_str()); return 1; }
     fclose(o);
@@ -150,7 +157,7 @@ int main(int argc, char** argv) {
     CHECK(r0h_image_id_to_hex(image_id, hex));
     r0h_session_stats st;
     CHECK(r0h_last_session_stats(ctx, &st));
-    printf("{\"image_id\": \"%s\", \"segments\": %zu, \"cycles\": %llu, \"seconds\": %.4f, \"segments_per_s\": %.3f, \"executor_s\": %.4f, \"control_roots\": [", hex, n_seg,
+    printf("{\"receipt\": \"%s\", \"image_id\": \"%s\", \"segments\": %zu, \"cycles\": %llu, \"seconds\": %.4f, \"segments_per_s\": %.3f, \"executor_s\": %.4f, \"control_roots\": [", receipt_out.c_str(), hex, n_seg,
            (unsigned long long)cycles, secs, n_seg / secs, st.executor_s);
     for (size_t k = 0; k < sizes.size(); k++) {
       const size_t n = (size_t)1 << sizes[k];

@@ -151,6 +151,12 @@ def test_compiled_hosts_prove_the_guest_and_verify_the_receipt_like_host_and_ver
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert open(receipt2).read() == open(receipt).read()  # the same words in, the same receipt out
+    # ... written where the reference's verifier looks for it: <camt53 file>-Receipt-<image id>-latest.json (host/src/main.rs:312-316)
+    out = subprocess.run([CLI, circuit_path("trace"), "--code-object", entry.code_object_path("trace"), "--elf", elf_path, "--input", str(words), "--po2", "20",
+                          "--receipt-prefix", str(tmp_path / "test.xml")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    named = str(tmp_path / ("test.xml-Receipt-%s-latest.json" % info["image_id"]))
+    assert json.loads(out.stdout.strip().splitlines()[-1])["receipt"] == named and open(named).read() == open(receipt).read()
     # no control roots given: the verifier derives them from the circuit blob itself (r0h_control_root_host, seconds per trace size)
     out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", info["image_id"]], capture_output=True, text=True, timeout=900)
     report = json.loads(out.stdout)
