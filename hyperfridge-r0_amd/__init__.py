@@ -145,7 +145,21 @@ _SIGNATURES = {
     "r0h_vm_run_segment": [_vp, _vp, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_u32)],
     "r0h_vm_release_trace": [_vp, _sz],
     "r0h_vm_boundary": [_vp, _sz, _pp, _c.POINTER(_sz)],
-    "r0h_trace_witgen": [_vp, _vp, _sz, _vp, _sz, _u32, _vp, _vp],
+    "r0h_trace_witgen": [_vp, _vp, _sz, _vp, _sz, _u32, _vp, _vp, _vp],
+    "r0h_logup_multiplicities": [_vp, _vp, _u32, _vp, _vp],
+    "r0h_logup_multiplicities_host": [_vp, _sz, _u32, _vp, _vp],
+    "r0h_logup_totals": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "r0h_accum_public": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp],
+    "r0h_prefix_sums": [_vp, _vp, _u32],
+    "r0h_proof_data_root": [_vp, _vp],
+    "r0h_proof_late": [_vp, _vp, _vp],
+    "r0h_proof_globals": [_vp, _vp],
+    "r0h_code_commit_columns": [_vp, _pp],
+    "r0h_verify_seal_roots": [_vp, _sz, _vp, _sz, _vp, _c.POINTER(_c.c_int), _c.POINTER(_u32), _vp],
+    "r0h_session_begin": [_vp, _vp, _vp, _sz, _vp, _sz, _u32, _u64, _u32, _u32, _pp],
+    "r0h_session_records": [_vp, _vp, _vp, _sz, _c.POINTER(_sz)],
+    "r0h_session_finish": [_vp, _vp, _sz, _pp, _vp, _c.POINTER(_u64)],
+    "r0h_session_free": [_vp],
     "r0h_last_session_stats": [_vp, _vp],
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
@@ -176,6 +190,7 @@ _PLAIN = {
     "r0h_receipt_n_segments": ([_vp], _sz),
     "r0h_ebics_n_documents": ([_vp], _sz),
     "r0h_vm_n_segments": ([_vp], _sz),
+    "r0h_session_n_segments": ([_vp], _sz),
     "r0h_vm_cycles": ([_vp], _u64),
     "r0h_vm_reg": ([_vp, _u32], _u32),
     "r0h_vm_pc": ([_vp], _u32),
@@ -576,9 +591,15 @@ class ReceiptClaim(ctypes.Structure):
         return claim_globals(self.digest())
 
 
-TRACE_COLUMNS = 288  # R0H_TRACE_COLUMNS
-TRACE_GLOBALS = 15   # R0H_TRACE_GLOBALS: claim words 0..7, first pc, pc after the last cycle, cycles, end kind (0 cut / 1 HALT / 2 PAUSE), kind != 0, exit code halves
-TRACE_MAX_PO2 = 21
+TRACE_COLUMNS = 138  # R0H_TRACE_COLUMNS
+# R0H_TRACE_GLOBALS: claim words 0..7, first pc, pc after the last cycle, cycles, end kind (0 cut / 1 HALT / 2 PAUSE), kind != 0, exit code halves, segment
+# number, closing, number x (1 - closing), first / last boundary address; LATE (the last 20): the session challenge (16), the segment's sum under it (4)
+TRACE_GLOBALS = 40
+TRACE_LATE_GLOBALS = 20
+TRACE_GAMMA, TRACE_SUM = 20, 36
+SESSION_RECORD_WORDS = 28
+TRACE_MIN_PO2, TRACE_MAX_PO2 = 16, 21
+JOURNAL_BASE = 0x20000000  # R0H_JOURNAL_BASE: journal word i is the word at JOURNAL_BASE + 4 i when COMMIT names it
 REG_BASE = 0x10000000  # R0H_REG_BASE: address of x[i] in the trace circuit's one address space (memory: word index)
 MEM_NONE, MEM_READ, MEM_WRITE = 0, 1, 2  # r0h_preflight_row.mem_kind
 
@@ -600,7 +621,7 @@ class VmLimits(ctypes.Structure):
 
 class VmSegment(ctypes.Structure):
     _fields_ = [("index", _u32), ("exit_system", _u32), ("exit_user", _u32), ("pages_in", _u32), ("pages_out", _u32), ("boundary_rows", _u32),
-                ("user_cycles", _u64), ("paging_cycles", _u64), ("pre", SystemState), ("post", SystemState)]
+                ("closing", _u32), ("reserved", _u32), ("user_cycles", _u64), ("paging_cycles", _u64), ("pre", SystemState), ("post", SystemState)]
 
 
 class PreflightRow(ctypes.Structure):
@@ -613,7 +634,11 @@ class SessionStats(ctypes.Structure):
 
 
 class PreflightBound(ctypes.Structure):
-    _fields_ = [("addr", _u32), ("first_value", _u32), ("last_value", _u32), ("last_ts", _u32)]
+    _fields_ = [("addr", _u32), ("first_value", _u32), ("last_value", _u32), ("last_ts", _u32), ("prev_seg", _u32), ("init_value", _u32), ("flags", _u32), ("reserved", _u32)]
+
+
+class TraceSegment(ctypes.Structure):
+    _fields_ = [("number", _u32), ("closing", _u32), ("idle_pc", _u32), ("reserved", _u32)]
 
 
 class Vm:
@@ -683,7 +708,7 @@ class Vm:
             out.append(s)
         return out
 
-    def trace_witness(self, i, po2, claim_globals=None):
+    def trace_witness(self, i, po2, claim_globals=None, multiplicities=True):
         """DATA group of the trace circuit (TRACE_COLUMNS x 2^po2, Montgomery words, column-major) from segment i's preflight and
         boundary rows on the HOST (r0h_vm_trace_witness: the reference the device kernel is compared with), and its TRACE_GLOBALS
         public inputs: claim_globals (8 words, zeros when None), first pc, pc after the last cycle, cycles, how it ends, exit code."""
@@ -692,6 +717,9 @@ class Vm:
         _check(lib().r0h_vm_trace_witness(self.handle, i, po2, data.ctypes.data_as(_vp), glob.ctypes.data_as(_vp)))
         if claim_globals is not None:
             glob[:8] = claim_globals
+        if multiplicities:  # the lookup tables' multiplicity columns, from the circuit's own description of its lookups
+            blob = trace_blob()
+            _check(lib().r0h_logup_multiplicities_host(blob.ctypes.data_as(_vp), blob.size, po2, data.ctypes.data_as(_vp), glob.ctypes.data_as(_vp)))
         return data, glob
 
     def _preflight_raw(self, i):
@@ -712,10 +740,10 @@ class Vm:
         return [rows[k] for k in range(m)]
 
     def preflight_arrays(self, i):
-        """The compact rows of segment i as numpy arrays (copies): [n, 18] uint32 cycles, [m, 4] uint32 boundary rows."""
+        """The compact rows of segment i as numpy arrays (copies): [n, 18] uint32 cycles, [m, 8] uint32 boundary rows."""
         p, n, q, m = self._preflight_raw(i)
         rows = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(_u32)), shape=(n, 18)).copy() if n else np.zeros((0, 18), np.uint32)
-        bounds = np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(_u32)), shape=(m, 4)).copy() if m else np.zeros((0, 4), np.uint32)
+        bounds = np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(_u32)), shape=(m, 8)).copy() if m else np.zeros((0, 8), np.uint32)
         return rows, bounds
 
     @property
@@ -742,6 +770,17 @@ class Vm:
             self.close()
         except Exception:
             pass
+
+
+_trace_blob = None
+
+
+def trace_blob():
+    """circuits/trace.r0c (built by __graft_entry__.build())"""
+    global _trace_blob
+    if _trace_blob is None:
+        _trace_blob = np.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "circuits", "trace.r0c"), dtype=np.uint32)
+    return _trace_blob
 
 
 def control_root_host(blob, po2, round_constants=None, diag_m1=None):

@@ -76,21 +76,83 @@ const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
         R0H_REQUIRE(len == 4, "circuit blob: INFO must be 4 words");
         memcpy(c->info, p, 16);
         break;
+      case R0H_SEC_LATE:
+        R0H_REQUIRE(len == 1, "circuit blob: LATE must be 1 word");
+        c->n_late = p[0];
+        break;
+      case R0H_SEC_LOGUP: {
+        size_t at = 0;
+        auto word = [&](uint32_t* out) -> bool { if (at >= len) return false; *out = p[at++]; return true; };
+        auto form = [&](Lf* lf) -> bool {
+          uint32_t n;
+          if (!word(&n) || n > 64) return false;
+          lf->terms.resize(n);
+          for (LfTerm& t : lf->terms)
+            if (!word(&t.coef) || !word(&t.global) || !word(&t.col) || t.coef >= P) return false;
+          return true;
+        };
+        uint32_t n_acc = 0, n_tab = 0;
+        R0H_REQUIRE(word(&n_acc) && word(&n_tab) && n_acc >= 1 && n_acc <= 64 && n_tab <= 8, "circuit blob: LOGUP header");
+        c->logup.tables.resize(n_tab);
+        for (LogupTable& t : c->logup.tables) R0H_REQUIRE(word(&t.data_col) && word(&t.kind) && (t.kind == R0H_TABLE_R16 || t.kind == R0H_TABLE_AND), "circuit blob: LOGUP table");
+        c->logup.accs.resize(n_acc);
+        bool chain_over = false;
+        for (LogupAcc& a : c->logup.accs) {
+          uint32_t nf = 0;
+          R0H_REQUIRE(word(&nf) && word(&a.final_global) && nf == 4, "circuit blob: a LOGUP accumulator has four fractions");
+          if (a.final_global == 0xffffffffu) { R0H_REQUIRE(!chain_over, "circuit blob: LOGUP chain links come first"); c->logup.n_chain++; }
+          else chain_over = true;
+          a.fr.resize(nf);
+          for (LogupFraction& f : a.fr) {
+            uint32_t np = 0;
+            R0H_REQUIRE(word(&f.table) && f.table <= 2 && form(&f.num) && word(&np) && np >= 1 && np <= 8, "circuit blob: LOGUP fraction");
+            f.parts.resize(np);
+            for (LogupPart& q : f.parts) R0H_REQUIRE(word(&q.ch_kind) && q.ch_kind <= 2 && word(&q.ch_idx) && form(&q.lf), "circuit blob: LOGUP part");
+            if (f.table) R0H_REQUIRE(np == 2 && f.parts[1].ch_kind == 0, "circuit blob: a lookup's value is its second part");
+          }
+        }
+        R0H_REQUIRE(at == len, "circuit blob: LOGUP length mismatch");
+        break;
+      }
       default: break;
     }
     pos += 2 + len;
   }
   for (int t = 1; t <= 4; t++) R0H_REQUIRE(seen[t], "circuit blob: section %d missing", t);
   // WITGEN + ACCUM (the synthetic column program) are optional: a circuit imported from risc0 brings its own witness
-  const bool any_accum = seen[R0H_SEC_ACCUM] || seen[R0H_SEC_ACCUM_FP];
+  const bool any_accum = seen[R0H_SEC_ACCUM] || seen[R0H_SEC_ACCUM_FP] || seen[R0H_SEC_LOGUP];
   c->has_column_program = seen[R0H_SEC_WITGEN] && any_accum;
-  R0H_REQUIRE(seen[R0H_SEC_WITGEN] == any_accum && !(seen[R0H_SEC_ACCUM] && seen[R0H_SEC_ACCUM_FP]), "circuit blob: WITGEN comes with exactly one of ACCUM / ACCUM_FP");
+  R0H_REQUIRE(seen[R0H_SEC_WITGEN] == any_accum && (int)seen[R0H_SEC_ACCUM] + (int)seen[R0H_SEC_ACCUM_FP] + (int)seen[R0H_SEC_LOGUP] <= 1,
+              "circuit blob: WITGEN comes with exactly one of ACCUM / ACCUM_FP / LOGUP");
+  R0H_REQUIRE(c->n_late <= c->n_global, "circuit blob: more late public inputs than public inputs");
   if (c->has_column_program) {
     R0H_REQUIRE(c->code_cols.size() == c->group_size[R0H_GROUP_CODE] && c->data_cols.size() == c->group_size[R0H_GROUP_DATA],
                 "circuit blob: group sizes disagree with the column programs");
     if (seen[R0H_SEC_ACCUM])
       R0H_REQUIRE(4 * c->acc_cols.size() == c->group_size[R0H_GROUP_ACCUM] && c->n_mix == 8 * c->acc_cols.size(), "circuit blob: group sizes disagree with the accumulators");
-    else
+    else if (seen[R0H_SEC_LOGUP]) {
+      R0H_REQUIRE(4 * c->logup.accs.size() == c->group_size[R0H_GROUP_ACCUM] && c->logup.n_chain >= 1, "circuit blob: group sizes disagree with the log-derivative accumulators");
+      auto form_ok = [&](const Lf& lf) {
+        for (const LfTerm& t : lf.terms) {
+          if (t.global > c->n_global) return false;
+          if (t.col) {
+            const uint32_t ref = t.col - 1, g = ref >> 28, col = ref & 0xfffffu;
+            if ((g != R0H_GROUP_CODE && g != R0H_GROUP_DATA) || col >= c->group_size[g]) return false;
+          }
+        }
+        return true;
+      };
+      for (const LogupTable& t : c->logup.tables) R0H_REQUIRE(t.data_col < c->group_size[R0H_GROUP_DATA], "circuit blob: LOGUP multiplicity column out of range");
+      for (const LogupAcc& a : c->logup.accs) {
+        R0H_REQUIRE(a.final_global == 0xffffffffu || (uint64_t)a.final_global + 4 <= c->n_global, "circuit blob: LOGUP total outside the public inputs");
+        for (const LogupFraction& f : a.fr) {
+          R0H_REQUIRE(form_ok(f.num), "circuit blob: LOGUP numerator refers outside the circuit");
+          for (const LogupPart& q : f.parts)
+            R0H_REQUIRE(form_ok(q.lf) && (q.ch_kind == 0 || (q.ch_kind == 1 && 4 * (uint64_t)q.ch_idx + 4 <= c->n_mix) || (q.ch_kind == 2 && (uint64_t)q.ch_idx + 4 <= c->n_global)),
+                        "circuit blob: LOGUP part refers outside the circuit");
+        }
+      }
+    } else
       R0H_REQUIRE(4 * c->acc_fp.size() == c->group_size[R0H_GROUP_ACCUM] && c->n_mix == 16, "circuit blob: group sizes disagree with the fingerprint accumulators");
   }
   // taps: sorted, in range, every column owns back 0
@@ -542,6 +604,8 @@ __global__ void witgen_fixed_kernel(uint32_t* __restrict__ buf, const uint32_t* 
   else if (kind == 1) v = r == n - 1 ? ONE : 0u;
   else if (kind == 2) v = enc(r);
   else if (kind == 3) v = synth_word(seed_mixed, stream, r);
+  else if (kind == 4) v = r < 65536u ? enc(r) : 0u;                                                     // the 16-bit range table
+  else if (kind == 5) v = enc(R0H_TAG_AND + (r < 65536u ? r + 65536u * ((r & 255u) & (r >> 8)) : 0u));  // the byte-AND table
   else return;  // derived column: filled later
   buf[((size_t)col << po2) + r] = v;
 }
@@ -720,6 +784,7 @@ const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0
   R0H_REQUIRE(((size_t)c->data_cols.size() << po2) * 4 <= data->bytes && ((size_t)c->group_size[R0H_GROUP_ACCUM] << po2) * 4 <= accum->bytes,
               "r0h_accum: buffers too small for 2^%u rows", po2);
   for (uint32_t i = 0; i < c->n_mix; i++) R0H_REQUIRE(mix[i] < P, "r0h_accum: mix[%u] not canonical", i);
+  R0H_REQUIRE(c->logup.accs.empty(), "r0h_accum: this circuit accumulates a log-derivative argument that reads public inputs: use r0h_accum_public");
   r0h_buf* term = nullptr;
   R0H_TRY(buf_alloc_pooled(ctx, (size_t)n * 16, &term));
   for (uint32_t j = 0; j < c->acc_fp.size(); j++) {
@@ -747,6 +812,12 @@ const char* r0h_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0
   R0H_REQUIRE(e == hipSuccess, "r0h_accum: launch failed: %s", hipGetErrorString(e));
   return nullptr;
   R0H_GUARD_END
+}
+
+const char* r0h_accum_public(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data, const uint32_t* global, const uint32_t* mix, r0h_buf* accum) {
+  R0H_REQUIRE(ctx && c, "r0h_accum_public: NULL argument");
+  if (c->logup.accs.empty()) return r0h_accum(ctx, c, po2, code, data, mix, accum);
+  return logup_accum(ctx, c, po2, code, data, global, mix, accum);
 }
 
 const char* r0h_eval_check(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* eval_accum, const r0h_buf* eval_code,

@@ -12,6 +12,18 @@ struct DataCol { uint32_t kind, a, b, c, e; };
 struct AccCol { uint32_t first, a, b; };
 struct AccFp { uint32_t n_f; uint32_t col[3][4]; };  // running product of up to three tuple fingerprints (R0H_SEC_ACCUM_FP)
 struct Term { uint32_t pow, v; std::vector<uint32_t> conds; };
+// the log-derivative argument (R0H_SEC_LOGUP): fractions numerator / (sum of challenge x linear form), four to an accumulator
+struct LfTerm { uint32_t coef, global, col; };  // canonical coefficient; public input + 1 or 0; column ref + 1 or 0 (the constant one)
+struct Lf { std::vector<LfTerm> terms; };
+struct LogupPart { uint32_t ch_kind, ch_idx; Lf lf; };
+struct LogupFraction { uint32_t table; Lf num; std::vector<LogupPart> parts; };
+struct LogupAcc { uint32_t final_global; std::vector<LogupFraction> fr; };
+struct LogupTable { uint32_t data_col, kind; };
+struct Logup {
+  std::vector<LogupTable> tables;
+  std::vector<LogupAcc> accs;
+  uint32_t n_chain = 0;  // the first n_chain accumulators are links of the chain
+};
 
 struct Plan {                      // how the constraint program is cut into kernels
   std::vector<Term> terms;         // flattened, in chain order
@@ -37,6 +49,8 @@ struct r0h_circuit {
   std::vector<r0h::DataCol> data_cols;
   std::vector<r0h::AccCol> acc_cols;
   std::vector<r0h::AccFp> acc_fp;
+  r0h::Logup logup;
+  uint32_t n_late = 0;  // the last n_late public inputs enter the transcript after the DATA commitment (R0H_SEC_LATE)
   bool has_column_program = false;  // WITGEN + ACCUM present (synthetic circuits); imported circuits bring their own witness
   std::vector<uint32_t> blob;
   uint8_t info[16] = {'R', '0', 'H', 'I', 'P', '_', 'S', 'Y', 'N', 'T', 'H', ':', 'v', '1', '_', '_'};  // circuit ProtocolInfo tag
@@ -48,4 +62,6 @@ struct r0h_circuit {
 namespace r0h {
 // fills the host tables of `c` from a blob (no device work); validates every index the sequencer and the verifier follow
 const char* parse_blob(r0h_circuit* c, const uint32_t* blob, size_t n_words);
+// the log-derivative accumulation on the device (logup.hip): multiplicities into DATA, the ACCUM group, totals of the public accumulators
+const char* logup_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data, const uint32_t* global, const uint32_t* mix, r0h_buf* accum);
 }  // namespace r0h

@@ -133,6 +133,28 @@ void claim_globals(const uint8_t digest[32], uint32_t out[8]) {
   p2_hash_elems_host(*k, halves, 16, out);
 }
 
+// The challenge all segments of a trace-circuit session share (late public inputs 20..35 of every seal): alpha_g and gamma, gamma^2,
+// gamma^3, drawn from the Poseidon2 digest of a tag and every segment's record -- its early public inputs and the root of its DATA
+// commitment -- in index order.  Every tuple of the session sum is committed before the challenge exists.
+void session_challenge(const uint32_t* records, size_t n_records, uint32_t out[16]) {
+  static const char tag[] = "R0HIP_SESSION:v1";
+  std::vector<uint32_t> elems;
+  elems.reserve(16 + n_records * R0H_SESSION_RECORD_WORDS);
+  for (int i = 0; i < 16; i++) elems.push_back(enc((uint8_t)tag[i]));
+  elems.insert(elems.end(), records, records + n_records * R0H_SESSION_RECORD_WORDS);
+  std::unique_ptr<P2Consts> k(new P2Consts);
+  p2_default_host(*k);
+  uint32_t cells[P2_CELLS] = {0};
+  p2_hash_elems_host(*k, elems.data(), elems.size(), cells);
+  p2_mix_host(*k, cells);
+  Fp4 alpha{{cells[0], cells[1], cells[2], cells[3]}}, g{{cells[4], cells[5], cells[6], cells[7]}};
+  const Fp4 g2 = g * g, g3 = g2 * g;
+  memcpy(out, alpha.e, 16);
+  memcpy(out + 4, g.e, 16);
+  memcpy(out + 8, g2.e, 16);
+  memcpy(out + 12, g3.e, 16);
+}
+
 }  // namespace r0h
 
 using namespace r0h;

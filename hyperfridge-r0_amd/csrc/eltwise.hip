@@ -221,60 +221,65 @@ static ScanGeom scan_geom(uint32_t n) {
   return g;
 }
 
-// running product: io[i] = prod_{j<=i} io[j]
+// running product (SUM = false): io[i] = prod_{j<=i} io[j]; running sum (SUM = true): io[i] = sum_{j<=i} io[j]
+template <bool SUM> R0H_HD Fp4 scan_id() { return SUM ? fp4_zero() : fp4_one(); }
+template <bool SUM> R0H_HD Fp4 scan_op(const Fp4& a, const Fp4& b) { return SUM ? a + b : a * b; }
+template <bool SUM>
 __global__ void prefix_chunk_prod_kernel(uint32_t* __restrict__ chunk_prod, const uint32_t* __restrict__ io, uint32_t E) {
   extern __shared__ uint32_t sh[];
   const uint32_t t = threadIdx.x, nt = blockDim.x;
   const uint32_t* p = io + 4 * ((size_t)blockIdx.x * nt * E + (size_t)t * E);
-  Fp4 v = fp4_one();
-  for (uint32_t k = 0; k < E; k++) v = v * ld4(p + 4 * k);
+  Fp4 v = scan_id<SUM>();
+  for (uint32_t k = 0; k < E; k++) v = scan_op<SUM>(v, ld4(p + 4 * k));
   st4(sh + 4 * t, v);
   __syncthreads();
   for (uint32_t s = nt / 2; s >= 1; s >>= 1) {
-    if (t < s) st4(sh + 4 * t, ld4(sh + 4 * t) * ld4(sh + 4 * (t + s)));
+    if (t < s) st4(sh + 4 * t, scan_op<SUM>(ld4(sh + 4 * t), ld4(sh + 4 * (t + s))));
     __syncthreads();
   }
   if (t == 0) st4(chunk_prod + 4 * (size_t)blockIdx.x, ld4(sh));
 }
-// exclusive running product over the chunk summaries, one block: serial per thread, Hillis-Steele across threads
+// exclusive scan over the chunk summaries, one block: serial per thread, Hillis-Steele across threads
+template <bool SUM>
 __global__ __launch_bounds__(256) void prefix_chunk_scan_kernel(uint32_t* chunk_prod, uint32_t n_chunks) {
   __shared__ uint32_t sh[256 * 4];
   const uint32_t t = threadIdx.x, per = (n_chunks + 255) / 256, b0 = t * per;
-  Fp4 v = fp4_one();
-  for (uint32_t k = 0; k < per && b0 + k < n_chunks; k++) v = v * ld4(chunk_prod + 4 * (size_t)(b0 + k));
+  Fp4 v = scan_id<SUM>();
+  for (uint32_t k = 0; k < per && b0 + k < n_chunks; k++) v = scan_op<SUM>(v, ld4(chunk_prod + 4 * (size_t)(b0 + k)));
   st4(sh + 4 * t, v);
   __syncthreads();
   for (uint32_t s = 1; s < 256; s <<= 1) {
-    Fp4 o = t >= s ? ld4(sh + 4 * (t - s)) : fp4_one();
+    Fp4 o = t >= s ? ld4(sh + 4 * (t - s)) : scan_id<SUM>();
     __syncthreads();
-    if (t >= s) st4(sh + 4 * t, ld4(sh + 4 * t) * o);
+    if (t >= s) st4(sh + 4 * t, scan_op<SUM>(ld4(sh + 4 * t), o));
     __syncthreads();
   }
-  Fp4 cur = t ? ld4(sh + 4 * (t - 1)) : fp4_one();
+  Fp4 cur = t ? ld4(sh + 4 * (t - 1)) : scan_id<SUM>();
   for (uint32_t k = 0; k < per && b0 + k < n_chunks; k++) {
     Fp4 x = ld4(chunk_prod + 4 * (size_t)(b0 + k));
     st4(chunk_prod + 4 * (size_t)(b0 + k), cur);
-    cur = cur * x;
+    cur = scan_op<SUM>(cur, x);
   }
 }
+template <bool SUM>
 __global__ void prefix_apply_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ chunk_excl, uint32_t E) {
   extern __shared__ uint32_t sh[];
   const uint32_t t = threadIdx.x, nt = blockDim.x;
   uint32_t* p = io + 4 * ((size_t)blockIdx.x * nt * E + (size_t)t * E);
-  Fp4 v = fp4_one();
-  for (uint32_t k = 0; k < E; k++) v = v * ld4(p + 4 * k);
+  Fp4 v = scan_id<SUM>();
+  for (uint32_t k = 0; k < E; k++) v = scan_op<SUM>(v, ld4(p + 4 * k));
   st4(sh + 4 * t, v);
   __syncthreads();
   for (uint32_t s = 1; s < nt; s <<= 1) {  // inclusive scan over threads
-    Fp4 o = t >= s ? ld4(sh + 4 * (t - s)) : fp4_one();
+    Fp4 o = t >= s ? ld4(sh + 4 * (t - s)) : scan_id<SUM>();
     __syncthreads();
-    if (t >= s) st4(sh + 4 * t, ld4(sh + 4 * t) * o);
+    if (t >= s) st4(sh + 4 * t, scan_op<SUM>(ld4(sh + 4 * t), o));
     __syncthreads();
   }
   Fp4 cur = ld4(chunk_excl + 4 * (size_t)blockIdx.x);
-  if (t > 0) cur = cur * ld4(sh + 4 * (t - 1));
+  if (t > 0) cur = scan_op<SUM>(cur, ld4(sh + 4 * (t - 1)));
   for (uint32_t k = 0; k < E; k++) {
-    cur = cur * ld4(p + 4 * k);
+    cur = scan_op<SUM>(cur, ld4(p + 4 * k));
     st4(p + 4 * k, cur);
   }
 }
@@ -617,18 +622,24 @@ const char* r0h_fri_fold(r0h_ctx* ctx, r0h_buf* out, const r0h_buf* in, const ui
   return launch_ok("fri_fold_kernel");
 }
 
-const char* r0h_prefix_products(r0h_ctx* ctx, r0h_buf* io, uint32_t n) {
-  R0H_REQUIRE(ctx && io, "r0h_prefix_products: NULL argument");
-  R0H_REQUIRE(n && (n & (n - 1)) == 0, "r0h_prefix_products: n %u is not a power of two", n);
-  R0H_REQUIRE((size_t)n * 16 <= io->bytes, "r0h_prefix_products: n %u exceeds the buffer", n);
+}  // extern "C"
+template <bool SUM>
+static const char* prefix_scan(r0h_ctx* ctx, r0h_buf* io, uint32_t n, const char* what) {
+  R0H_REQUIRE(ctx && io, "%s: NULL argument", what);
+  R0H_REQUIRE(n && (n & (n - 1)) == 0, "%s: n %u is not a power of two", what, n);
+  R0H_REQUIRE((size_t)n * 16 <= io->bytes, "%s: n %u exceeds the buffer", what, n);
   const ScanGeom g = scan_geom(n);
   R0H_TRY(ensure_scratch(ctx, (size_t)(g.n_chunks + 1) * 16));
   uint32_t* cp = (uint32_t*)ctx->scratch;
-  hipLaunchKernelGGL(prefix_chunk_prod_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, cp, u32(io), g.E);
-  hipLaunchKernelGGL(prefix_chunk_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, cp, g.n_chunks);
-  hipLaunchKernelGGL(prefix_apply_kernel, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, u32(io), cp, g.E);
-  return launch_ok("prefix_products kernels");
+  hipLaunchKernelGGL(prefix_chunk_prod_kernel<SUM>, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, cp, u32(io), g.E);
+  hipLaunchKernelGGL(prefix_chunk_scan_kernel<SUM>, dim3(1), dim3(256), 0, ctx->stream, cp, g.n_chunks);
+  hipLaunchKernelGGL(prefix_apply_kernel<SUM>, dim3(g.n_chunks), dim3(g.threads), g.threads * 16, ctx->stream, u32(io), cp, g.E);
+  return launch_ok(what);
 }
+extern "C" {
+const char* r0h_prefix_products(r0h_ctx* ctx, r0h_buf* io, uint32_t n) { return prefix_scan<false>(ctx, io, n, "r0h_prefix_products"); }
+// the additive counterpart (the running sums of a log-derivative argument): io[i] = sum_{j <= i} io[j] over extension elements
+const char* r0h_prefix_sums(r0h_ctx* ctx, r0h_buf* io, uint32_t n) { return prefix_scan<true>(ctx, io, n, "r0h_prefix_sums"); }
 
 const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint32_t z[4], uint32_t remainder[4]) {
   R0H_REQUIRE(ctx && poly && z, "r0h_poly_divide: NULL argument");

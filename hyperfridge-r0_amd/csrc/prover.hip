@@ -222,6 +222,7 @@ struct r0h_code_commit {
   r0h_ctx* ctx = nullptr;
   uint32_t count = 0, po2 = 0;
   r0h_buf *coeffs = nullptr, *evaluated = nullptr, *nodes = nullptr;
+  r0h_buf* witness = nullptr;  // the CODE columns themselves (a log-derivative accumulation reads its tables from them); may be absent
   std::vector<uint32_t> top;  // the top layer as tree_commit writes it to the seal
   uint32_t root[8] = {0};
 };
@@ -237,6 +238,9 @@ struct r0h_proof {
   r0h::WriteIop io;
   r0h::Group g_accum, g_code, g_data, g_check;
   std::vector<uint32_t> mix, global;
+  size_t seal_globals_at = 0;   // where the seal's opening block of public inputs starts
+  uint32_t data_root[8] = {0};  // the DATA group's Merkle root (what a session's common challenge is derived from)
+  bool mix_drawn = false;
   r0h_proof(r0h_ctx* c, const r0h_circuit* ci, uint32_t p, const r0h::CircuitView& v)
       : ctx(c), circ(ci), po2(p), cv(v), io(&c->p2_host), g_accum(v.group_size[R0H_GROUP_ACCUM], (size_t)4 << p),
         g_code(v.group_size[R0H_GROUP_CODE], (size_t)4 << p), g_data(v.group_size[R0H_GROUP_DATA], (size_t)4 << p),
@@ -245,6 +249,7 @@ struct r0h_proof {
 
 namespace r0h {
 
+static const char* proof_late(r0h_proof& st, const uint32_t* late);
 static const char* proof_begin(r0h_proof& st, const r0h_buf* code, const r0h_code_commit* cc, const r0h_buf* data, const uint32_t* global) {
   r0h_ctx* ctx = st.ctx;
   const r0h_circuit* circ = st.circ;
@@ -268,12 +273,18 @@ static const char* proof_begin(r0h_proof& st, const r0h_buf* code, const r0h_cod
     for (int i = 0; i < 16; i++) e[i] = enc(circ->info[i]);
     p2_hash_elems_host(ctx->p2_host, e, 16, d);
     io.commit(d);
-    std::vector<uint32_t> gv(global, global + cv.n_global);
+    // the seal opens with every public input and po2; the transcript takes the early ones here and the late ones (inputs that depend
+    // on commitments made outside this proof, R0H_SEC_LATE) after the DATA group is committed
+    const uint32_t n_early = cv.n_global - circ->n_late;
+    std::vector<uint32_t> gv(global, global + n_early);
     for (uint32_t w : gv) R0H_REQUIRE(w < P, "prove_segment: global word not canonical");
     gv.push_back(enc(po2));
     p2_hash_elems_host(ctx->p2_host, gv.data(), gv.size(), d);
     io.commit(d);
-    io.write(gv.data(), gv.size());
+    st.seal_globals_at = io.proof.size();
+    io.write(global, cv.n_global);
+    const uint32_t po2_word = enc(po2);
+    io.write(&po2_word, 1);
   }
 
   phase(ctx, "commit_code");
@@ -294,14 +305,33 @@ static const char* proof_begin(r0h_proof& st, const r0h_buf* code, const r0h_cod
   phase(ctx, "commit_data");
   R0H_TRY(group_from_witness(ctx, sc, g_data, data, po2));
   R0H_TRY(tree_commit(ctx, g_data.tree, io));
+  R0H_TRY(r0h_buf_d2h(ctx, g_data.tree.nodes, 32, st.data_root, 32));
+  if (!circ->n_late) return proof_late(st, nullptr);
+  return nullptr;
+}
 
-  st.mix.resize(cv.n_mix);
-  for (uint32_t i = 0; i < cv.n_mix; i++) st.mix[i] = io.rng.elem();
-  phase(ctx, "accum");
+// the late public inputs enter the transcript (and the seal's opening block), then the accumulation mix is drawn
+static const char* proof_late(r0h_proof& st, const uint32_t* late) {
+  const uint32_t n_late = st.circ->n_late, n_early = st.cv.n_global - n_late;
+  R0H_REQUIRE(!st.mix_drawn, "r0h_proof_late: the accumulation mix has been drawn already");
+  if (n_late) {
+    R0H_REQUIRE(late, "r0h_proof_late: NULL argument");
+    for (uint32_t i = 0; i < n_late; i++) R0H_REQUIRE(late[i] < P, "r0h_proof_late: word %u not canonical", i);
+    memcpy(st.global.data() + n_early, late, (size_t)n_late * 4);
+    memcpy(st.io.proof.data() + st.seal_globals_at + n_early, late, (size_t)n_late * 4);
+    uint32_t d[8];
+    p2_hash_elems_host(st.ctx->p2_host, late, n_late, d);
+    st.io.commit(d);
+  }
+  st.mix.resize(st.cv.n_mix);
+  for (uint32_t i = 0; i < st.cv.n_mix; i++) st.mix[i] = st.io.rng.elem();
+  st.mix_drawn = true;
+  phase(st.ctx, "accum");
   return nullptr;
 }
 
 static const char* proof_finish(r0h_proof& st, const r0h_buf* accum, std::vector<uint32_t>& seal) {
+  R0H_REQUIRE(st.mix_drawn, "r0h_proof_finish: this circuit has late public inputs: r0h_proof_late comes first");
   r0h_ctx* ctx = st.ctx;
   const r0h_circuit* circ = st.circ;
   const uint32_t po2 = st.po2;
@@ -546,9 +576,13 @@ static const char* prove_segment_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32
     circuit_view(c, &cv);
     r0h_proof st(ctx, c, po2, cv);
     R0H_TRY(proof_begin(st, code, cc, data, global));
+    if (c->n_late) R0H_TRY(proof_late(st, global + (cv.n_global - c->n_late)));
     r0h_buf* accum = nullptr;
     R0H_TRY(st.sc.alloc(ctx, ((size_t)cv.group_size[R0H_GROUP_ACCUM] << po2) * 4, &accum));
-    R0H_TRY(r0h_accum(ctx, c, po2, code, data, st.mix.data(), accum));
+    const r0h_buf* code_cols = code;
+    r0h_buf code_view;
+    if (!code_cols && cc && cc->witness) { code_view = *cc->witness; code_cols = &code_view; }
+    R0H_TRY(r0h_accum_public(ctx, c, po2, code_cols, data, st.global.data(), st.mix.data(), accum));
     R0H_TRY(proof_finish(st, accum, seal));
   }
   *seal_words_out = seal.size();
@@ -570,7 +604,7 @@ static const char* proof_begin_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32_t
   r0h_proof* st = new r0h_proof(ctx, c, po2, cv);
   const char* err = proof_begin(*st, code, cc, data, global);
   if (err) { delete st; return err; }
-  if (cv.n_mix) memcpy(mix_out, st->mix.data(), (size_t)cv.n_mix * 4);
+  if (cv.n_mix && st->mix_drawn) memcpy(mix_out, st->mix.data(), (size_t)cv.n_mix * 4);
   *out = st;
   return nullptr;
   R0H_GUARD_END
@@ -617,6 +651,12 @@ const char* r0h_code_commit_new(r0h_ctx* ctx, const r0h_buf* code, uint32_t coun
     cc->top.swap(io.proof);
     R0H_TRY(r0h_buf_d2h(ctx, g.tree.nodes, 32, cc->root, 32));
     cc->coeffs = g.coeffs; cc->evaluated = g.evaluated; cc->nodes = g.tree.nodes;
+    {  // a copy of the columns stays with the commitment
+      const size_t bytes = ((size_t)count << po2) * 4;
+      R0H_TRY(r0h_buf_alloc(ctx, bytes, &cc->witness));
+      R0H_TRY_HIP(hipMemcpyAsync(cc->witness->ptr, code->ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    }
     sc.bufs.clear();
     // long-lived and read from other contexts' streams: on release these go back to the device (hipFree waits for every stream),
     // not into this context's stream-ordered pool
@@ -633,9 +673,15 @@ const char* r0h_code_commit_free(r0h_code_commit* cc) {
   if (cc->coeffs) r0h_buf_free(cc->coeffs);
   if (cc->evaluated) r0h_buf_free(cc->evaluated);
   if (cc->nodes) r0h_buf_free(cc->nodes);
+  if (cc->witness) r0h_buf_free(cc->witness);
   r0h_ctx* ctx = cc->ctx;
   delete cc;
   if (ctx) ctx_release(ctx);
+  return nullptr;
+}
+const char* r0h_code_commit_columns(const r0h_code_commit* cc, const r0h_buf** columns_out) {
+  R0H_REQUIRE(cc && columns_out && cc->witness, "r0h_code_commit_columns: NULL argument");
+  *columns_out = cc->witness;
   return nullptr;
 }
 const char* r0h_code_commit_root(const r0h_code_commit* cc, uint32_t root_out[8]) {
@@ -657,6 +703,27 @@ const char* r0h_proof_finish(r0h_proof* proof, const r0h_buf* accum, uint32_t* s
   if (seal_out) memcpy(seal_out, seal.data(), seal.size() * 4);
   return nullptr;
   R0H_GUARD_END
+}
+
+const char* r0h_proof_data_root(const r0h_proof* proof, uint32_t root_out[8]) {
+  R0H_REQUIRE(proof && root_out, "r0h_proof_data_root: NULL argument");
+  memcpy(root_out, proof->data_root, 32);
+  return nullptr;
+}
+const char* r0h_proof_late(r0h_proof* proof, const uint32_t* late_globals, uint32_t* mix_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(proof && (mix_out || !proof->cv.n_mix), "r0h_proof_late: NULL argument");
+  R0H_REQUIRE(proof->circ->n_late, "r0h_proof_late: this circuit has no late public inputs");
+  R0H_TRY_HIP(hipSetDevice(proof->ctx->device));
+  R0H_TRY(proof_late(*proof, late_globals));
+  if (proof->cv.n_mix) memcpy(mix_out, proof->mix.data(), (size_t)proof->cv.n_mix * 4);
+  return nullptr;
+  R0H_GUARD_END
+}
+const char* r0h_proof_globals(const r0h_proof* proof, uint32_t* globals_out) {
+  R0H_REQUIRE(proof && globals_out, "r0h_proof_globals: NULL argument");
+  memcpy(globals_out, proof->global.data(), proof->global.size() * 4);
+  return nullptr;
 }
 
 const char* r0h_proof_abort(r0h_proof* proof) {

@@ -43,4 +43,5 @@ void tagged_struct(const char* tag, const uint8_t (*down)[32], size_t n_down, co
 void system_state_digest(const r0h_system_state& st, uint8_t out[32]);
 void claim_digest(const r0h_receipt_claim& c, uint8_t out[32]);
 void claim_globals(const uint8_t digest[32], uint32_t out[8]);
+void session_challenge(const uint32_t* records, size_t n_records, uint32_t out[16]);
 }  // namespace r0h

@@ -23,7 +23,10 @@
 // ecall ABI (a7 = x17 selects; arguments a0, a1; every ecall cycle reads a7 and a0 -- they are the cycle's two register reads):
 //   0 HALT        a0 = exit code                        -- ends the run (ExitCode::Halted(a0))
 //   1 READ_WORDS  a0 = destination, a1 = word count     -- the next words of the input stream (ExecutorEnv frames), zero past its end
-//   2 COMMIT      a0 = source, a1 = word count          -- appends words to the journal (`env::commit`: the journal is a word stream)
+//   2 COMMIT      a0 = source, a1 = word count          -- journal words (`env::commit`).  The journal is a WINDOW of guest memory: the
+//                                                          word at R0H_JOURNAL_BASE + 4 i is journal word i, committed once; a run's
+//                                                          commits together cover [0, n) -- so that a verifier who knows only the
+//                                                          journal knows which (address, word) pairs the COMMIT rows name (csrc/claim.cpp)
 //   3 CYCLES                                            -- a0 = cycles executed so far (`env::cycle_count()`)
 //   4 PAUSE       a0 = exit code                        -- ends the run resumably (ExitCode::Paused(a0))
 // The two transfers move one word per cycle and keep no state outside the registers, so that a cycle is a function of what it
@@ -60,6 +63,7 @@ constexpr size_t MAX_RESIDENT_PAGES = (size_t)1 << 21;  // 2 GiB of guest memory
 struct Page {
   uint32_t w[PAGE_WORDS];
   uint32_t ts[PAGE_WORDS];  // timestamp of the last access in segment `epoch` (0 = not touched yet)
+  uint32_t seg[PAGE_WORDS]; // number (index + 1) of the last segment that touched the word, 0 = none yet: what a boundary row names
   uint32_t epoch, in_epoch, out_epoch;  // segment (index + 1) for which ts / "paged in" / "dirtied" hold
   uint32_t stale;           // 1: written since its leaf of the memory tree was last hashed (it is then on the vm's stale list)
 };
@@ -87,6 +91,10 @@ struct r0h_vm {
   std::vector<uint32_t> input;
   size_t input_pos = 0;
   std::vector<uint8_t> journal;
+  std::vector<uint8_t> journal_seen;  // per journal word: committed already
+  uint32_t reg_seg[32] = {0};         // per register: the last segment that touched it (0 = none yet)
+  std::vector<std::pair<uint32_t, uint32_t>> image;  // (word index, word) of everything loaded before the run: the program image
+  bool image_sorted = false;
   uint64_t cycles = 0;  // cycles (rows) over the whole run
   bool finished = false; // a run ended in HALT / PAUSE / the cycle limit: its segments are final
   std::vector<Segment> segments;
@@ -175,14 +183,17 @@ void memory_root(r0h_vm& vm, uint8_t out[32]) {
   memcpy(out, top == vm.tree.end() ? vm.zero_level[N_PAGE_BITS] : top->second.data(), 32);
 }
 
+struct Touched { uint32_t addr, first_value, prev_seg; };
+inline bool operator<(const Touched& a, const Touched& b) { return a.addr < b.addr; }
+
 struct Run {
   r0h_vm& vm;
   const r0h_vm_limits lim;
   Segment cur;
   uint32_t epoch = 0;                  // index of the current segment + 1
   uint32_t n_in = 0, n_out = 0;        // pages first touched / dirtied in the current segment
-  uint32_t reg_ts[32], reg_first[32], reg_mask = 0;
-  std::vector<std::pair<uint32_t, uint32_t>> touched;  // (word index, value found) of every word first touched in the segment
+  uint32_t reg_ts[32], reg_first[32], reg_prev_seg[32], reg_mask = 0;
+  std::vector<Touched> touched;        // every word first touched in the segment: what was found there, which segment left it
   uint64_t seg_budget, executed = 0;
   const char* err = nullptr;
   r0h_preflight_row* row = nullptr;
@@ -191,7 +202,18 @@ struct Run {
   uint8_t root_now[32];                // memory root at the last segment boundary (the next segment starts from it)
   bool have_root = false;
 
-  Run(r0h_vm& v, const r0h_vm_limits& l) : vm(v), lim(l), seg_budget((uint64_t)1 << l.segment_po2) {}
+  Run(r0h_vm& v, const r0h_vm_limits& l) : vm(v), lim(l), seg_budget((uint64_t)1 << l.segment_po2) {
+    if (!vm.image_sorted) {  // later loads of a word replace earlier ones; then by address
+      std::stable_sort(vm.image.begin(), vm.image.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+      std::vector<std::pair<uint32_t, uint32_t>> uniq;
+      for (const auto& e : vm.image) {
+        if (!uniq.empty() && uniq.back().first == e.first) uniq.back() = e;
+        else uniq.push_back(e);
+      }
+      vm.image.swap(uniq);
+      vm.image_sorted = true;
+    }
+  }
 
   uint64_t paging_cycles() const { return (uint64_t)n_in * lim.page_in_cycles + (uint64_t)n_out * lim.page_out_cycles; }
   uint64_t boundary_count() const { return lim.boundary_rows ? touched.size() + (uint64_t)__builtin_popcount(reg_mask) : 0; }
@@ -214,33 +236,100 @@ struct Run {
       cur.rows.reserve((size_t)std::min<uint64_t>(seg_budget, (uint64_t)1 << 22));
     }
   }
-  void end_segment(uint32_t exit_system, uint32_t exit_user) {
+  // one boundary row per address the segment touched, in increasing address order (registers sit above memory)
+  void own_bounds(std::vector<r0h_preflight_bound>& out) {
+    std::sort(touched.begin(), touched.end());
+    out.reserve(touched.size() + 32);
+    for (const Touched& t : touched) {
+      const Page* p = vm.table[t.addr >> 8];
+      out.push_back(r0h_preflight_bound{t.addr, t.first_value, p->w[t.addr & 255], p->ts[t.addr & 255], t.prev_seg, 0, 0, 0});
+    }
+    for (uint32_t i = 0; i < 32; i++)
+      if (reg_mask >> i & 1) out.push_back(r0h_preflight_bound{R0H_REG_BASE + i, reg_first[i], vm.x[i], reg_ts[i], reg_prev_seg[i], 0, 0, 0});
+  }
+  // The rows that close the session: one per word any segment touched or the image holds, and per register touched, in increasing
+  // address order.  `own` (sorted) are the boundary rows of the segment that is being closed (empty for a segment without cycles): an
+  // address among them keeps its history; any other is merely named -- found and left as it is, never accessed.  Each row carries the
+  // address's initial value: the image's word, or zero.
+  void closing_rows(const std::vector<r0h_preflight_bound>& own, std::vector<r0h_preflight_bound>& out) {
+    std::vector<uint32_t> pages(vm.page_list);
+    std::sort(pages.begin(), pages.end());
+    size_t io = 0, im = 0;
+    const std::vector<std::pair<uint32_t, uint32_t>>& image = vm.image;
+    auto emit = [&](uint32_t addr, uint32_t value, uint32_t seg) {
+      while (im < image.size() && image[im].first < addr) im++;
+      const bool in_image = im < image.size() && image[im].first == addr;
+      r0h_preflight_bound b;
+      if (io < own.size() && own[io].addr == addr) b = own[io++];
+      else b = r0h_preflight_bound{addr, value, value, 0, seg, 0, 0, 0};
+      b.init_value = in_image ? image[im].second : 0u;
+      b.flags = in_image ? R0H_BOUND_IMAGE : 0u;
+      out.push_back(b);
+    };
+    for (uint32_t idx : pages) {
+      const Page* p = vm.table[idx];
+      // the image's words of this page that nothing has touched are named too (the verifier multiplies out the whole image)
+      size_t lo = std::lower_bound(image.begin(), image.end(), std::make_pair(idx << 8, 0u)) - image.begin();
+      for (uint32_t k = 0; k < PAGE_WORDS; k++) {
+        const uint32_t addr = idx << 8 | k;
+        while (lo < image.size() && image[lo].first < addr) lo++;
+        const bool in_image = lo < image.size() && image[lo].first == addr;
+        if (p->seg[k] || in_image) emit(addr, p->w[k], p->seg[k]);
+      }
+    }
+    for (uint32_t i = 0; i < 32; i++)
+      if (vm.reg_seg[i]) emit(R0H_REG_BASE + i, vm.x[i], vm.reg_seg[i]);
+  }
+  void push_segment(uint32_t exit_system, uint32_t exit_user) {
     cur.info.post.pc = vm.pc;
     memory_root(vm, root_now);
     memcpy(cur.info.post.merkle_root, root_now, 32);
     cur.info.pages_in = n_in;
     cur.info.pages_out = n_out;
     cur.info.paging_cycles = paging_cycles();
-    cur.info.boundary_rows = (uint32_t)boundary_count();
     cur.info.exit_system = exit_system;
     cur.info.exit_user = exit_user;
-    if (lim.keep_trace) {  // one boundary row per address touched, in increasing address order (registers sit above memory)
-      std::sort(touched.begin(), touched.end());
-      cur.bounds.reserve(touched.size() + 32);
-      for (const auto& t : touched) {
-        const Page* p = vm.table[t.first >> 8];
-        cur.bounds.push_back(r0h_preflight_bound{t.first, t.second, p->w[t.first & 255], p->ts[t.first & 255]});
-      }
-      for (uint32_t i = 1; i < 32; i++)
-        if (reg_mask >> i & 1) cur.bounds.push_back(r0h_preflight_bound{R0H_REG_BASE + i, reg_first[i], vm.x[i], reg_ts[i]});
+  }
+  // final: the run ends with this segment -- the session is closed in it if the closing rows fit beside its cycles, in segments
+  // of closing rows only (no cycles) after it otherwise
+  void end_segment(uint32_t exit_system, uint32_t exit_user, bool final = false) {
+    push_segment(exit_system, exit_user);
+    cur.info.boundary_rows = (uint32_t)boundary_count();
+    if (!(lim.keep_trace && lim.boundary_rows)) {
+      vm.segments.push_back(std::move(cur));
+      return;
+    }
+    own_bounds(cur.bounds);
+    if (!final) {
+      vm.segments.push_back(std::move(cur));
+      return;
+    }
+    std::vector<r0h_preflight_bound> all;
+    closing_rows(cur.bounds, all);
+    if (cur.info.user_cycles + all.size() <= seg_budget) {
+      cur.bounds.swap(all);
+      cur.info.boundary_rows = (uint32_t)cur.bounds.size();
+      cur.info.closing = 1;
+      vm.segments.push_back(std::move(cur));
+      return;
     }
     vm.segments.push_back(std::move(cur));
+    all.clear();
+    closing_rows(std::vector<r0h_preflight_bound>(), all);  // every address now names the segment just pushed, or an earlier one
+    for (size_t at = 0; at < all.size(); at += (size_t)seg_budget) {
+      begin_segment();
+      cur.bounds.assign(all.begin() + at, all.begin() + std::min(all.size(), at + (size_t)seg_budget));
+      push_segment(2, 0);
+      cur.info.boundary_rows = (uint32_t)cur.bounds.size();
+      cur.info.closing = 1;
+      vm.segments.push_back(std::move(cur));
+    }
   }
 
   // ---- the accesses of a cycle, each with its timestamp: returns when the same register / word was last touched in this segment
   uint32_t touch_reg(uint32_t i, uint32_t ts) {
     const uint32_t prev = reg_ts[i];
-    if (!(reg_mask >> i & 1)) { reg_mask |= 1u << i; reg_first[i] = vm.x[i]; }
+    if (!(reg_mask >> i & 1)) { reg_mask |= 1u << i; reg_first[i] = vm.x[i]; reg_prev_seg[i] = vm.reg_seg[i]; vm.reg_seg[i] = epoch; }
     reg_ts[i] = ts;
     return prev;
   }
@@ -256,7 +345,7 @@ struct Run {
   uint32_t touch_word(Page* p, uint32_t addr, uint32_t ts) {
     if (p->epoch != epoch) { p->epoch = epoch; memset(p->ts, 0, sizeof p->ts); }
     const uint32_t k = (addr & (PAGE_BYTES - 1)) >> 2, prev = p->ts[k];
-    if (!prev) touched.emplace_back(addr >> 2, p->w[k]);
+    if (!prev) { touched.push_back(Touched{addr >> 2, p->w[k], p->seg[k]}); p->seg[k] = epoch; }
     p->ts[k] = ts;
     return prev;
   }
@@ -264,7 +353,7 @@ struct Run {
   void mem_access(uint32_t addr, bool write, uint32_t value, uint32_t* before) {
     Page* p = page(addr, write);
     const uint32_t k = (addr & (PAGE_BYTES - 1)) >> 2;
-    const uint32_t prev = touch_word(p, addr, r0h::trace::stamp((uint32_t)cur.info.user_cycles, 3));
+    const uint32_t prev = touch_word(p, addr, r0h::trace::stamp((uint32_t)cur.info.user_cycles, r0h::trace::ACC_MEM));
     *before = p->w[k];
     if (write) p->w[k] = value;
     if (row) {
@@ -317,7 +406,7 @@ struct Run {
     const uint32_t cyc = (uint32_t)cur.info.user_cycles;
     Page* fp = page(m.pc, false);
     const uint32_t insn = fp->w[(m.pc & (PAGE_BYTES - 1)) >> 2];
-    const uint32_t fetch_prev = touch_word(fp, m.pc, r0h::trace::stamp(cyc, 4));
+    const uint32_t fetch_prev = touch_word(fp, m.pc, r0h::trace::stamp(cyc, r0h::trace::ACC_FETCH));
     const uint32_t op = insn & 0x7f, rd = (insn >> 7) & 31, f3 = (insn >> 12) & 7, rs1 = (insn >> 15) & 31, rs2 = (insn >> 20) & 31, f7 = insn >> 25;
     const bool sys = op == 0x73;  // an ecall reads a7 and a0 where another instruction reads x[rs1] and x[rs2]
     const uint32_t r1 = sys ? 17u : rs1, r2 = sys ? 10u : rs2;
@@ -328,7 +417,8 @@ struct Run {
     const int32_t imm_j = ((int32_t)(insn & 0x80000000) >> 11) | (int32_t)(insn & 0xff000) | (int32_t)((insn >> 9) & 0x800) | (int32_t)((insn >> 20) & 0x7fe);
     uint32_t next = m.pc + 4, wr = 0, wr_reg = rd;
     bool has_wr = false;
-    const uint32_t p0 = r1 ? touch_reg(r1, r0h::trace::stamp(cyc, 0)) : 0, p1 = r2 ? touch_reg(r2, r0h::trace::stamp(cyc, 1)) : 0;
+    // x0 is a register like any other to the memory argument (nothing ever writes it): every cycle reads two registers
+    const uint32_t p0 = touch_reg(r1, r0h::trace::stamp(cyc, r0h::trace::ACC_RS1)), p1 = touch_reg(r2, r0h::trace::stamp(cyc, r0h::trace::ACC_RS2));
     if (lim.keep_trace) {
       cur.rows.emplace_back();  // value-initialised: all zero
       row = &cur.rows.back();
@@ -454,10 +544,9 @@ struct Run {
               if (((uint64_t)a0 + 4ull * a1) >> ADDRESS_BITS) { err = "ecall buffer outside the 1 GiB address space"; return false; }
               m.io_active = true;
               m.io_total = a1;
-              m.io_base = fn == 1 ? m.input_pos : m.journal.size();
-              if (fn == 2) {
-                if (m.journal.size() + 4ull * a1 > MAX_JOURNAL_BYTES) { err = "COMMIT: the journal exceeds 2^28 bytes"; return false; }
-                m.journal.resize(m.journal.size() + 4 * (size_t)a1);
+              m.io_base = fn == 1 ? m.input_pos : 0;
+              if (fn == 2) {  // the journal is a window of memory: word i of it lives at R0H_JOURNAL_BASE + 4 i
+                if (a0 < R0H_JOURNAL_BASE || (uint64_t)a0 + 4ull * a1 > (uint64_t)R0H_JOURNAL_BASE + MAX_JOURNAL_BYTES) { err = "COMMIT: the source lies outside the journal window"; return false; }
               }
             }
             if (a1 > m.io_total) { err = "ecall: a1 grew during a transfer"; return false; }
@@ -467,8 +556,14 @@ struct Run {
               mem_access(a0 + 4 * idx, true, m.io_base + idx < m.input.size() ? m.input[m.io_base + idx] : 0u, &old);
             } else {
               uint32_t w;
+              if (a0 < R0H_JOURNAL_BASE) { err = "COMMIT: the source lies outside the journal window"; return false; }
+              const size_t j = (size_t)(a0 - R0H_JOURNAL_BASE) / 4 + idx;
+              if (4 * (j + 1) > MAX_JOURNAL_BYTES) { err = "COMMIT: the journal exceeds 2^28 bytes"; return false; }
+              if (m.journal_seen.size() <= j) { m.journal_seen.resize(j + 1, 0); m.journal.resize(4 * (j + 1), 0); }
+              if (m.journal_seen[j]) { err = "COMMIT: a journal word is committed twice"; return false; }
+              m.journal_seen[j] = 1;
               mem_access(a0 + 4 * idx, false, 0, &w);
-              for (uint32_t i = 0; i < 4; i++) m.journal[m.io_base + 4 * (size_t)idx + i] = (uint8_t)(w >> (8 * i));
+              for (uint32_t i = 0; i < 4; i++) m.journal[4 * j + i] = (uint8_t)(w >> (8 * i));
             }
             set(idx);
             next = m.pc;
@@ -482,7 +577,7 @@ struct Run {
       default: err = "illegal instruction"; return false;
     }
     if (has_wr && wr_reg != 0) {
-      const uint32_t p2 = touch_reg(wr_reg, r0h::trace::stamp(cyc, 2));
+      const uint32_t p2 = touch_reg(wr_reg, r0h::trace::stamp(cyc, r0h::trace::ACC_RD));
       if (row) { row->rd = wr_reg; row->rd_before = m.x[wr_reg]; row->rd_after = wr; row->prev[2] = p2; }
       m.x[wr_reg] = wr;
     }
@@ -498,12 +593,14 @@ struct Run {
     const size_t before = vm.segments.size();
     *finished = false;
     while (vm.segments.size() == before) {
-      if (lim.max_cycles && executed >= lim.max_cycles) { end_segment(2, 2); *finished = true; return nullptr; }  // SessionLimit
+      if (lim.max_cycles && executed >= lim.max_cycles) { end_segment(2, 2, true); *finished = true; return nullptr; }  // SessionLimit
       const bool running = step();
       if (err) return r0h::make_error("guest trap at pc %#x after %llu cycles: %s", vm.pc, (unsigned long long)vm.cycles, err);
       executed++;
       if (!running) {
-        end_segment(exit_kind == R0H_VM_HALTED ? 0 : 1, exit_code);  // Halted(code) / Paused(code)
+        for (uint8_t seen : vm.journal_seen)
+          if (!seen) return r0h::make_error("the guest's commits leave a hole in the journal window");
+        end_segment(exit_kind == R0H_VM_HALTED ? 0 : 1, exit_code, true);  // Halted(code) / Paused(code)
         *finished = true;
         return nullptr;
       }
@@ -535,26 +632,26 @@ const char* column_name(uint32_t column) {
   static const std::vector<std::string> names = [] {
     std::vector<std::string> n;
     auto run = [&](const char* stem, int count) { for (int k = 0; k < count; k++) n.push_back(stem + std::to_string(k)); };
-    for (const char* s : {"live", "bnd", "cycle", "pc", "next_pc", "insn_lo", "insn_hi"}) n.push_back(s);
-    run("bit", 32);
+    for (const char* s : {"live", "bnd", "cycle", "pc", "next_pc"}) n.push_back(s);
     for (const char* s : {"lui", "auipc", "jal", "jalr", "branch", "load", "store", "imm", "op", "fence", "system"}) n.push_back(std::string("opc_") + s);
     run("f3_", 8);
-    for (const char* s : {"alu", "z1", "inv1", "act0", "addr0", "rs1_lo", "rs1_hi", "p0", "tw0", "z2", "inv2", "act1", "addr1", "rs2_lo", "rs2_hi", "p1", "tw1",
-                          "zrd", "inv_rd", "act2", "addr2", "old_lo", "old_hi", "new_lo", "new_hi", "p2", "tw2",
-                          "mem_kind", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "tw3", "addr4", "p4", "tw4"})
+    for (const char* s : {"alu", "rd0", "rdA", "rdB", "r10", "r1A", "r1B", "r20", "r2A", "r2B", "b25", "f7A", "f7B", "b30", "b31",
+                          "rs1_lo", "rs1_hi", "p0", "dl0", "dh0", "rs2_lo", "rs2_hi", "p1", "dl1", "dh1",
+                          "zrd", "inv_rd", "act2", "old_lo", "old_hi", "p2", "dl2", "dh2",
+                          "mem_act", "mem_wr", "top", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "dl3", "dh3", "p4", "dl4", "dh4"})
       n.push_back(s);
-    for (int k = 0; k < 5; k++) run(("d" + std::to_string(k) + "_").c_str(), 12);
-    run("ub", 32);
-    run("vb", 32);
-    run("zd", 16);
-    run("wd", 16);
-    for (const char* s : {"res_lo", "res_hi", "c0", "c1", "lt", "eq", "zinv", "ob0", "ob1", "sb", "sgn", "p8", "sx", "sm"}) n.push_back(s);
+    run("u", 4);
+    run("v", 4);
+    run("a", 4);
+    n.push_back("su");
+    n.push_back("sv");
+    run("sh", 5);
+    for (const char* s : {"vrd", "vrb", "z_lo", "z_hi", "ob0", "ob1", "zq", "w_lo", "w_hi", "aux0", "aux1",
+                          "res_lo", "res_hi", "c0", "c1", "lt", "eq", "zinv", "sb", "sgn", "p8", "sx", "sm"})
+      n.push_back(s);
     run("mb", 4);
-    run("cx", 4);
-    n.push_back("c3");
-    for (const char* s : {"dv", "ovf", "k0", "a31"}) n.push_back(s);
-    run("at", 8);
-    n.push_back("io");
+    for (const char* s : {"ce0", "ce1a", "ce1b", "ce2", "cb1", "cb2", "cband", "c3", "dv", "ovf", "k0", "a31", "io", "f0", "f1", "f2", "fn_cyc", "cact", "fimg", "m16", "mand"})
+      n.push_back(s);
     return n;
   }();
   return column < names.size() ? names[column].c_str() : nullptr;
@@ -584,12 +681,15 @@ const char* r0h_vm_load(r0h_vm* vm, uint32_t addr, const uint32_t* words, size_t
   R0H_GUARD_BEGIN
   R0H_REQUIRE(vm && (words || !n), "r0h_vm_load: NULL argument");
   R0H_REQUIRE((addr & 3) == 0 && (uint64_t)addr + 4 * (uint64_t)n <= ((uint64_t)1 << 32), "r0h_vm_load: [%#x, +%zu words) is misaligned or leaves the address space", addr, n);
+  R0H_REQUIRE(!vm->run && vm->segments.empty(), "r0h_vm_load: the run has begun (what is loaded before it is the program image)");
   for (size_t i = 0; i < n; i++) {
     const uint32_t a = addr + 4 * (uint32_t)i;
     Page* p = vm->get(a >> PAGE_SHIFT);
     p->w[(a & (PAGE_BYTES - 1)) >> 2] = words[i];
     vm->mark_stale(p, a >> PAGE_SHIFT);
+    vm->image.emplace_back(a >> 2, words[i]);
   }
+  vm->image_sorted = false;
   return nullptr;
   R0H_GUARD_END
 }
@@ -622,7 +722,7 @@ const char* r0h_vm_load_elf(r0h_vm* vm, const uint8_t* elf, size_t n) {
       if (base + PAGE_BYTES <= z0 || base >= z1) continue;
       Page* p = vm->table[idx];
       for (uint32_t w = 0; w < PAGE_WORDS; w++)
-        if (base + 4 * w >= z0 && base + 4 * w < z1) p->w[w] = 0;
+        if (base + 4 * w >= z0 && base + 4 * w < z1 && p->w[w]) { p->w[w] = 0; vm->image.emplace_back((uint32_t)((base + 4 * w) >> 2), 0u); }
       vm->mark_stale(p, idx);
     }
   }
@@ -771,16 +871,19 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
 const char* r0h_trace_column_name(uint32_t column) { return column < trace::N_COLS ? trace::column_name(column) : nullptr; }
 
 // The DATA group of the trace circuit on the host (the reference tests compare r0h_trace_witgen's device kernel with): cycles first,
-// then the boundary rows, blank rows to the end -- csrc/trace.hpp holds the expansion both sides compile.
+// then the boundary rows, blank rows to the end -- csrc/trace.hpp holds the expansion both sides compile.  The two multiplicity
+// columns are left zero: r0h_logup_multiplicities_host counts the lookups (from the circuit's own description of them).
 const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint32_t* data_out, uint32_t globals_out[R0H_TRACE_GLOBALS]) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(vm && data_out && globals_out, "r0h_vm_trace_witness: NULL argument");
   R0H_REQUIRE(i < vm->segments.size(), "r0h_vm_trace_witness: segment %zu of %zu", i, vm->segments.size());
   const std::vector<r0h_preflight_row>& rows = vm->segments[i].rows;
   const std::vector<r0h_preflight_bound>& bounds = vm->segments[i].bounds;
-  R0H_REQUIRE(!rows.empty(), "r0h_vm_trace_witness: segment %zu has no preflight rows (run with keep_trace)", i);
-  R0H_REQUIRE(po2 <= R0H_TRACE_MAX_PO2 && rows.size() + bounds.size() <= ((size_t)1 << po2), "r0h_vm_trace_witness: %zu cycles and %zu boundary rows do not fit 2^%u",
-              rows.size(), bounds.size(), po2);
+  const r0h_vm_segment& info = vm->segments[i].info;
+  R0H_REQUIRE(!rows.empty() || (info.user_cycles == 0 && !bounds.empty()), "r0h_vm_trace_witness: segment %zu has no preflight rows (run with keep_trace)", i);
+  R0H_REQUIRE(po2 >= R0H_TRACE_MIN_PO2 && po2 <= R0H_TRACE_MAX_PO2, "r0h_vm_trace_witness: po2 %u outside [%u, %u] (the lookup tables have 2^16 rows)", po2,
+              (unsigned)R0H_TRACE_MIN_PO2, (unsigned)R0H_TRACE_MAX_PO2);
+  R0H_REQUIRE(rows.size() + bounds.size() <= ((size_t)1 << po2), "r0h_vm_trace_witness: %zu cycles and %zu boundary rows do not fit 2^%u", rows.size(), bounds.size(), po2);
   const size_t n = (size_t)1 << po2;
   const trace::Tables& T = trace::trace_tables();
   memset(data_out, 0, (size_t)R0H_TRACE_COLUMNS * n * 4);  // the Montgomery form of 0 is 0
@@ -792,12 +895,12 @@ const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint3
       trace::live_row(rows[r], T, put, raw);
     } else if (r < rows.size() + bounds.size()) {
       const size_t j = r - rows.size();
-      trace::bound_row(bounds[j], j ? bounds[j - 1].addr : 0xffffffffu, T, put, raw);
+      trace::bound_row(bounds[j], j ? bounds[j - 1].addr : 0xffffffffu, info.index + 1, info.closing != 0, T, put, raw);
     } else {
       trace::blank_row(T, put, raw);
     }
   }
-  trace::trace_globals(rows.data(), rows.size(), globals_out);
+  trace::trace_globals(rows.data(), rows.size(), bounds.data(), bounds.size(), info.index + 1, info.closing != 0, info.pre.pc, globals_out);
   return nullptr;
   R0H_GUARD_END
 }

@@ -165,7 +165,7 @@ Fp4 constraint_at_z(const r0h_circuit& c, const Fp4& poly_mix, const std::vector
 }
 
 void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_t seal_words, uint32_t* po2_out, const uint32_t* expected_code_root,
-            uint32_t* code_root_out) {
+            uint32_t* code_root_out, uint32_t* data_root_out = nullptr) {
   SealReader io(k, seal, seal_words);
   {
     static const char proof_system_info[] = "RISC0_STARK:v1__";
@@ -179,7 +179,11 @@ void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_
   const uint32_t po2 = dec(global[c.n_global]);
   if (po2 < 9 || po2 > 24) throw Reject{R0H_VERIFY_BAD_PO2};
   if (po2_out) *po2_out = po2;
-  io.commit_elems(global, (size_t)c.n_global + 1);
+  {  // the early public inputs and po2 open the transcript; the late ones follow the DATA commitment
+    std::vector<uint32_t> early(global, global + (c.n_global - c.n_late));
+    early.push_back(global[c.n_global]);
+    io.commit_elems(early.data(), early.size());
+  }
   const size_t n = (size_t)1 << po2, domain = n * R0H_INV_RATE;
   const uint32_t n_taps = (uint32_t)c.taps.size(), n_regs = (uint32_t)c.regs.size(), n_combos = (uint32_t)c.combo_begin.size() - 1;
   const uint32_t n_u = n_taps + R0H_CHECK_SIZE;
@@ -192,6 +196,8 @@ void verify(const r0h_circuit& c, const P2Consts& k, const uint32_t* seal, size_
   if (code_root_out) memcpy(code_root_out, group[R0H_GROUP_CODE]->root(), 32);
   if (expected_code_root && memcmp(expected_code_root, group[R0H_GROUP_CODE]->root(), 32) != 0) throw Reject{R0H_VERIFY_CODE_ROOT};
   group[R0H_GROUP_DATA].reset(new TreeVerifier(io, domain, c.group_size[R0H_GROUP_DATA], R0H_VERIFY_MERKLE_GROUP));
+  if (data_root_out) memcpy(data_root_out, group[R0H_GROUP_DATA]->root(), 32);
+  if (c.n_late) io.commit_elems(global + (c.n_global - c.n_late), c.n_late);
   std::vector<uint32_t> mix(c.n_mix);
   for (uint32_t& m : mix) m = io.elem();
   group[R0H_GROUP_ACCUM].reset(new TreeVerifier(io, domain, c.group_size[R0H_GROUP_ACCUM], R0H_VERIFY_MERKLE_GROUP));
@@ -391,7 +397,7 @@ const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t di
 
 static const char* verify_entry(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
                                 const uint32_t* seal, size_t seal_words, const uint32_t* expected_code_root, int* verdict_out, uint32_t* po2_out,
-                                uint32_t* code_root_out) {
+                                uint32_t* code_root_out, uint32_t* data_root_out = nullptr) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(blob && (seal || seal_words == 0) && verdict_out, "r0h_verify_seal: NULL argument");
   R0H_REQUIRE((p2_round_constants == nullptr) == (p2_diag_m1 == nullptr), "r0h_verify_seal: pass both Poseidon2 tables or neither");
@@ -410,7 +416,7 @@ static const char* verify_entry(const uint32_t* blob, size_t blob_words, const u
   if (po2_out) *po2_out = 0;
   if (code_root_out) memset(code_root_out, 0, 32);
   try {
-    verify(c, *k, seal, seal_words, po2_out, expected_code_root, code_root_out);
+    verify(c, *k, seal, seal_words, po2_out, expected_code_root, code_root_out, data_root_out);
     *verdict_out = R0H_VERIFY_OK;
   } catch (const Reject& r) {
     *verdict_out = r.code;
@@ -428,6 +434,15 @@ const char* r0h_verify_seal_bound(const uint32_t* blob, size_t blob_words, const
                                   const uint32_t* seal, size_t seal_words, const uint32_t* expected_code_root, int* verdict_out,
                                   uint32_t* po2_out, uint32_t* code_root_out) {
   return verify_entry(blob, blob_words, p2_round_constants, p2_diag_m1, seal, seal_words, expected_code_root, verdict_out, po2_out, code_root_out);
+}
+
+// the same, also returning the DATA group's Merkle root as the seal's transcript recomputes it: what a session's common challenge is
+// derived from (csrc/claim.cpp)
+const char* r0h_verify_seal_roots(const uint32_t* blob, size_t blob_words, const uint32_t* seal, size_t seal_words, const uint32_t* expected_code_root, int* verdict_out,
+                                  uint32_t* po2_out, uint32_t* data_root_out) {
+  R0H_REQUIRE(data_root_out, "r0h_verify_seal_roots: NULL argument");
+  memset(data_root_out, 0, 32);
+  return verify_entry(blob, blob_words, nullptr, nullptr, seal, seal_words, expected_code_root, verdict_out, po2_out, nullptr, data_root_out);
 }
 
 // ---- the control root of a circuit's own CODE columns, on the host.  A verifier is handed control roots (risc0's has a table of
@@ -494,11 +509,13 @@ const char* r0h_control_root_host(const uint32_t* blob, size_t blob_words, const
   for (uint32_t col = 0; col < count; col++) {
     uint32_t* a = &evals[(size_t)col * m];
     const uint32_t kind = c.code_cols[col].kind, stream = (1u << 16) | col;  // the stream r0h_witgen draws CODE column `col` from
-    R0H_REQUIRE(kind <= 3, "r0h_control_root_host: CODE column %u has kind %u", col, kind);
+    R0H_REQUIRE(kind <= 5, "r0h_control_root_host: CODE column %u has kind %u", col, kind);
     for (size_t r = 0; r < n; r++) {
       if (kind == 0) a[r] = r == 0 ? ONE : 0u;
       else if (kind == 1) a[r] = r == n - 1 ? ONE : 0u;
       else if (kind == 2) a[r] = enc((uint32_t)r);
+      else if (kind == 4) a[r] = r < 65536 ? enc((uint32_t)r) : 0u;
+      else if (kind == 5) a[r] = enc(R0H_TAG_AND + (r < 65536 ? (uint32_t)r + 65536u * (((uint32_t)r & 255u) & ((uint32_t)r >> 8)) : 0u));
       else {
         const uint64_t h = splitmix64_h(seed ^ (((uint64_t)stream << 32) | (uint32_t)r));
         a[r] = (uint32_t)(((h >> 32) * (uint64_t)P) >> 32);

@@ -117,6 +117,7 @@ const char* r0h_scatter_slices(r0h_ctx* ctx, r0h_buf* into, const uint32_t* inde
                                const uint32_t* values, uint32_t n_values);
 const char* r0h_hash_fold_io(r0h_ctx* ctx, r0h_buf* io, uint32_t input_size, uint32_t output_size);
 const char* r0h_prefix_products(r0h_ctx* ctx, r0h_buf* io, uint32_t n);
+const char* r0h_prefix_sums(r0h_ctx* ctx, r0h_buf* io, uint32_t n); /* io[i] = sum_{j <= i} io[j] over extension elements (AoS), n a power of two */
 /* in-place synthetic division of an extension-coefficient polynomial (AoS, natural order) by (x - z) */
 const char* r0h_poly_divide(r0h_ctx* ctx, r0h_buf* poly, uint32_t n, const uint32_t z[4], uint32_t remainder[4]);
 
@@ -161,6 +162,15 @@ const char* r0h_proof_begin(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, co
 const char* r0h_proof_finish(r0h_proof* proof, const r0h_buf* accum, uint32_t* seal_out, size_t seal_capacity_words,
                              size_t* seal_words_out);
 const char* r0h_proof_abort(r0h_proof* proof);
+/* Late public inputs (blob section LATE: inputs that depend on commitments made outside this proof -- the trace circuit's session
+ * challenge, derived from the DATA roots of ALL segments, and the segment's sum under it).  For such a circuit r0h_proof_begin stops
+ * after the DATA commitment without drawing the mix: r0h_proof_data_root gives the root, r0h_proof_late takes the last n_late
+ * public inputs (the transcript absorbs them; the seal's opening block receives them) and draws the accumulation mix into mix_out.
+ * r0h_prove_segment[_committed] takes all public inputs at once and does the same internally.  r0h_proof_globals: all of them, as
+ * the proof holds them. */
+const char* r0h_proof_data_root(const r0h_proof* proof, uint32_t root_out[8]);
+const char* r0h_proof_late(r0h_proof* proof, const uint32_t* late_globals, uint32_t* mix_out);
+const char* r0h_proof_globals(const r0h_proof* proof, uint32_t* globals_out);
 /* Control root of a program at trace size 2^po2: Merkle root of the committed CODE group (count columns of 2^po2 words),
  * computed exactly as the sequencer commits it.  What a verifier passes to r0h_verify_seal_bound. */
 const char* r0h_code_root(r0h_ctx* ctx, const r0h_buf* code, uint32_t count, uint32_t po2, uint32_t root_out[8]);
@@ -173,6 +183,7 @@ typedef struct r0h_code_commit r0h_code_commit;
 const char* r0h_code_commit_new(r0h_ctx* ctx, const r0h_buf* code, uint32_t count, uint32_t po2, r0h_code_commit** out);
 const char* r0h_code_commit_free(r0h_code_commit* cc);
 const char* r0h_code_commit_root(const r0h_code_commit* cc, uint32_t root_out[8]); /* == r0h_code_root of the same columns */
+const char* r0h_code_commit_columns(const r0h_code_commit* cc, const r0h_buf** columns_out); /* the committed columns themselves (device; owned by cc) */
 const char* r0h_prove_segment_committed(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_code_commit* code,
                                         const r0h_buf* data, const uint32_t* global_host, uint32_t* seal_out,
                                         size_t seal_capacity_words, size_t* seal_words_out);
@@ -209,6 +220,10 @@ const char* r0h_verify_seal_bound(const uint32_t* blob, size_t blob_words, const
                                   const uint32_t* p2_diag_m1, const uint32_t* seal, size_t seal_words,
                                   const uint32_t* expected_code_root, int* verdict_out, uint32_t* po2_out,
                                   uint32_t* code_root_out);
+/* the same, also giving the DATA group's Merkle root as the seal's transcript recomputes it (the session challenge of the trace
+ * circuit is derived from these roots: csrc/claim.cpp) */
+const char* r0h_verify_seal_roots(const uint32_t* blob, size_t blob_words, const uint32_t* seal, size_t seal_words,
+                                  const uint32_t* expected_code_root, int* verdict_out, uint32_t* po2_out, uint32_t* data_root_out);
 /* The control root of a circuit's own CODE columns at trace size 2^po2, computed on the HOST from the blob alone (circuits with a
  * column program: the CODE columns r0h_witgen generates) -- the same 8 words as r0h_code_root / r0h_code_commit_root on the device.
  * A verifier that has the circuit need not be told its control roots (risc0's verifier has them compiled in).  Seconds at po2 = 20. */
@@ -394,6 +409,7 @@ typedef struct {
 } r0h_vm_limits;
 typedef struct {
   uint32_t index, exit_system, exit_user, pages_in, pages_out, boundary_rows;
+  uint32_t closing, reserved; /* closing = 1: the boundary rows of this segment close the session (see r0h_preflight_bound) */
   uint64_t user_cycles, paging_cycles;
   r0h_system_state pre, post; /* pc + Merkle root of memory before the first and after the last instruction of the segment */
 } r0h_vm_segment;
@@ -416,7 +432,14 @@ typedef struct {
 /* One per register / memory word a segment touched, in increasing address order: the value the segment found there, the value it
  * left, and the timestamp of its last access.  addr: word index (byte address / 4) for memory, R0H_REG_BASE + i for x[i]. */
 #define R0H_REG_BASE 0x10000000u
-typedef struct { uint32_t addr, first_value, last_value, last_ts; } r0h_preflight_bound;
+#define R0H_BOUND_IMAGE 1u
+/* prev_seg: the number (index + 1) of the segment that last touched the address before this one, 0 if none did.  In a CLOSING
+ * segment (the run's last, or segments of boundary rows only that follow it when those do not fit) there is a row for every word
+ * and register the session touched and for every word of the program image, touched or not: init_value is what the address held
+ * when the run began (the image's word, or zero) and flags says whether it is an image word. */
+typedef struct { uint32_t addr, first_value, last_value, last_ts, prev_seg, init_value, flags, reserved; } r0h_preflight_bound;
+/* the journal is a window of guest memory: journal word i is the word at R0H_JOURNAL_BASE + 4 i when COMMIT names it */
+#define R0H_JOURNAL_BASE 0x20000000u
 #define R0H_VM_HALTED 0
 #define R0H_VM_PAUSED 1
 #define R0H_VM_LIMIT 2
@@ -475,8 +498,13 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
  * (R0H_TRACE_GLOBALS): 8 words naming the segment's ReceiptClaim (r0h_claim_globals), first pc, pc after the last cycle, number of
  * cycles, how the segment ends (0: cut, 1: HALT, 2: PAUSE -- such an ecall is the last cycle of its segment), that being non-zero,
  * the two halves of the exit code (a0); r0h_receipt_verify holds them against the claim's pcs and ExitCode.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
-#define R0H_TRACE_COLUMNS 288
-#define R0H_TRACE_GLOBALS 15
+#define R0H_TRACE_COLUMNS 138
+#define R0H_TRACE_GLOBALS 40
+#define R0H_TRACE_LATE_GLOBALS 20 /* the last 20 public inputs: the session's challenge (16 words) and the segment's sum under it (4) */
+#define R0H_TRACE_GAMMA 20         /* where the session challenge sits among the public inputs; the segment's sum follows at 36 */
+#define R0H_TRACE_SUM 36
+#define R0H_SESSION_RECORD_WORDS 28 /* what a segment contributes to the session challenge: its 20 early public inputs, its DATA root */
+#define R0H_TRACE_MIN_PO2 16      /* the lookup tables have 2^16 rows */
 #define R0H_TRACE_MAX_PO2 21
 const char* r0h_trace_column_name(uint32_t column); /* static string; NULL past the last column */
 /* host reference of the witness (what tests compare the device kernel with): data_out = R0H_TRACE_COLUMNS * 2^po2 words;
@@ -485,8 +513,20 @@ const char* r0h_vm_trace_witness(const r0h_vm* vm, size_t i, uint32_t po2, uint3
 /* the same on the device: the compact rows (72 B per cycle, 16 B per boundary row) are uploaded and one thread per row expands
  * them into the column-major Montgomery DATA group in `data` (R0H_TRACE_COLUMNS * 2^po2 words).  Stream-ordered; the host arrays
  * may be released when the call returns. */
+typedef struct { uint32_t number /* index + 1 */, closing, idle_pc /* where a segment without cycles stands */, reserved; } r0h_trace_segment;
 const char* r0h_trace_witgen(r0h_ctx* ctx, const r0h_preflight_row* rows, size_t n_rows, const r0h_preflight_bound* bounds,
-                             size_t n_bounds, uint32_t po2, r0h_buf* data, uint32_t globals_out[R0H_TRACE_GLOBALS]);
+                             size_t n_bounds, uint32_t po2, const r0h_trace_segment* segment, r0h_buf* data,
+                             uint32_t globals_out[R0H_TRACE_GLOBALS]);
+/* ---- the log-derivative argument of a circuit (blob section LOGUP): lookups, memory tuples, session tuples as fractions of running
+ * sums in ACCUM.  Multiplicities: the table columns of DATA are filled from the lookups the rows make -- BEFORE the DATA group is
+ * committed (r0h_trace_witgen and r0h_vm_trace_witness leave them zero).  Totals: the accumulators whose challenges are public inputs
+ * (the trace circuit's session sum) are summed over the rows and written into global_io where the circuit reads them -- once those
+ * challenges are known, before r0h_proof_late.  r0h_accum_public is r0h_accum for circuits whose accumulation reads public inputs. */
+const char* r0h_logup_multiplicities(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, r0h_buf* data, const uint32_t* global);
+const char* r0h_logup_multiplicities_host(const uint32_t* blob, size_t blob_words, uint32_t po2, uint32_t* data, const uint32_t* global);
+const char* r0h_logup_totals(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data, uint32_t* global_io);
+const char* r0h_accum_public(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data,
+                             const uint32_t* global, const uint32_t* mix, r0h_buf* accum);
 const char* r0h_vm_journal(const r0h_vm* vm, const uint8_t** bytes, size_t* n);
 /* the ReceiptClaim of segment i: system states and exit code from the run, Output{journal} on the last segment */
 const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* out);
@@ -512,6 +552,20 @@ const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf
 const char* r0h_prove_elf_part(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words,
                                size_t n_input, uint32_t segment_po2, uint64_t max_cycles, uint32_t part, uint32_t parts,
                                r0h_receipt** receipt_out, uint8_t image_id_out[32], uint64_t* cycles_out);
+/* The two phases of a trace-circuit session, for ranks that share one (r0h_prove_elf is begin + finish on one rank): `begin` executes
+ * the guest and commits the DATA group of this rank's segments (part, part + parts, ...); `records` gives what they contribute to the
+ * session challenge; the ranks exchange their records (28 words per segment: an all-gather); `finish` takes the records of ALL
+ * segments in index order, derives the challenge, finishes this rank's proofs and returns their receipt (r0h_receipt_merge joins
+ * the ranks' receipts).  A session holds device memory (about 3 GiB per 2^20-row segment) until it is finished or freed. */
+typedef struct r0h_session r0h_session;
+const char* r0h_session_begin(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words,
+                              size_t n_input, uint32_t segment_po2, uint64_t max_cycles, uint32_t part, uint32_t parts,
+                              r0h_session** session_out);
+size_t r0h_session_n_segments(const r0h_session* s); /* of the whole session */
+const char* r0h_session_records(const r0h_session* s, uint32_t* indices_out, uint32_t* records_out, size_t capacity, size_t* n_out);
+const char* r0h_session_finish(r0h_session* s, const uint32_t* all_records, size_t n_records, r0h_receipt** receipt_out,
+                               uint8_t image_id_out[32], uint64_t* cycles_out);
+const char* r0h_session_free(r0h_session* s);
 /* composite receipts that each hold some segments of one session -> one receipt with all of them in index order.  Refused: a
  * segment index missing or present twice, journals that differ, a receipt that is not composite. */
 const char* r0h_receipt_merge(const r0h_receipt* const* parts, size_t n, r0h_receipt** out);

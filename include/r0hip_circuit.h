@@ -16,7 +16,8 @@
  *                  4 ADD / 5 SUB / 6 MUL a,b=fp vars                      7 TRUE
  *                  8 AND_EQZ a=mix var, b=fp var                          9 AND_COND a=mix var, b=fp var, c=inner mix var
  *                fp vars and mix vars are numbered separately in creation order (risc0-zkp adapter.rs PolyExtStep)
- *   WITGEN  (5): [optional, with ACCUM: the synthetic column program; circuits imported from risc0 omit both] n_code, (kind, param) per CODE column: 0 first-row flag, 1 last-row flag, 2 row counter, 3 fixed random;
+ *   WITGEN  (5): [optional, with ACCUM: the synthetic column program; circuits imported from risc0 omit both] n_code, (kind, param) per CODE column: 0 first-row flag, 1 last-row flag, 2 row counter, 3 fixed random,
+ *                4 the 16-bit range table (row r < 2^16: r, else 0), 5 the byte-AND table (row r = a + 256 b < 2^16: 2^24 + r + 65536 (a & b), else 2^24);
  *                n_data, (kind, a, b, c, e) per DATA column: 0 seeded random, 1 a*b+e, 2 a*b*c+e with refs
  *                ref = group<<28 | back<<20 | column (group 1 or 2; DATA refs point at lower-numbered columns)
  *   INFO    (7): optional, 4 words = the circuit's 16-byte ProtocolInfo tag committed into the transcript (risc0 `CIRCUIT_INFO`)
@@ -26,6 +27,19 @@
  *                n_f (1..3) and three (addr, lo, hi, t) quadruples of DATA columns; extension column j is the running product
  *                from row 0 of prod_{f < n_f} (alpha - addr_f - b1 lo_f - b2 hi_f - b3 t_f) with alpha = mix[0..4),
  *                b1 = mix[4..8), b2 = mix[8..12), b3 = mix[12..16) shared by all accumulators (n_mix = 16)
+ *   LATE    (9): n_late: the last n_late public inputs are absorbed by the transcript AFTER the DATA group is committed (and before
+ *                the accumulation mix is drawn) instead of at the start -- inputs that depend on commitments made outside this proof
+ *                (the trace circuit's session-wide challenge and the segment's sum under it)
+ *   LOGUP  (10): [instead of ACCUM: a log-derivative argument -- lookups, memory tuples, session tuples] n_acc, n_tables, then
+ *                (DATA column, kind) per looked-up table (the column receives the multiplicities; kind 1 = range-16, 2 = byte-AND),
+ *                then per accumulator: n_fractions (<= 4), final (0xffffffff: a link of the chain; else the index of the first of
+ *                the four public inputs its total is), and per fraction: table (0 none / 1 / 2: a lookup into that table, whose
+ *                value is minus the form of part 1 [minus 2^24 for kind 2]), the numerator (a linear form), n_parts, and per
+ *                part (challenge kind 0 one / 1 mix element / 2 four public inputs, its index, a linear form): the denominator is
+ *                the sum over parts of challenge x form.  A linear form is n_terms x (canonical coefficient, public input + 1 or
+ *                0, column ref + 1 or 0 for the constant one), ref = group << 28 | column.  Extension column j (ACCUM columns
+ *                4j..4j+3): chain links run ONE sum through the row's accumulators and on through the rows, wrapping around the
+ *                end of the trace (so its total is zero); an accumulator with a public total runs alone and wraps with it
  */
 #ifndef R0HIP_CIRCUIT_H
 #define R0HIP_CIRCUIT_H
@@ -38,6 +52,11 @@
 #define R0H_SEC_ACCUM 6
 #define R0H_SEC_INFO 7
 #define R0H_SEC_ACCUM_FP 8
+#define R0H_SEC_LATE 9
+#define R0H_SEC_LOGUP 10
+#define R0H_TABLE_R16 1
+#define R0H_TABLE_AND 2
+#define R0H_TAG_AND (1u << 24)
 #define R0H_OP_CONST 0
 #define R0H_OP_GET 2
 #define R0H_OP_GET_GLOBAL 3

@@ -225,7 +225,7 @@ def test_loads_stores_branches_and_jumps():
 
 def _guest(n_loop):
     """reads two input words, loops n_loop times doing memory traffic over several pages, commits two words, halts with 0"""
-    buf, scratch = 0x10000, 0x20000
+    buf, scratch = r0.JOURNAL_BASE, 0x20000  # (the buffer is the head of the journal window: COMMIT names words there)
     return flat(LI(A0, buf), ADDI(A1, 0, 2), ADDI(A7, 0, 1), ECALL,              # READ_WORDS(buf, 2)
                 LI(S0, scratch), LI(T2, n_loop), ADDI(T1, 0, 0),
                 # loop body: store counter at scratch + (t1 & 0xFFC) * 16 (walks pages), accumulate

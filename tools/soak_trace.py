@@ -57,8 +57,9 @@ def random_program(rng, n):
     body += [ADDI(0, 0, 0)] * 3  # landing room for the last forward jumps
     loop = flat(body, ADDI(29, 29, -1), B(-4 * (len(body) + 1), 0, 29, 1))
     n_io = int(rng.integers(0, 9))
-    io = flat(LI(A0, 0x50000), ADDI(11, 0, n_io), ADDI(A7, 0, 1), ECALL,                  # READ_WORDS(0x50000, n_io)
-              LI(A0, 0x50004), ADDI(11, 0, max(0, n_io - 1)), ADDI(A7, 0, 2), ECALL)            # COMMIT(0x50004, n_io - 1)
+    jb = 0x20000000  # R0H_JOURNAL_BASE: COMMIT names words of the journal window, word i at jb + 4 i
+    io = flat(LI(A0, jb), ADDI(11, 0, n_io), ADDI(A7, 0, 1), ECALL,                        # READ_WORDS(jb, n_io)
+              LI(A0, jb), ADDI(11, 0, max(0, n_io - 1)), ADDI(A7, 0, 2), ECALL)               # COMMIT(jb, n_io - 1)
     return flat(LI(28, 0x40000), ADDI(29, 0, int(rng.integers(1, 7))), loop, io, ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL)
 
 
