@@ -104,6 +104,7 @@ _SIGNATURES = {
     "r0h_receipt_add_segment_claim": [_vp, _vp, _sz, _u32, _vp, _vp],
     "r0h_receipt_segment_claim": [_vp, _sz, _vp, _c.POINTER(_c.c_int)],
     "r0h_receipt_verify": [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_c.c_int), _c.POINTER(_sz), _c.POINTER(_c.c_int)],
+    "r0h_receipt_verify_elf": [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _c.POINTER(_c.c_int), _c.POINTER(_sz), _c.POINTER(_c.c_int)],
     "r0h_sha256": [_vp, _sz, _vp],
     "r0h_image_id_from_hex": [_cp, _vp],
     "r0h_image_id_to_hex": [_vp, _vp],
@@ -906,9 +907,11 @@ class Receipt:
             out.append(c if has.value else None)
         return out
 
-    def verify(self, blob, control_roots, image_id):
+    def verify(self, blob, control_roots, image_id, elf=None):
         """`receipt.verify(image_id)` (r0h_receipt_verify): control_roots = {po2: root[8]}; image_id is required, as it is in the
-        reference (None is passed through and yields verdict 12 "not tied to a program", never 0).  Returns (verdict, reason,
+        reference (None is passed through and yields verdict 12 "not tied to a program", never 0).  A receipt over the trace circuit
+        binds its program through the session sum: give the ELF (r0h_receipt_verify_elf: its image id is derived, image_id is then
+        ignored); with an image id alone the verdict is at best 15 "the program image was not given".  Returns (verdict, reason,
         segment, seal verdict)."""
         b, pb = _u32arr(blob)
         table = np.zeros(9 * max(len(control_roots), 1), dtype=np.uint32)
@@ -916,8 +919,13 @@ class Receipt:
             table[9 * k] = po2
             table[9 * k + 1:9 * k + 9] = root
         verdict, seg, sv = _c.c_int(-1), _sz(0), _c.c_int(0)
-        _check(lib().r0h_receipt_verify(self.handle, pb, b.size, table.ctypes.data_as(_vp), len(control_roots), None if image_id is None else bytes(image_id),
-                                        ctypes.byref(verdict), ctypes.byref(seg), ctypes.byref(sv)))
+        if elf is not None:
+            elf = bytes(elf)
+            _check(lib().r0h_receipt_verify_elf(self.handle, pb, b.size, table.ctypes.data_as(_vp), len(control_roots), elf, len(elf),
+                                                ctypes.byref(verdict), ctypes.byref(seg), ctypes.byref(sv)))
+        else:
+            _check(lib().r0h_receipt_verify(self.handle, pb, b.size, table.ctypes.data_as(_vp), len(control_roots), None if image_id is None else bytes(image_id),
+                                            ctypes.byref(verdict), ctypes.byref(seg), ctypes.byref(sv)))
         return verdict.value, lib().r0h_receipt_verify_reason(verdict.value).decode(), seg.value, sv.value
 
     @property
@@ -948,6 +956,43 @@ class Receipt:
     def close(self):
         if self.handle:
             lib().r0h_receipt_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Session:
+    """A session between its two phases (r0h_session_*): this rank's segments are committed; the proofs wait for the challenge that
+    the records of ALL segments determine."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @property
+    def n_segments(self):
+        return lib().r0h_session_n_segments(self.handle)
+
+    def records(self):
+        """(indices, records [k, SESSION_RECORD_WORDS]) of this rank's segments"""
+        cap = self.n_segments + 1
+        idx, rec, n = np.zeros(cap, np.uint32), np.zeros((cap, SESSION_RECORD_WORDS), np.uint32), _sz(0)
+        _check(lib().r0h_session_records(self.handle, idx.ctypes.data_as(_vp), rec.ctypes.data_as(_vp), cap, ctypes.byref(n)))
+        return idx[:n.value].copy(), rec[:n.value].copy()
+
+    def finish(self, all_records):
+        """all_records: [n_segments, SESSION_RECORD_WORDS] in index order.  Returns (Receipt of this rank's segments, image id, cycles)."""
+        rec = np.ascontiguousarray(all_records, dtype=np.uint32).reshape(-1, SESSION_RECORD_WORDS)
+        h, image_id, cycles = _vp(), (ctypes.c_uint8 * 32)(), _u64(0)
+        _check(lib().r0h_session_finish(self.handle, rec.ctypes.data_as(_vp), rec.shape[0], ctypes.byref(h), image_id, ctypes.byref(cycles)))
+        return Receipt(h), bytes(image_id), cycles.value
+
+    def close(self):
+        if self.handle:
+            lib().r0h_session_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -1118,16 +1163,22 @@ class Hal:
         _check(lib().r0h_witgen(self.ctx, circuit.handle, po2, seed, code.handle, data.handle, glob.ctypes.data_as(_vp)))
         return code, data, glob[:circuit.n_global]
 
-    def trace_witgen(self, rows, bounds, po2, claim_globals=None, into=None):
+    def trace_witgen(self, rows, bounds, po2, claim_globals=None, into=None, number=1, closing=True, idle_pc=0, circuit=None):
         """DATA group of the trace circuit expanded ON THE DEVICE from the compact preflight rows (r0h_trace_witgen): rows [n, 18]
-        and bounds [m, 4] uint32 (Vm.preflight_arrays).  Returns (Buf of TRACE_COLUMNS * 2^po2 words, the TRACE_GLOBALS public inputs)."""
+        and bounds [m, 8] uint32 (Vm.preflight_arrays); number / closing: the segment's number in its session and whether its
+        boundary rows close it.  With `circuit` (the loaded trace circuit) the lookup tables' multiplicity columns are filled too
+        (r0h_logup_multiplicities); without, they stay zero.  Returns (Buf of TRACE_COLUMNS * 2^po2 words, the TRACE_GLOBALS public
+        inputs -- the late ones zero)."""
         rows = np.ascontiguousarray(rows, dtype=np.uint32).reshape(-1, 18)
-        bounds = np.ascontiguousarray(bounds, dtype=np.uint32).reshape(-1, 4)
+        bounds = np.ascontiguousarray(bounds, dtype=np.uint32).reshape(-1, 8)
         data = into if into is not None else self.alloc(TRACE_COLUMNS << po2)
         glob = np.zeros(TRACE_GLOBALS, dtype=np.uint32)
+        seg = TraceSegment(number, 1 if closing else 0, idle_pc, 0)
         try:
-            _check(lib().r0h_trace_witgen(self.ctx, rows.ctypes.data_as(_vp), rows.shape[0], bounds.ctypes.data_as(_vp), bounds.shape[0], po2, data.handle,
-                                          glob.ctypes.data_as(_vp)))
+            _check(lib().r0h_trace_witgen(self.ctx, rows.ctypes.data_as(_vp), rows.shape[0], bounds.ctypes.data_as(_vp), bounds.shape[0], po2, ctypes.byref(seg),
+                                          data.handle, glob.ctypes.data_as(_vp)))
+            if circuit is not None:
+                _check(lib().r0h_logup_multiplicities(self.ctx, circuit.handle, po2, data.handle, glob.ctypes.data_as(_vp)))
         except R0HipError:
             if into is None:
                 data.free()
@@ -1148,6 +1199,24 @@ class Hal:
         out = self.alloc(circuit.group_size[GROUP_ACCUM] * n)
         _check(lib().r0h_accum(self.ctx, circuit.handle, po2, code.handle, data.handle, pm, out.handle))
         return out
+
+    def accum_public(self, circuit, po2, code, data, glob, mix):
+        """r0h_accum for a circuit whose accumulation reads public inputs (the log-derivative argument of the trace circuit)"""
+        n = 1 << po2
+        g, pg = _u32arr(glob)
+        m, pm = _u32arr(mix)
+        out = self.alloc(circuit.group_size[GROUP_ACCUM] * n)
+        _check(lib().r0h_accum_public(self.ctx, circuit.handle, po2, code.handle, data.handle, pg, pm, out.handle))
+        return out
+
+    def logup_totals(self, circuit, po2, code, data, glob):
+        """the public inputs with the totals of the accumulators that run under public challenges filled in (r0h_logup_totals)"""
+        g = np.ascontiguousarray(glob, dtype=np.uint32).copy()
+        _check(lib().r0h_logup_totals(self.ctx, circuit.handle, po2, code.handle, data.handle, g.ctypes.data_as(_vp)))
+        return g
+
+    def prefix_sums(self, io, n):
+        _check(lib().r0h_prefix_sums(self.ctx, io.handle, n))
 
     def eval_check(self, circuit, po2, eval_accum, eval_code, eval_data, glob, mix, poly_mix):
         g, pg = _u32arr(glob)
@@ -1208,6 +1277,15 @@ class Hal:
         _check(lib().r0h_prove_elf_part(self.ctx, circuit.handle, elf, len(elf), pw, len(input_words), segment_po2, max_cycles, part, parts, ctypes.byref(h),
                                         image_id, ctypes.byref(cycles)))
         return Receipt(h), bytes(image_id), cycles.value
+
+    def session_begin(self, circuit, elf, input_words, segment_po2=20, max_cycles=0, part=0, parts=1):
+        """Phase 1 of a session some ranks share (r0h_session_begin): executes the guest and commits this rank's segments.  Returns a
+        Session: .records() is what its segments contribute to the session challenge, .finish(all records) the rank's receipt."""
+        elf = bytes(elf)
+        w, pw = _u32arr(input_words if len(input_words) else [0])
+        h = _vp()
+        _check(lib().r0h_session_begin(self.ctx, circuit.handle, elf, len(elf), pw, len(input_words), segment_po2, max_cycles, part, parts, ctypes.byref(h)))
+        return Session(h)
 
     def last_session_stats(self):
         """Stage timing of the last prove_elf on this context (r0h_last_session_stats)."""

@@ -24,6 +24,7 @@
 
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/r0hip.h"
@@ -239,13 +240,17 @@ const char* r0h_receipt_verify_reason(int verdict) {
                                       "the journal is not the one the last segment's claim commits to", "the first pre-state is not the expected image id",
                                       "the final exit code is not Halted(0) or Paused(0)", "the circuit exposes fewer than 8 globals: claims cannot be bound",
                                       "a segment names a hash function other than poseidon2",
-                                      "seals, claims and chain are valid but no image id was given: nothing ties the receipt to a program"};
-  return verdict >= 0 && verdict <= R0H_RECEIPT_V_UNBOUND ? names[verdict] : "unknown";
+                                      "seals, claims and chain are valid but no image id was given: nothing ties the receipt to a program",
+                                      "a seal's session number, closing flag or challenge is not this session's",
+                                      "the segments' session sums do not balance with the program image and the journal",
+                                      "seals, claims, chain and image id are valid, but the program image (the ELF) was not given: the session sum is unchecked"};
+  return verdict >= 0 && verdict <= R0H_RECEIPT_V_NEEDS_IMAGE ? names[verdict] : "unknown";
 }
 
 // risc0-zkvm receipt/composite.rs `verify_integrity_with_context` + receipt/mod.rs `Receipt::verify(image_id)`
-const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots, size_t n_roots,
-                               const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out) {
+static const char* receipt_verify_impl(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots, size_t n_roots,
+                                       const uint8_t* image_id, const std::vector<std::pair<uint32_t, uint32_t>>* image, int* verdict_out, size_t* segment_out,
+                                       int* seal_verdict_out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(rc && blob && verdict_out && (control_roots || !n_roots), "r0h_receipt_verify: NULL argument");
   if (segment_out) *segment_out = 0;
@@ -256,9 +261,16 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
   R0H_TRY(parse_blob(&circ, blob, blob_words));
   if (circ.n_global < 8) return done(R0H_RECEIPT_V_NO_BINDING, 0);
   const size_t n = rc->segments.size();
-  const bool trace_circuit = !memcmp(circ.info, "R0HIP_TRACE:v3__", 16);  // its seals also carry the first and last pc of the segment
+  // the trace circuit's seals also carry the first and last pc of the segment, how it ends, and the session's public inputs
+  const bool trace_circuit = !memcmp(circ.info, "R0HIP_TRACE:v4__", 16) && circ.n_global == R0H_TRACE_GLOBALS && circ.n_late == R0H_TRACE_LATE_GLOBALS;
   for (size_t i = 0; i < n; i++)  // before any claim is read (the chain check below looks one segment ahead)
     if (!rc->segments[i].has_claim) return done(R0H_RECEIPT_V_NO_CLAIM, i);
+  // the segment that ends the run: the first whose claim is Halted / Paused; what follows it can only be rows that close the session
+  size_t term = n - 1;
+  for (size_t i = 0; i < n; i++)
+    if (rc->segments[i].claim.exit_system <= 1) { term = i; break; }
+  if (!trace_circuit && term != n - 1) return done(R0H_RECEIPT_V_CHAIN, term + 1);
+  std::vector<uint32_t> records(trace_circuit ? n * R0H_SESSION_RECORD_WORDS : 0);
   for (size_t i = 0; i < n; i++) {
     const r0h_receipt::Segment& g = rc->segments[i];
     if (g.hashfn != "poseidon2") return done(R0H_RECEIPT_V_HASHFN, i);  // the only suite this prover and this verifier implement
@@ -273,7 +285,8 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
       if (control_roots[9 * k] == po2) root = control_roots + 9 * k + 1;
     if (!root) return done(R0H_RECEIPT_V_NO_CONTROL_ROOT, i);
     int sv = -1;
-    R0H_TRY(r0h_verify_seal_bound(blob, blob_words, nullptr, nullptr, g.seal.data(), g.seal.size(), root, &sv, nullptr, nullptr));
+    uint32_t data_root[8];
+    R0H_TRY(r0h_verify_seal_roots(blob, blob_words, g.seal.data(), g.seal.size(), root, &sv, nullptr, data_root));
     if (sv != R0H_VERIFY_OK) {
       if (seal_verdict_out) *seal_verdict_out = sv;
       return done(R0H_RECEIPT_V_SEAL, i);
@@ -287,31 +300,117 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
     // the trace circuit proves a run from its public first pc to its public last pc: they are the claim's
     // ... and it ends in a HALT / PAUSE ecall exactly when its public inputs say so, with the exit code they carry: the claim's ExitCode
     if (trace_circuit) {
-      if (circ.n_global < R0H_TRACE_GLOBALS || g.seal[8] != enc(g.claim.pre.pc) || g.seal[9] != enc(g.claim.post.pc)) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
+      if (g.seal[8] != enc(g.claim.pre.pc) || g.seal[9] != enc(g.claim.post.pc)) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
       const uint32_t kind = g.claim.exit_system == 0 ? 1u : g.claim.exit_system == 1 ? 2u : 0u, code = kind ? g.claim.exit_user : 0u;
       if (g.seal[11] != enc(kind) || g.seal[12] != enc(kind ? 1u : 0u) || g.seal[13] != enc(code & 0xffffu) || g.seal[14] != enc(code >> 16)) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
+      memcpy(&records[i * R0H_SESSION_RECORD_WORDS], g.seal.data(), (R0H_TRACE_GLOBALS - R0H_TRACE_LATE_GLOBALS) * 4);
+      memcpy(&records[i * R0H_SESSION_RECORD_WORDS + (R0H_TRACE_GLOBALS - R0H_TRACE_LATE_GLOBALS)], data_root, 32);
     }
-    // composite.rs: indices count up, every segment but the last ends in SystemSplit with no output, and hands its post-state on
+    // composite.rs: indices count up, every segment before the one that ends the run ends in SystemSplit with no output, and hands its
+    // post-state on; a segment after it has no cycles (trace circuit: the rows that close the session) and stands where the run stopped
     if (g.index != i) return done(R0H_RECEIPT_V_CHAIN, i);
+    static const uint8_t zero[32] = {0};
+    if (i != term && (g.claim.exit_system != 2 || g.claim.exit_user != 0 || memcmp(g.claim.output_digest, zero, 32) != 0)) return done(R0H_RECEIPT_V_CHAIN, i);
     if (i + 1 < n) {
-      static const uint8_t zero[32] = {0};
-      if (g.claim.exit_system != 2 || g.claim.exit_user != 0 || memcmp(g.claim.output_digest, zero, 32) != 0) return done(R0H_RECEIPT_V_CHAIN, i);
       uint8_t a[32], b[32];
       system_state_digest(g.claim.post, a);
       system_state_digest(rc->segments[i + 1].claim.pre, b);
       if (memcmp(a, b, 32) != 0) return done(R0H_RECEIPT_V_CHAIN, i + 1);
     }
+    if (i > term) {
+      uint8_t a[32], b[32];
+      system_state_digest(g.claim.pre, a);
+      system_state_digest(g.claim.post, b);
+      if (memcmp(a, b, 32) != 0 || g.seal[10] != 0) return done(R0H_RECEIPT_V_CHAIN, i);
+    }
   }
-  const r0h_receipt_claim& last = rc->segments[n - 1].claim;
-  if (!(last.exit_system <= 1 && last.exit_user == 0)) return done(R0H_RECEIPT_V_EXIT_CODE, n - 1);
+  const r0h_receipt_claim& last = rc->segments[term].claim;
+  if (!(last.exit_system <= 1 && last.exit_user == 0)) return done(R0H_RECEIPT_V_EXIT_CODE, term);
   uint8_t out[32];
   R0H_TRY(r0h_output_digest(rc->journal.data(), rc->journal.size(), nullptr, out));
-  if (memcmp(out, last.output_digest, 32) != 0) return done(R0H_RECEIPT_V_JOURNAL, n - 1);
+  if (memcmp(out, last.output_digest, 32) != 0) return done(R0H_RECEIPT_V_JOURNAL, term);
+  if (trace_circuit) {
+    // ---- the session: numbers, closing segments, the common challenge
+    uint32_t challenge[16];
+    session_challenge(records.data(), n, challenge);
+    bool closing_seen = false;
+    uint32_t closed_up_to = 0;
+    for (size_t i = 0; i < n; i++) {
+      const std::vector<uint32_t>& sl = rc->segments[i].seal;
+      const uint32_t fin = sl[16];
+      if (sl[15] != enc((uint32_t)i + 1) || (fin != 0 && fin != ONE) || sl[17] != (fin ? 0u : sl[15])) return done(R0H_RECEIPT_V_SESSION, i);
+      if (memcmp(&sl[R0H_TRACE_GAMMA], challenge, 64) != 0) return done(R0H_RECEIPT_V_SESSION, i);
+      // closing segments: the one that ends the run when it is the last, else every segment after it; their rows go up through the addresses
+      const bool must_close = term == n - 1 ? i == term : i > term;
+      if ((fin != 0) != must_close) return done(R0H_RECEIPT_V_SESSION, i);
+      if (fin) {
+        const uint32_t lo = dec(sl[18]), hi = dec(sl[19]);
+        if (closing_seen && lo <= closed_up_to) return done(R0H_RECEIPT_V_SESSION, i);
+        if (hi < lo) return done(R0H_RECEIPT_V_SESSION, i);
+        closing_seen = true;
+        closed_up_to = hi;
+      }
+    }
+    if (!image) {
+      if (!image_id) return done(R0H_RECEIPT_V_UNBOUND, 0);
+      uint8_t pre[32];
+      system_state_digest(rc->segments[0].claim.pre, pre);
+      if (memcmp(pre, image_id, 32) != 0) return done(R0H_RECEIPT_V_IMAGE_ID, 0);
+      return done(R0H_RECEIPT_V_NEEDS_IMAGE, 0);
+    }
+    // ---- the balance: sum of the segments' sums = sum over the image's words + sum over the journal's words of 1 / fingerprint
+    const Fp4 ag{{challenge[0], challenge[1], challenge[2], challenge[3]}}, g1{{challenge[4], challenge[5], challenge[6], challenge[7]}},
+        g2{{challenge[8], challenge[9], challenge[10], challenge[11]}}, g3{{challenge[12], challenge[13], challenge[14], challenge[15]}};
+    Fp4 total = fp4_zero();
+    for (size_t i = 0; i < n; i++) {
+      const uint32_t* q = &rc->segments[i].seal[R0H_TRACE_SUM];
+      total = total + Fp4{{q[0], q[1], q[2], q[3]}};
+    }
+    // batched inversion: the fingerprints are multiplied up, one inversion, and walked back
+    std::vector<Fp4> fps;
+    fps.reserve(image->size() + rc->journal.size() / 4);
+    auto fingerprint = [&](uint32_t addr, uint32_t word, uint32_t tag) {
+      Fp4 f = ag - scale(g1, enc(word & 0xffffu)) - scale(g2, enc(word >> 16)) - scale(g3, enc(tag));
+      f.e[0] = sub(f.e[0], enc(addr));
+      fps.push_back(f);
+    };
+    for (const auto& w : *image) fingerprint(w.first, w.second, R0H_SESSION_TAG_IMAGE);
+    if (rc->journal.size() % 4) return done(R0H_RECEIPT_V_JOURNAL, term);  // COMMIT moves words
+    for (size_t j = 0; j < rc->journal.size() / 4; j++) {
+      const uint8_t* b = &rc->journal[4 * j];
+      fingerprint(R0H_JOURNAL_BASE / 4 + (uint32_t)j, (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24, R0H_SESSION_TAG_JOURNAL);
+    }
+    std::vector<Fp4> prefix(fps.size() + 1, fp4_one());
+    for (size_t k = 0; k < fps.size(); k++) prefix[k + 1] = prefix[k] * fps[k];
+    Fp4 inv_run = fp4_inv(prefix[fps.size()]), other = fp4_zero();
+    for (size_t k = fps.size(); k-- > 0;) {
+      other = other + inv_run * prefix[k];
+      inv_run = inv_run * fps[k];
+    }
+    if (!(total == other)) return done(R0H_RECEIPT_V_SESSION_SUM, 0);
+  }
   if (!image_id) return done(R0H_RECEIPT_V_UNBOUND, 0);  // `receipt.verify(image_id)` always names the program: without it this is not OK
   uint8_t pre[32];
   system_state_digest(rc->segments[0].claim.pre, pre);
   if (memcmp(pre, image_id, 32) != 0) return done(R0H_RECEIPT_V_IMAGE_ID, 0);
   return done(R0H_RECEIPT_V_OK, 0);
+  R0H_GUARD_END
+}
+
+const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots, size_t n_roots,
+                               const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out) {
+  return receipt_verify_impl(rc, blob, blob_words, control_roots, n_roots, image_id, nullptr, verdict_out, segment_out, seal_verdict_out);
+}
+
+const char* r0h_receipt_verify_elf(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots, size_t n_roots, const uint8_t* elf,
+                                   size_t elf_len, int* verdict_out, size_t* segment_out, int* seal_verdict_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(elf, "r0h_receipt_verify_elf: NULL argument");
+  std::vector<std::pair<uint32_t, uint32_t>> image;
+  uint32_t entry = 0;
+  uint8_t image_id[32];
+  R0H_TRY(elf_image(elf, elf_len, image, &entry, image_id));
+  return receipt_verify_impl(rc, blob, blob_words, control_roots, n_roots, image_id, &image, verdict_out, segment_out, seal_verdict_out);
   R0H_GUARD_END
 }
 

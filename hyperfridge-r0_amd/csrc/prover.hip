@@ -596,7 +596,7 @@ static const char* proof_begin_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32_t
                                     const r0h_buf* data, const uint32_t* global, uint32_t* mix_out, r0h_proof** out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && c && (code || cc) && data && out, "r0h_proof_begin: NULL argument");
-  R0H_REQUIRE((global || r0h_circuit_n_global(c) == 0) && (mix_out || r0h_circuit_n_mix(c) == 0), "r0h_proof_begin: NULL globals / mix_out");
+  R0H_REQUIRE((global || r0h_circuit_n_global(c) == 0) && (mix_out || r0h_circuit_n_mix(c) == 0 || c->n_late), "r0h_proof_begin: NULL globals / mix_out");
   R0H_REQUIRE(po2 >= 9 && po2 <= R0H_MAX_PO2, "r0h_proof_begin: po2 %u outside [9, %u]", po2, R0H_MAX_PO2);
   R0H_TRY_HIP(hipSetDevice(ctx->device));
   CircuitView cv;
@@ -604,7 +604,7 @@ static const char* proof_begin_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32_t
   r0h_proof* st = new r0h_proof(ctx, c, po2, cv);
   const char* err = proof_begin(*st, code, cc, data, global);
   if (err) { delete st; return err; }
-  if (cv.n_mix && st->mix_drawn) memcpy(mix_out, st->mix.data(), (size_t)cv.n_mix * 4);
+  if (cv.n_mix && st->mix_drawn && mix_out) memcpy(mix_out, st->mix.data(), (size_t)cv.n_mix * 4);
   *out = st;
   return nullptr;
   R0H_GUARD_END

@@ -44,4 +44,5 @@ void system_state_digest(const r0h_system_state& st, uint8_t out[32]);
 void claim_digest(const r0h_receipt_claim& c, uint8_t out[32]);
 void claim_globals(const uint8_t digest[32], uint32_t out[8]);
 void session_challenge(const uint32_t* records, size_t n_records, uint32_t out[16]);
+const char* elf_image(const uint8_t* elf, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& image, uint32_t* entry, uint8_t image_id[32]);  // rv32im.cpp
 }  // namespace r0h

@@ -183,6 +183,19 @@ void memory_root(r0h_vm& vm, uint8_t out[32]) {
   memcpy(out, top == vm.tree.end() ? vm.zero_level[N_PAGE_BITS] : top->second.data(), 32);
 }
 
+// the program image by address; later loads of a word replace earlier ones
+void sort_image(r0h_vm& vm) {
+  if (vm.image_sorted) return;
+  std::stable_sort(vm.image.begin(), vm.image.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+  std::vector<std::pair<uint32_t, uint32_t>> uniq;
+  for (const auto& e : vm.image) {
+    if (!uniq.empty() && uniq.back().first == e.first) uniq.back() = e;
+    else uniq.push_back(e);
+  }
+  vm.image.swap(uniq);
+  vm.image_sorted = true;
+}
+
 struct Touched { uint32_t addr, first_value, prev_seg; };
 inline bool operator<(const Touched& a, const Touched& b) { return a.addr < b.addr; }
 
@@ -202,18 +215,7 @@ struct Run {
   uint8_t root_now[32];                // memory root at the last segment boundary (the next segment starts from it)
   bool have_root = false;
 
-  Run(r0h_vm& v, const r0h_vm_limits& l) : vm(v), lim(l), seg_budget((uint64_t)1 << l.segment_po2) {
-    if (!vm.image_sorted) {  // later loads of a word replace earlier ones; then by address
-      std::stable_sort(vm.image.begin(), vm.image.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
-      std::vector<std::pair<uint32_t, uint32_t>> uniq;
-      for (const auto& e : vm.image) {
-        if (!uniq.empty() && uniq.back().first == e.first) uniq.back() = e;
-        else uniq.push_back(e);
-      }
-      vm.image.swap(uniq);
-      vm.image_sorted = true;
-    }
-  }
+  Run(r0h_vm& v, const r0h_vm_limits& l) : vm(v), lim(l), seg_budget((uint64_t)1 << l.segment_po2) { sort_image(vm); }
 
   uint64_t paging_cycles() const { return (uint64_t)n_in * lim.page_in_cycles + (uint64_t)n_out * lim.page_out_cycles; }
   uint64_t boundary_count() const { return lim.boundary_rows ? touched.size() + (uint64_t)__builtin_popcount(reg_mask) : 0; }
@@ -812,6 +814,22 @@ const char* r0h_vm_run(r0h_vm* vm, const r0h_vm_limits* limits, int* exit_kind, 
 
 }  // extern "C"
 namespace r0h {
+// what a verifier needs of an ELF: the image as (word index, word) in address order, the entry point, the image id
+const char* elf_image(const uint8_t* elf, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& image, uint32_t* entry, uint8_t image_id[32]) {
+  r0h_vm* vm = nullptr;
+  R0H_TRY(r0h_vm_new(&vm));
+  struct Guard { r0h_vm* v; ~Guard() { r0h_vm_free(v); } } guard{vm};
+  R0H_TRY(r0h_vm_load_elf(vm, elf, n));
+  sort_image(*vm);
+  image = vm->image;
+  *entry = vm->pc;
+  r0h_system_state st;
+  memset(&st, 0, sizeof st);
+  st.pc = vm->pc;
+  memory_root(*vm, st.merkle_root);
+  system_state_digest(st, image_id);
+  return nullptr;
+}
 // the rows of segment i change hands (session.cpp hands them to the prover while the guest runs on)
 void vm_take_trace(r0h_vm* vm, size_t i, std::vector<r0h_preflight_row>& rows, std::vector<r0h_preflight_bound>& bounds) {
   rows.swap(vm->segments[i].rows);

@@ -319,8 +319,22 @@ const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out);
 #define R0H_RECEIPT_V_NO_BINDING 10
 #define R0H_RECEIPT_V_HASHFN 11
 #define R0H_RECEIPT_V_UNBOUND 12 /* everything else holds, but image_id was NULL: the receipt is not tied to a program */
+#define R0H_RECEIPT_V_SESSION 13       /* trace circuit: a seal's session number / closing flags / challenge are not the session's */
+#define R0H_RECEIPT_V_SESSION_SUM 14   /* trace circuit: the segments' sums, the program image and the journal do not balance */
+#define R0H_RECEIPT_V_NEEDS_IMAGE 15   /* trace circuit: everything else holds, but the program image (the ELF) was not given */
 const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots,
                                size_t n_roots, const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out);
+/* `receipt.verify(image_id)` for receipts over the trace circuit (circuits/trace.r0c), where the program is bound by a session-wide
+ * memory argument instead of in-circuit hashing: the verifier is given the ELF itself (the reference's host embeds it as
+ * HYPERFRIDGE_ELF next to HYPERFRIDGE_ID, methods/build.rs:2).  Beyond what r0h_receipt_verify checks: the image id of the ELF is
+ * the first pre-state; every seal carries the session challenge derived from ALL seals' DATA roots and early public inputs; segment
+ * numbers count up, the closing segments are the run's last (or segments without cycles after it) with increasing address ranges;
+ * and the sum of the segments' session sums equals the sum over the ELF's image words and the journal's words of their tuples'
+ * fractions -- so every first touch of a word finds the image (or zero), every later one what the previous segment left, and the
+ * journal is what the COMMIT rows read.  With r0h_receipt_verify (no ELF) such a receipt is at best R0H_RECEIPT_V_NEEDS_IMAGE. */
+const char* r0h_receipt_verify_elf(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots,
+                                   size_t n_roots, const uint8_t* elf, size_t elf_len, int* verdict_out, size_t* segment_out,
+                                   int* seal_verdict_out);
 const char* r0h_receipt_verify_reason(int verdict); /* static string, do not free */
 /* The image id as text, the reference's way (host/src/main.rs:445-449, verifier/src/main.rs:131-143, host/out/IMAGE_ID.hex): eight
  * u32 words printed `{:08x}`, each stored little-endian in the 32-byte digest (`Digest::from([u32; 8])`) -- NOT the digest's bytes
@@ -503,6 +517,8 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
 #define R0H_TRACE_LATE_GLOBALS 20 /* the last 20 public inputs: the session's challenge (16 words) and the segment's sum under it (4) */
 #define R0H_TRACE_GAMMA 20         /* where the session challenge sits among the public inputs; the segment's sum follows at 36 */
 #define R0H_TRACE_SUM 36
+#define R0H_SESSION_TAG_IMAGE ((1u << 20) + 1)   /* the "segment" coordinate of an image word's tuple in the session sum */
+#define R0H_SESSION_TAG_JOURNAL ((1u << 20) + 2) /* ... and of a journal word's */
 #define R0H_SESSION_RECORD_WORDS 28 /* what a segment contributes to the session challenge: its 20 early public inputs, its DATA root */
 #define R0H_TRACE_MIN_PO2 16      /* the lookup tables have 2^16 rows */
 #define R0H_TRACE_MAX_PO2 21

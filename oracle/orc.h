@@ -95,6 +95,13 @@ void orc_witgen_foreign_code(const orc_circuit_t* c, uint32_t po2, uint64_t seed
                              uint32_t* code, uint32_t* data, uint32_t* global);
 void orc_accum(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, const uint32_t* mix,
                uint32_t* accum);
+/* the log-derivative argument of a circuit (blob section 10): multiplicity columns of DATA (returns -1 if a looked-up value is in no
+ * table), totals of the accumulators whose challenges are public inputs, and the accumulation with public inputs at hand */
+int orc_logup_multiplicities(const orc_circuit_t* c, uint32_t po2, uint32_t* data, const uint32_t* global);
+void orc_logup_totals(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, uint32_t* global_io);
+void orc_accum_public(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, const uint32_t* global,
+                      const uint32_t* mix, uint32_t* accum);
+uint32_t orc_circuit_n_late(const orc_circuit_t* c);
 void orc_eval_check(const orc_circuit_t* c, uint32_t po2, const uint32_t* eval_accum, const uint32_t* eval_code,
                     const uint32_t* eval_data, const uint32_t* global, const uint32_t* mix, const uint32_t poly_mix[4],
                     uint32_t* check /*[4][4N]*/);

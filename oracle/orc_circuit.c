@@ -18,18 +18,20 @@
 #include <string.h>
 
 #define BLOB_MAGIC 0x31433052u
-enum { SEC_GROUPS = 1, SEC_TAPS = 2, SEC_GLOBALS = 3, SEC_POLY = 4, SEC_WITGEN = 5, SEC_ACCUM = 6, SEC_INFO = 7, SEC_ACCUM_FP = 8 };
+enum { SEC_GROUPS = 1, SEC_TAPS = 2, SEC_GLOBALS = 3, SEC_POLY = 4, SEC_WITGEN = 5, SEC_ACCUM = 6, SEC_INFO = 7, SEC_ACCUM_FP = 8, SEC_LATE = 9, SEC_LOGUP = 10 };
+#define TAG_AND (1u << 24)
 
 uint32_t orc_circuit_group_size(const orc_circuit_t* c, uint32_t g) { return c->group_size[g]; }
 uint32_t orc_circuit_n_taps(const orc_circuit_t* c) { return c->n_taps; }
 uint32_t orc_circuit_n_global(const orc_circuit_t* c) { return c->n_global; }
 uint32_t orc_circuit_n_mix(const orc_circuit_t* c) { return c->n_mix; }
+uint32_t orc_circuit_n_late(const orc_circuit_t* c) { return c->n_late; }
 uint32_t orc_circuit_n_combos(const orc_circuit_t* c) { return c->n_combos; }
 
 void orc_circuit_free(orc_circuit_t* c) {
   if (!c) return;
   free(c->taps); free(c->regs); free(c->combo_begin); free(c->combo_backs); free(c->steps);
-  free(c->code_cols); free(c->data_cols); free(c->acc_cols); free(c->acc_fp); free(c->global_cols); free(c);
+  free(c->code_cols); free(c->data_cols); free(c->acc_cols); free(c->acc_fp); free(c->global_cols); free(c->logup); free(c->logup_words); free(c);
 }
 
 static void derive_regs_and_combos(orc_circuit_t* c) {
@@ -115,6 +117,44 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
       case SEC_INFO:
         if (len >= 4) memcpy(c->info, p, 16);
         break;
+      case SEC_LATE:
+        if (len != 1) goto bad;
+        c->n_late = p[0];
+        break;
+      case SEC_LOGUP: {
+        if (len < 2 || c->logup_words) goto bad;
+        c->logup_words = (uint32_t*)malloc(4 * (size_t)len);
+        memcpy(c->logup_words, p, 4 * (size_t)len);
+        const uint32_t* q = c->logup_words;
+        size_t at = 0;
+#define WORD(dst) do { if (at >= len) goto bad; (dst) = q[at++]; } while (0)
+#define FORM(lf) do { WORD((lf).n); if ((lf).n > 64 || at + 3 * (size_t)(lf).n > len) goto bad; (lf).t = (const orc_lf_term_t*)(q + at); at += 3 * (size_t)(lf).n; } while (0)
+        WORD(c->n_logup); WORD(c->n_tables);
+        if (c->n_logup < 1 || c->n_logup > 64 || c->n_tables > 8) goto bad;
+        for (uint32_t k = 0; k < c->n_tables; k++) { WORD(c->table_col[k]); WORD(c->table_kind[k]); }
+        c->logup = (orc_logup_acc_t*)calloc(c->n_logup, sizeof(orc_logup_acc_t));
+        int chain_over = 0;
+        for (uint32_t j = 0; j < c->n_logup; j++) {
+          orc_logup_acc_t* a = &c->logup[j];
+          uint32_t nf;
+          WORD(nf); WORD(a->final_global);
+          if (nf != 4) goto bad;
+          if (a->final_global == 0xffffffffu) { if (chain_over) goto bad; c->n_chain++; } else chain_over = 1;
+          for (uint32_t f = 0; f < 4; f++) {
+            orc_logup_fraction_t* fr = &a->fr[f];
+            WORD(fr->table);
+            FORM(fr->num);
+            WORD(fr->n_parts);
+            if (fr->table > 2 || fr->n_parts < 1 || fr->n_parts > 8) goto bad;
+            for (uint32_t k = 0; k < fr->n_parts; k++) { WORD(fr->parts[k].ch_kind); WORD(fr->parts[k].ch_idx); FORM(fr->parts[k].lf); if (fr->parts[k].ch_kind > 2) goto bad; }
+            if (fr->table && (fr->n_parts != 2 || fr->parts[1].ch_kind != 0)) goto bad;
+          }
+        }
+        if (at != len) goto bad;
+#undef WORD
+#undef FORM
+        break;
+      }
       default: break;
     }
     pos += 2 + len;
@@ -125,7 +165,34 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
     else c->n_fp_vars++;
   }
   /* WITGEN/ACCUM (the synthetic column program) are optional: circuits imported from risc0 tables omit both */
-  if ((c->code_cols || c->acc_cols || c->acc_fp) && (c->n_code != c->group_size[ORC_GROUP_CODE] || c->n_data != c->group_size[ORC_GROUP_DATA])) goto bad;
+  if ((c->code_cols || c->acc_cols || c->acc_fp || c->logup) && (c->n_code != c->group_size[ORC_GROUP_CODE] || c->n_data != c->group_size[ORC_GROUP_DATA])) goto bad;
+  if (c->n_late > c->n_global) goto bad;
+  if (c->logup) {  /* every reference of the log-derivative argument stays inside the circuit */
+    if (c->acc_cols || c->acc_fp || 4 * c->n_logup != c->group_size[ORC_GROUP_ACCUM] || !c->n_chain) goto bad;
+    for (uint32_t k = 0; k < c->n_tables; k++)
+      if (c->table_col[k] >= c->n_data || (c->table_kind[k] != 1 && c->table_kind[k] != 2)) goto bad;
+    for (uint32_t j = 0; j < c->n_logup; j++) {
+      const orc_logup_acc_t* a = &c->logup[j];
+      if (a->final_global != 0xffffffffu && (uint64_t)a->final_global + 4 > c->n_global) goto bad;
+      for (int f = 0; f < 4; f++) {
+        const orc_logup_fraction_t* fr = &a->fr[f];
+        for (uint32_t k = 0; k <= fr->n_parts; k++) {
+          const orc_lf_t* lf = k ? &fr->parts[k - 1].lf : &fr->num;
+          for (uint32_t t = 0; t < lf->n; t++) {
+            if (lf->t[t].coef >= ORC_P || lf->t[t].global > c->n_global) goto bad;
+            if (lf->t[t].col) {
+              uint32_t ref = lf->t[t].col - 1, g = ref >> 28, col = ref & 0xfffffu;
+              if ((g != ORC_GROUP_CODE && g != ORC_GROUP_DATA) || col >= c->group_size[g]) goto bad;
+            }
+          }
+          if (k) {
+            const orc_logup_part_t* q = &fr->parts[k - 1];
+            if ((q->ch_kind == 1 && 4 * (uint64_t)q->ch_idx + 4 > c->n_mix) || (q->ch_kind == 2 && (uint64_t)q->ch_idx + 4 > c->n_global)) goto bad;
+          }
+        }
+      }
+    }
+  } else
   if (c->acc_fp) {  /* the trace circuit's memory-consistency accumulators: alpha, b1, b2, b3 shared */
     if (c->acc_cols || 4 * c->n_acc_fp != c->group_size[ORC_GROUP_ACCUM] || c->n_mix != 16) goto bad;
     for (uint32_t j = 0; j < c->n_acc_fp; j++) {
@@ -183,6 +250,8 @@ void orc_witgen_foreign_code(const orc_circuit_t* c, uint32_t po2, uint64_t seed
       if (kind == 0) v = r == 0 ? ORC_ONE : 0;
       else if (kind == 1) v = r == n - 1 ? ORC_ONE : 0;
       else if (kind == 2) v = fp_enc((uint32_t)r);
+      else if (kind == 4) v = r < 65536 ? fp_enc((uint32_t)r) : 0;                                                        /* the 16-bit range table */
+      else if (kind == 5) v = fp_enc(TAG_AND + (r < 65536 ? (uint32_t)r + 65536u * (((uint32_t)r & 255u) & ((uint32_t)r >> 8)) : 0u));  /* the byte-AND table */
       else v = synth_word(code_seed, (1u << 16) | k, (uint32_t)r);
       col[r] = v;
     }
@@ -215,6 +284,123 @@ void orc_witgen_foreign_code(const orc_circuit_t* c, uint32_t po2, uint64_t seed
   }
   const uint32_t* gcols = c->global_cols;
   for (uint32_t k = 0; k < c->n_global; k++) global[k] = data[(size_t)gcols[k] * n];
+}
+
+/* ---- the log-derivative argument (blob section 10; risc0-circuit-rv32im 4.0.4 `step_accum` stands here) */
+static fp_t lf_eval(const orc_lf_t* lf, const uint32_t* code, const uint32_t* data, const uint32_t* global, size_t n, size_t r) {
+  fp_t acc = 0;
+  for (uint32_t t = 0; t < lf->n; t++) {
+    fp_t v = fp_enc(lf->t[t].coef);
+    if (lf->t[t].global) v = fp_mul(v, global[lf->t[t].global - 1]);
+    if (lf->t[t].col) {
+      uint32_t ref = lf->t[t].col - 1;
+      const uint32_t* src = (ref >> 28) == ORC_GROUP_CODE ? code : data;
+      v = fp_mul(v, src[(size_t)(ref & 0xfffffu) * n + r]);
+    }
+    acc = fp_add(acc, v);
+  }
+  return acc;
+}
+/* sum over the accumulator's four fractions of numerator / denominator on row r */
+static fp4_t logup_term(const orc_logup_acc_t* a, const uint32_t* code, const uint32_t* data, const uint32_t* global, const uint32_t* mix, size_t n, size_t r) {
+  fp4_t d[4];
+  fp_t num[4];
+  for (int f = 0; f < 4; f++) {
+    const orc_logup_fraction_t* fr = &a->fr[f];
+    num[f] = lf_eval(&fr->num, code, data, global, n, r);
+    fp4_t den = fp4_zero();
+    for (uint32_t k = 0; k < fr->n_parts; k++) {
+      const orc_logup_part_t* q = &fr->parts[k];
+      fp_t v = lf_eval(&q->lf, code, data, global, n, r);
+      if (q->ch_kind == 0) den.e[0] = fp_add(den.e[0], v);
+      else {
+        fp4_t ch;
+        memcpy(&ch, q->ch_kind == 1 ? mix + 4 * (size_t)q->ch_idx : global + q->ch_idx, 16);
+        den = fp4_add(den, fp4_scale(ch, v));
+      }
+    }
+    d[f] = den;
+  }
+  fp4_t d01 = fp4_mul(d[0], d[1]), d23 = fp4_mul(d[2], d[3]);
+  fp4_t top = fp4_add(fp4_mul(fp4_add(fp4_scale(d[1], num[0]), fp4_scale(d[0], num[1])), d23), fp4_mul(fp4_add(fp4_scale(d[3], num[2]), fp4_scale(d[2], num[3])), d01));
+  return fp4_mul(top, fp4_inv(fp4_mul(d01, d23)));
+}
+
+/* the multiplicity columns of DATA from the lookups the rows make (before DATA is committed); -1 if a value is not in its table */
+int orc_logup_multiplicities(const orc_circuit_t* c, uint32_t po2, uint32_t* data, const uint32_t* global) {
+  size_t n = (size_t)1 << po2;
+  if (!c->n_tables) return 0;
+  if (po2 < 16) return -1;
+  uint32_t* hist = (uint32_t*)calloc((size_t)c->n_tables * 65536, 4);
+  int bad = 0;
+  for (uint32_t j = 0; j < c->n_chain; j++)
+    for (int f = 0; f < 4; f++) {
+      const orc_logup_fraction_t* fr = &c->logup[j].fr[f];
+      if (!fr->table || fr->table > c->n_tables) continue;
+      for (size_t r = 0; r < n; r++) {
+        if (lf_eval(&fr->num, data, data, global, n, r) != ORC_ONE) continue;
+        uint32_t v = fp_dec(fp_sub(0, lf_eval(&fr->parts[1].lf, data, data, global, n, r)));
+        if (fr->table == 2) {
+          v -= TAG_AND;
+          if (v >> 24 || ((v & 255u) & ((v >> 8) & 255u)) != v >> 16) { bad = 1; continue; }
+          v &= 0xffffu;
+        } else if (v >> 16) { bad = 1; continue; }
+        hist[(size_t)(fr->table - 1) * 65536 + v]++;
+      }
+    }
+  for (uint32_t k = 0; k < c->n_tables; k++) {
+    uint32_t* col = data + (size_t)c->table_col[k] * n;
+    memset(col, 0, n * 4);
+    for (uint32_t v = 0; v < 65536; v++) col[v] = fp_enc(hist[(size_t)k * 65536 + v]);
+  }
+  free(hist);
+  return bad ? -1 : 0;
+}
+
+/* the totals of the accumulators that run alone (their challenges are public inputs): written into global_io where the circuit reads them */
+void orc_logup_totals(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, uint32_t* global_io) {
+  size_t n = (size_t)1 << po2;
+  for (uint32_t j = c->n_chain; j < c->n_logup; j++) {
+    fp4_t tot = fp4_zero();
+#pragma omp parallel
+    {
+      fp4_t part = fp4_zero();
+#pragma omp for nowait
+      for (size_t r = 0; r < n; r++) part = fp4_add(part, logup_term(&c->logup[j], code, data, global_io, NULL, n, r));
+#pragma omp critical
+      tot = fp4_add(tot, part);
+    }
+    memcpy(global_io + c->logup[j].final_global, &tot, 16);
+  }
+}
+
+static void logup_accum(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, const uint32_t* global, const uint32_t* mix, uint32_t* accum) {
+  size_t n = (size_t)1 << po2;
+  fp4_t* term = (fp4_t*)malloc(sizeof(fp4_t) * n * c->n_logup);
+#pragma omp parallel for
+  for (size_t r = 0; r < n; r++)
+    for (uint32_t j = 0; j < c->n_logup; j++) term[r * c->n_logup + j] = logup_term(&c->logup[j], code, data, global, mix, n, r);
+  /* the chain: one running sum through the row's links and on through the rows; the others run alone */
+  fp4_t run = fp4_zero();
+  for (size_t r = 0; r < n; r++)
+    for (uint32_t j = 0; j < c->n_chain; j++) {
+      run = fp4_add(run, term[r * c->n_logup + j]);
+      for (int k = 0; k < 4; k++) accum[((size_t)4 * j + k) * n + r] = run.e[k];
+    }
+  for (uint32_t j = c->n_chain; j < c->n_logup; j++) {
+    run = fp4_zero();
+    for (size_t r = 0; r < n; r++) {
+      run = fp4_add(run, term[r * c->n_logup + j]);
+      for (int k = 0; k < 4; k++) accum[((size_t)4 * j + k) * n + r] = run.e[k];
+    }
+  }
+  free(term);
+}
+
+void orc_accum_public(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, const uint32_t* global, const uint32_t* mix,
+                      uint32_t* accum) {
+  if (c->logup) logup_accum(c, po2, code, data, global, mix, accum);
+  else orc_accum(c, po2, code, data, mix, accum);
 }
 
 void orc_accum(const orc_circuit_t* c, uint32_t po2, const uint32_t* code, const uint32_t* data, const uint32_t* mix,

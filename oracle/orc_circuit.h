@@ -11,6 +11,12 @@ typedef struct { uint32_t kind, param; } orc_code_col_t;
 typedef struct { uint32_t kind, a, b, c, e; } orc_data_col_t;
 typedef struct { uint32_t first, a, b; } orc_acc_col_t;
 typedef struct { uint32_t n_f; uint32_t col[3][4]; } orc_acc_fp_t; /* running product of up to three tuple fingerprints (blob section 8) */
+/* the log-derivative argument (blob section 10): fractions numerator / sum of (challenge x linear form), four to an accumulator */
+typedef struct { uint32_t coef, global, col; } orc_lf_term_t; /* canonical coefficient; public input + 1 or 0; column ref + 1 or 0 */
+typedef struct { uint32_t n; const orc_lf_term_t* t; } orc_lf_t; /* points into the circuit's copy of the section */
+typedef struct { uint32_t ch_kind, ch_idx; orc_lf_t lf; } orc_logup_part_t;
+typedef struct { uint32_t table; orc_lf_t num; uint32_t n_parts; orc_logup_part_t parts[8]; } orc_logup_fraction_t;
+typedef struct { uint32_t final_global; orc_logup_fraction_t fr[4]; } orc_logup_acc_t;
 
 struct orc_circuit {
   uint32_t group_size[3];
@@ -25,6 +31,11 @@ struct orc_circuit {
   uint32_t n_data; orc_data_col_t* data_cols;
   uint32_t n_acc; orc_acc_col_t* acc_cols;
   uint32_t n_acc_fp; orc_acc_fp_t* acc_fp;
+  uint32_t n_late;                       /* the last n_late public inputs enter the transcript after the DATA commitment */
+  uint32_t n_logup, n_chain, n_tables;   /* accumulators of the log-derivative argument; how many are links of the chain */
+  orc_logup_acc_t* logup;
+  uint32_t table_col[8], table_kind[8];  /* DATA column that holds a table's multiplicities; 1 = range-16, 2 = byte-AND */
+  uint32_t* logup_words;                 /* the section itself (the linear forms point into it) */
   uint8_t info[16]; /* circuit ProtocolInfo tag (risc0 `CIRCUIT_INFO`), 16 bytes */
 };
 

@@ -148,14 +148,17 @@ size_t orc_prove_segment(const orc_circuit_t* c, const uint32_t* blob, size_t bl
   (void)blob; (void)blob_words;
   transcript_seed(&io.rng, c);
 
-  /* globals ++ po2 */
+  /* globals ++ po2: the seal opens with all of them; the transcript takes the early ones (and po2) here, the late ones -- public
+   * inputs that depend on commitments made outside this proof -- after the DATA commitment */
   {
-    uint32_t ng = c->n_global, d[8];
+    uint32_t ng = c->n_global, ne = ng - c->n_late, d[8];
     uint32_t* v = (uint32_t*)malloc(4 * (ng + 1));
+    memcpy(v, global, 4 * ne);
+    v[ne] = fp_enc(po2);
+    orc_hash_elem_slice(v, ne + 1, d);
+    orc_rng_mix(&io.rng, d);
     memcpy(v, global, 4 * ng);
     v[ng] = fp_enc(po2);
-    orc_hash_elem_slice(v, ng + 1, d);
-    orc_rng_mix(&io.rng, d);
     wiop_write(&io, v, ng + 1);
     free(v);
   }
@@ -165,12 +168,17 @@ size_t orc_prove_segment(const orc_circuit_t* c, const uint32_t* blob, size_t bl
   merkle_commit(&grp[ORC_GROUP_CODE].merkle, &io);
   group_from_witness(&grp[ORC_GROUP_DATA], data, c->group_size[ORC_GROUP_DATA], po2);
   merkle_commit(&grp[ORC_GROUP_DATA].merkle, &io);
+  if (c->n_late) {
+    uint32_t d[8];
+    orc_hash_elem_slice(global + (c->n_global - c->n_late), c->n_late, d);
+    orc_rng_mix(&io.rng, d);
+  }
 
   uint32_t* mix = (uint32_t*)malloc(4 * (c->n_mix ? c->n_mix : 1));
   for (uint32_t i = 0; i < c->n_mix; i++) mix[i] = orc_rng_elem(&io.rng);
   {
     uint32_t* accum = (uint32_t*)malloc((size_t)c->group_size[ORC_GROUP_ACCUM] * n * 4);
-    orc_accum(c, po2, code, data, mix, accum);
+    orc_accum_public(c, po2, code, data, global, mix, accum);
     group_from_witness(&grp[ORC_GROUP_ACCUM], accum, c->group_size[ORC_GROUP_ACCUM], po2);
     free(accum);
   }
@@ -360,9 +368,13 @@ int orc_verify_segment_bound(const orc_circuit_t* c, const uint32_t* blob, size_
   uint32_t po2 = fp_dec(gvec[ng]);
   if (po2 < 9 || po2 > 24) return V_BAD_PO2;
   {
-    uint32_t d[8];
-    orc_hash_elem_slice(gvec, ng + 1, d);
+    uint32_t d[8], ne = ng - c->n_late;
+    uint32_t* early = (uint32_t*)malloc(4 * (ne + 1));
+    memcpy(early, gvec, 4 * ne);
+    early[ne] = gvec[ng];
+    orc_hash_elem_slice(early, ne + 1, d);
     orc_rng_mix(&io.rng, d);
+    free(early);
   }
   const size_t n = (size_t)1 << po2, domain = n * ORC_INV_RATE;
 
@@ -390,6 +402,11 @@ int orc_verify_segment_bound(const orc_circuit_t* c, const uint32_t* blob, size_
   VM_NEW(&vm[ORC_GROUP_CODE], domain, c->group_size[ORC_GROUP_CODE]);
   if (expected_code_root && memcmp(expected_code_root, vm[ORC_GROUP_CODE].top + 8, 32) != 0) { rc = V_CODE_ROOT; goto done; }
   VM_NEW(&vm[ORC_GROUP_DATA], domain, c->group_size[ORC_GROUP_DATA]);
+  if (c->n_late) {
+    uint32_t d[8];
+    orc_hash_elem_slice(gvec + (ng - c->n_late), c->n_late, d);
+    orc_rng_mix(&io.rng, d);
+  }
   for (uint32_t i = 0; i < c->n_mix; i++) mix[i] = orc_rng_elem(&io.rng);
   VM_NEW(&vm[ORC_GROUP_ACCUM], domain, c->group_size[ORC_GROUP_ACCUM]);
   fp4_t poly_mix = rng_ext(&io.rng);

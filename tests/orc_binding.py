@@ -49,6 +49,12 @@ class Oracle:
         L.orc_witgen_public.argtypes = [_vp, _u32, _u64, _vp, _vp, _vp, _vp]
         L.orc_witgen_foreign_code.argtypes = [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp]
         L.orc_accum.argtypes = [_vp, _u32, _vp, _vp, _vp, _vp]
+        L.orc_accum_public.argtypes = [_vp, _u32, _vp, _vp, _vp, _vp, _vp]
+        L.orc_logup_multiplicities.restype = ctypes.c_int
+        L.orc_logup_multiplicities.argtypes = [_vp, _u32, _vp, _vp]
+        L.orc_logup_totals.argtypes = [_vp, _u32, _vp, _vp, _vp]
+        L.orc_circuit_n_late.restype = _u32
+        L.orc_circuit_n_late.argtypes = [_vp]
         L.orc_eval_check.argtypes = [_vp, _u32] + [_vp] * 7
         L.orc_poly_ext.argtypes = [_vp] * 6
         L.orc_batch_interpolate_ntt.argtypes = [_vp, _u32, _u32]
@@ -211,6 +217,7 @@ class OrcCircuit:
         self.group_size = [L.orc_circuit_group_size(self.h, g) for g in range(3)]
         self.n_taps, self.n_global = L.orc_circuit_n_taps(self.h), L.orc_circuit_n_global(self.h)
         self.n_mix, self.n_combos = L.orc_circuit_n_mix(self.h), L.orc_circuit_n_combos(self.h)
+        self.n_late = L.orc_circuit_n_late(self.h)
 
     def witgen(self, po2, seed, globals_in=None, code_seed=None):
         n = 1 << po2
@@ -232,6 +239,25 @@ class OrcCircuit:
         mix = u32(mix)
         self.o.L.orc_accum(self.h, po2, _ptr(u32(code)), _ptr(u32(data)), _ptr(mix), _ptr(out))
         return out
+
+    def accum_public(self, po2, code, data, glob, mix):
+        """the accumulation of a circuit whose argument reads public inputs (the log-derivative argument of the trace circuit)"""
+        out = np.zeros(self.group_size[0] << po2, np.uint32)
+        self.o.L.orc_accum_public(self.h, po2, _ptr(u32(code)), _ptr(u32(data)), _ptr(u32(glob)), _ptr(u32(mix)), _ptr(out))
+        return out
+
+    def logup_multiplicities(self, po2, data, glob):
+        """data with the lookup tables' multiplicity columns filled from the lookups its rows make"""
+        data = u32(data).copy()
+        rc = self.o.L.orc_logup_multiplicities(self.h, po2, _ptr(data), _ptr(u32(glob)))
+        assert rc == 0, "a looked-up value is in no table"
+        return data
+
+    def logup_totals(self, po2, code, data, glob):
+        """glob with the totals of the accumulators that run under public challenges written where the circuit reads them"""
+        glob = u32(glob).copy()
+        self.o.L.orc_logup_totals(self.h, po2, _ptr(u32(code)), _ptr(u32(data)), _ptr(glob))
+        return glob
 
     def eval_check(self, po2, ea, ec, ed, glob, mix, poly_mix):
         out = np.zeros(16 << po2, np.uint32)

@@ -120,9 +120,10 @@ class Camt53:
         L.const("CRC_TABLE", struct.pack("<256I", *crc))
         for name, size in (("AUTH_LEN", 4), ("AUTH", guest_rsa.MAX_MSG + 128), ("DIGEST3", 32), ("B64OUT", 48), ("N_BANK", 256), ("N_CLIENT", 256), ("N_WITNESS", 256), ("DERBUF", 296), ("FORM", 4), ("IBAN_LEN", 4), ("IBAN", 64), ("HOST_LEN", 4), ("HOST", 256), ("RK", 176), ("ST", 16), ("TMP16", 16), ("KEY", 16),
                            ("PLAIN", guest_rsa.MAX_MSG + 32), ("LENCODE", 64 + 4 * 288), ("DISTCODE", 64 + 4 * 32), ("CLCODE", 64 + 4 * 19), ("OFFS", 64),
-                           ("CL_LENGTHS", 4 * 19), ("LENGTHS", 4 * 320), ("ZIPBUF", ZIP_MAX), ("DOC", DOC_MAX), ("JP", 4), ("N_STMTS", 4), ("JOUT", OUT_MAX),
+                           ("CL_LENGTHS", 4 * 19), ("LENGTHS", 4 * 320), ("ZIPBUF", ZIP_MAX), ("DOC", DOC_MAX), ("JP", 4), ("N_STMTS", 4),
                            ("TXBLOCK", 256)):
             L.var(name, size)
+        L.fixed("JOUT", guest_rsa.JOURNAL_BASE)  # the commitment is put together in the journal window: COMMIT names its words there
         assert L.bss_top < STACK_TOP - 4096
 
     def after_signed_info(self, a, L, fresh, halt):

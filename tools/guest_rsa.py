@@ -26,6 +26,7 @@ from rvasm import (A0, A1, A2, A3, A4, A5, A6, A7, RA, S0, S1, S2, S3, S4, S5, S
                    Asm, elf)
 
 TEXT, DATA, BSS = 0x10000, 0x20000, 0x30000
+JOURNAL_BASE = 0x20000000  # R0H_JOURNAL_BASE (include/r0hip.h): journal word i is the word at JOURNAL_BASE + 4 i when COMMIT names it
 K256 = [0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74,
         0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d,
         0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e,
@@ -49,6 +50,10 @@ class Layout:
     def var(self, name, n_bytes):
         self.bss_sym[name] = self.bss_top
         self.bss_top += (n_bytes + 3) & ~3
+
+    def fixed(self, name, addr):
+        """a buffer at an address the executor's ABI prescribes (the journal window)"""
+        self.bss_sym[name] = addr
 
     def __getitem__(self, name):
         return self.data_sym[name] if name in self.data_sym else self.bss_sym[name]
@@ -196,8 +201,20 @@ def emit_commit(a, L, frame, halt):
     a.la(A0, L["DIGEST2"])
     a.la(A1, L["JSON"] + 4 + TEMPLATE.rindex(b"0" * 64))
     a.call("hex32")
-    a.la(A0, L["JSON"])
-    a.li(A1, (len(frame) + 3) >> 2)  # COMMIT takes words
+    # the journal is a window of memory (R0H_JOURNAL_BASE: word i of it at + 4 i): the frame moves there, then COMMIT names its words
+    n_words = (len(frame) + 3) >> 2
+    a.la(T0, L["JSON"])
+    a.li(T1, JOURNAL_BASE)
+    a.li(T2, n_words)
+    a.label("commit_copy")
+    a.lw(T3, 0, T0)
+    a.sw(T3, 0, T1)
+    a.addi(T0, T0, 4)
+    a.addi(T1, T1, 4)
+    a.addi(T2, T2, -1)
+    a.bne(T2, ZERO, "commit_copy")
+    a.li(A0, JOURNAL_BASE)
+    a.li(A1, n_words)  # COMMIT takes words
     a.li(A7, 2)
     a.ecall()
     halt(0)
