@@ -161,6 +161,7 @@ _SIGNATURES = {
     "r0h_session_records": [_vp, _vp, _vp, _sz, _c.POINTER(_sz)],
     "r0h_session_finish": [_vp, _vp, _sz, _pp, _vp, _c.POINTER(_u64)],
     "r0h_session_free": [_vp],
+    "r0h_session_challenge": [_vp, _sz, _vp],
     "r0h_last_session_stats": [_vp, _vp],
     "r0h_vm_journal": [_vp, _pp, _c.POINTER(_sz)],
     "r0h_vm_segment_claim": [_vp, _sz, _vp],
@@ -771,6 +772,15 @@ class Vm:
             self.close()
         except Exception:
             pass
+
+
+def session_challenge(records):
+    """the 16 words all seals of a trace-circuit session carry at TRACE_GAMMA (r0h_session_challenge): records [n, SESSION_RECORD_WORDS]
+    = every segment's early public inputs and DATA root, in index order"""
+    rec = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1, SESSION_RECORD_WORDS)
+    out = np.zeros(16, dtype=np.uint32)
+    _check(lib().r0h_session_challenge(rec.ctypes.data_as(_vp), rec.shape[0], out.ctypes.data_as(_vp)))
+    return out
 
 
 _trace_blob = None

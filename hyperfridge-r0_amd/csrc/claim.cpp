@@ -134,6 +134,17 @@ void claim_globals(const uint8_t digest[32], uint32_t out[8]) {
   p2_hash_elems_host(*k, halves, 16, out);
 }
 
+// what a trace-circuit seal says in its public inputs beyond the claim's name, held against the claim it is carried with: the pc the
+// run starts from and stops at, whether it ends in HALT / PAUSE, and with which exit code (r0h_receipt_verify, r0h_lift)
+bool is_trace_circuit(const r0h_circuit& circ) {
+  return !memcmp(circ.info, "R0HIP_TRACE:v4__", 16) && circ.n_global == R0H_TRACE_GLOBALS && circ.n_late == R0H_TRACE_LATE_GLOBALS;
+}
+bool trace_seal_carries_claim(const uint32_t* seal, const r0h_receipt_claim& claim) {
+  if (seal[8] != enc(claim.pre.pc) || seal[9] != enc(claim.post.pc)) return false;
+  const uint32_t kind = claim.exit_system == 0 ? 1u : claim.exit_system == 1 ? 2u : 0u, code = kind ? claim.exit_user : 0u;
+  return seal[11] == enc(kind) && seal[12] == enc(kind ? 1u : 0u) && seal[13] == enc(code & 0xffffu) && seal[14] == enc(code >> 16);
+}
+
 // The challenge all segments of a trace-circuit session share (late public inputs 20..35 of every seal): alpha_g and gamma, gamma^2,
 // gamma^3, drawn from the Poseidon2 digest of a tag and every segment's record -- its early public inputs and the root of its DATA
 // commitment -- in index order.  Every tuple of the session sum is committed before the challenge exists.
@@ -196,6 +207,15 @@ const char* r0h_claim_digest(const r0h_receipt_claim* claim, uint8_t digest_out[
   R0H_REQUIRE(claim->exit_system <= 2, "r0h_claim_digest: exit code system part %u is not one of Halted(0) / Paused(1) / Split,Limit(2)", claim->exit_system);
   claim_digest(*claim, digest_out);
   return nullptr;
+}
+
+const char* r0h_session_challenge(const uint32_t* records, size_t n_records, uint32_t challenge_out[16]) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(records && n_records && challenge_out, "r0h_session_challenge: NULL argument");
+  for (size_t i = 0; i < n_records * R0H_SESSION_RECORD_WORDS; i++) R0H_REQUIRE(records[i] < P, "r0h_session_challenge: word %zu is not a canonical field word", i);
+  session_challenge(records, n_records, challenge_out);
+  return nullptr;
+  R0H_GUARD_END
 }
 
 const char* r0h_claim_globals(const uint8_t claim_digest[32], uint32_t globals_out[8]) {
@@ -262,7 +282,7 @@ static const char* receipt_verify_impl(const r0h_receipt* rc, const uint32_t* bl
   if (circ.n_global < 8) return done(R0H_RECEIPT_V_NO_BINDING, 0);
   const size_t n = rc->segments.size();
   // the trace circuit's seals also carry the first and last pc of the segment, how it ends, and the session's public inputs
-  const bool trace_circuit = !memcmp(circ.info, "R0HIP_TRACE:v4__", 16) && circ.n_global == R0H_TRACE_GLOBALS && circ.n_late == R0H_TRACE_LATE_GLOBALS;
+  const bool trace_circuit = is_trace_circuit(circ);
   for (size_t i = 0; i < n; i++)  // before any claim is read (the chain check below looks one segment ahead)
     if (!rc->segments[i].has_claim) return done(R0H_RECEIPT_V_NO_CLAIM, i);
   // the segment that ends the run: the first whose claim is Halted / Paused; what follows it can only be rows that close the session
@@ -300,9 +320,7 @@ static const char* receipt_verify_impl(const r0h_receipt* rc, const uint32_t* bl
     // the trace circuit proves a run from its public first pc to its public last pc: they are the claim's
     // ... and it ends in a HALT / PAUSE ecall exactly when its public inputs say so, with the exit code they carry: the claim's ExitCode
     if (trace_circuit) {
-      if (g.seal[8] != enc(g.claim.pre.pc) || g.seal[9] != enc(g.claim.post.pc)) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
-      const uint32_t kind = g.claim.exit_system == 0 ? 1u : g.claim.exit_system == 1 ? 2u : 0u, code = kind ? g.claim.exit_user : 0u;
-      if (g.seal[11] != enc(kind) || g.seal[12] != enc(kind ? 1u : 0u) || g.seal[13] != enc(code & 0xffffu) || g.seal[14] != enc(code >> 16)) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
+      if (!trace_seal_carries_claim(g.seal.data(), g.claim)) return done(R0H_RECEIPT_V_CLAIM_MISMATCH, i);
       memcpy(&records[i * R0H_SESSION_RECORD_WORDS], g.seal.data(), (R0H_TRACE_GLOBALS - R0H_TRACE_LATE_GLOBALS) * 4);
       memcpy(&records[i * R0H_SESSION_RECORD_WORDS + (R0H_TRACE_GLOBALS - R0H_TRACE_LATE_GLOBALS)], data_root, 32);
     }

@@ -10,6 +10,7 @@
 // id (digest of state 0) and the control root of the trace size are printed for the verifier (`r0h_verify --receipt`).
 //
 //   usage: r0h_prove <trace.r0c> --elf guest.elf --input words.bin [--code-object file.hsaco] [--po2 N] [--device D] --receipt-out file.json
+//                    [--receipts R --contexts C --receipt-dir dir]   R sessions of the guest, C in flight (BASELINE.json configs[3]), each receipt verified with the ELF
 // `prover.prove(env, ELF)` itself (host/src/main.rs:420-423) as a compiled host: the guest ELF is executed on the u32 input stream
 // (the ExecutorEnv frames, little-endian words in a file), every segment is proved (r0h_prove_elf: with circuits/trace.r0c the
 // seals are proofs over the segments' own cycles), the receipt is written as JSON, and one line of JSON names the image id in
@@ -98,7 +99,7 @@ int main(int argc, char** argv) {
     if (!slurp(elf_path, &elf)) { fprintf(stderr, "r0h_prove: cannot open %s\n", elf_path.c_str()); return 1; }
     if (!input_path.empty() && !slurp(input_path, &raw)) { fprintf(stderr, "r0h_prove: cannot open %s\n", input_path.c_str()); return 1; }
     if (raw.size() % 4) { fprintf(stderr, "r0h_prove: --input is a stream of 32-bit words\n"); return 1; }
-    if (receipt_out.empty() && receipt_prefix.empty()) { fprintf(stderr, "r0h_prove: --elf needs --receipt-out or --receipt-prefix\n"); return 1; }
+    if (receipt_out.empty() && receipt_prefix.empty() && receipt_dir.empty()) { fprintf(stderr, "r0h_prove: --elf needs --receipt-out, --receipt-prefix or --receipt-dir\n"); return 1; }
     std::vector<uint32_t> words(raw.size() / 4);
     if (!words.empty()) memcpy(words.data(), raw.data(), raw.size());
     if (camt.count("response")) {
@@ -121,28 +122,62 @@ int main(int argc, char** argv) {
       r0h_free_error((const char*)stream);
       r0h_ebics_free(eb);
     }
-    r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; r0h_receipt* rc = nullptr;
-    CHECK(r0h_ctx_create((int)device, &ctx));
-    CHECK(r0h_circuit_load(ctx, blob.data(), blob.size(), co_path.empty() ? nullptr : co_path.c_str(), &circ));
+    // BASELINE.json configs[3] on the real workload: --receipts R sessions of this guest (host/src/main.rs:389-423 looped by
+    // data/watchdog.sh:46-109), --contexts C of them in flight -- each on a context of its own with its own executor thread and
+    // prover lanes -- one receipt file each, every receipt verified with the ELF afterwards (outside the timed region)
+    if (contexts < 1 || contexts > 8) { fprintf(stderr, "r0h_prove: --contexts must be 1..8 with --elf\n"); return 1; }
+    if (receipts > 1 && receipt_dir.empty()) { fprintf(stderr, "r0h_prove: --receipts R > 1 writes one file per receipt: use --receipt-dir\n"); return 1; }
+    if (contexts > receipts) contexts = receipts;
+    struct Worker { r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; };
+    std::vector<Worker> workers(contexts);
+    for (Worker& w : workers) {
+      CHECK(r0h_ctx_create((int)device, &w.ctx));
+      CHECK(r0h_circuit_load(w.ctx, blob.data(), blob.size(), co_path.empty() ? nullptr : co_path.c_str(), &w.circ));
+    }
+    r0h_ctx* ctx = workers[0].ctx;
+    r0h_circuit* circ = workers[0].circ;
+    std::vector<r0h_receipt*> made(receipts, nullptr);
     uint8_t image_id[32];
     uint64_t cycles = 0;
+    std::atomic<unsigned> next_receipt{0};
+    auto session_worker = [&](unsigned k) {
+      for (unsigned u; (u = next_receipt.fetch_add(1)) < receipts;) {
+        uint8_t id[32];
+        uint64_t cyc = 0;
+        CHECK(r0h_prove_elf(workers[k].ctx, workers[k].circ, elf.data(), elf.size(), words.data(), words.size(), po2, 0, &made[u], id, &cyc));
+        if (u == 0) { memcpy(image_id, id, 32); cycles = cyc; }
+      }
+    };
     const auto t0 = std::chrono::steady_clock::now();
-    CHECK(r0h_prove_elf(ctx, circ, elf.data(), elf.size(), words.data(), words.size(), po2, 0, &rc, image_id, &cycles));
-    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    char* text = nullptr;
-    CHECK(r0h_receipt_to_json(rc, &text));
-    if (receipt_out.empty()) {  // where the reference's verifier looks: <camt53 file>-Receipt-<image id>-latest.json
-      char id_hex[65];
-      CHECK(r0h_image_id_to_hex(image_id, id_hex));
-      receipt_out = receipt_prefix + "-Receipt-" + id_hex + "-latest.json";
+    {
+      std::vector<std::thread> threads;
+      for (unsigned k = 1; k < contexts; k++) threads.emplace_back(session_worker, k);
+      session_worker(0);
+      for (auto& t : threads) t.join();
     }
-    FILE* o = fopen(receipt_out.c_str(), "wb");
-    if (!o || fwrite(text, 1, strlen(text), o) != strlen(text)) { fprintf(stderr, "r0h_prove: cannot write %s\n", receipt_out.c_str()); return 1; }
-    fclose(o);
-    r0h_free_error(text);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    r0h_receipt* rc = made[0];
+    for (unsigned u = 0; u < receipts; u++) {
+      char* text = nullptr;
+      CHECK(r0h_receipt_to_json(made[u], &text));
+      std::string path = receipt_out;
+      if (receipts > 1 || (receipt_out.empty() && receipt_prefix.empty())) {
+        char name[64];
+        snprintf(name, sizeof name, "/receipt_%04u.json", u);
+        path = receipt_dir + name;
+      } else if (receipt_out.empty()) {  // where the reference's verifier looks: <camt53 file>-Receipt-<image id>-latest.json
+        char id_hex[65];
+        CHECK(r0h_image_id_to_hex(image_id, id_hex));
+        path = receipt_prefix + "-Receipt-" + id_hex + "-latest.json";
+      }
+      if (u == 0) receipt_out = path;
+      FILE* o = fopen(path.c_str(), "wb");
+      if (!o || fwrite(text, 1, strlen(text), o) != strlen(text)) { fprintf(stderr, "r0h_prove: cannot write %s\n", path.c_str()); return 1; }
+      fclose(o);
+      r0h_free_error(text);
+    }
     // the control root of every trace size the segments were proved at: what `r0h_verify --control-root` takes
     const size_t n_seg = r0h_receipt_n_segments(rc);
-    const uint32_t n_glob = r0h_circuit_n_global(circ);
     std::vector<uint32_t> sizes;
     for (size_t i = 0; i < n_seg; i++) {
       const uint32_t* seal; size_t n_words;
@@ -152,13 +187,7 @@ int main(int argc, char** argv) {
       if (verdict != R0H_VERIFY_OK) { fprintf(stderr, "r0h_prove: the verifier rejects seal %zu: %s\n", i, r0h_verify_reason(verdict)); return 3; }
       if (std::find(sizes.begin(), sizes.end(), size) == sizes.end()) sizes.push_back(size);
     }
-    (void)n_glob;
-    char hex[65];
-    CHECK(r0h_image_id_to_hex(image_id, hex));
-    r0h_session_stats st;
-    CHECK(r0h_last_session_stats(ctx, &st));
-    printf("{\"receipt\": \"%s\", \"image_id\": \"%s\", \"segments\": %zu, \"cycles\": %llu, \"seconds\": %.4f, \"segments_per_s\": %.3f, \"executor_s\": %.4f, \"control_roots\": [", receipt_out.c_str(), hex, n_seg,
-           (unsigned long long)cycles, secs, n_seg / secs, st.executor_s);
+    std::vector<uint32_t> root_table;
     for (size_t k = 0; k < sizes.size(); k++) {
       const size_t n = (size_t)1 << sizes[k];
       r0h_buf *code = nullptr, *data = nullptr;
@@ -167,14 +196,47 @@ int main(int argc, char** argv) {
       CHECK(r0h_witgen(ctx, circ, sizes[k], 0, code, data, nullptr));  // the circuit's fixed CODE columns
       uint32_t root[8];
       CHECK(r0h_code_root(ctx, code, r0h_circuit_group_size(circ, R0H_GROUP_CODE), sizes[k], root));
-      printf("%s\"%u:%u,%u,%u,%u,%u,%u,%u,%u\"", k ? ", " : "", sizes[k], root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7]);
+      root_table.push_back(sizes[k]);
+      root_table.insert(root_table.end(), root, root + 8);
       CHECK(r0h_buf_free(code));
       CHECK(r0h_buf_free(data));
     }
+    // every receipt verified the way the reference's verifier would (verifier/src/main.rs:124-126), with the ELF: host threads
+    std::atomic<unsigned> next_check{0}, refused{0};
+    const auto v0 = std::chrono::steady_clock::now();
+    auto check_worker = [&] {
+      for (unsigned u; (u = next_check.fetch_add(1)) < receipts;) {
+        int verdict = -1;
+        const char* e = r0h_receipt_verify_elf(made[u], blob.data(), blob.size(), root_table.data(), root_table.size() / 9, elf.data(), elf.size(), &verdict, nullptr, nullptr);
+        if (e) { r0h_free_error(e); verdict = -1; }
+        if (verdict != R0H_RECEIPT_V_OK) { fprintf(stderr, "r0h_prove: receipt %u is refused: %s\n", u, r0h_receipt_verify_reason(verdict)); refused++; }
+      }
+    };
+    {
+      std::vector<std::thread> threads;
+      for (unsigned k = 1; k < std::min(receipts, 8u); k++) threads.emplace_back(check_worker);
+      check_worker();
+      for (auto& t : threads) t.join();
+    }
+    const double verify_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - v0).count();
+    if (refused) return 3;
+    char hex[65];
+    CHECK(r0h_image_id_to_hex(image_id, hex));
+    r0h_session_stats st;
+    CHECK(r0h_last_session_stats(ctx, &st));
+    printf("{\"receipt\": \"%s\", \"image_id\": \"%s\", \"receipts\": %u, \"contexts\": %u, \"segments\": %zu, \"cycles\": %llu, \"seconds\": %.4f, \"segments_per_s\": %.3f, \"receipts_per_s\": %.4f, "
+           "\"executor_s\": %.4f, \"receipts_verified_with_the_elf\": %u, \"verify_seconds\": %.3f, \"control_roots\": [",
+           receipt_out.c_str(), hex, receipts, contexts, n_seg, (unsigned long long)cycles, secs, (double)n_seg * receipts / secs, receipts / secs, st.executor_s, receipts, verify_secs);
+    for (size_t k = 0; k < sizes.size(); k++) {
+      const uint32_t* root = &root_table[9 * k + 1];
+      printf("%s\"%u:%u,%u,%u,%u,%u,%u,%u,%u\"", k ? ", " : "", sizes[k], root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7]);
+    }
     printf("]}\n");
-    CHECK(r0h_receipt_free(rc));
-    CHECK(r0h_circuit_free(circ));
-    CHECK(r0h_ctx_destroy(ctx));
+    for (r0h_receipt* r : made) CHECK(r0h_receipt_free(r));
+    for (Worker& w : workers) {
+      CHECK(r0h_circuit_free(w.circ));
+      CHECK(r0h_ctx_destroy(w.ctx));
+    }
     return 0;
   }
   if (contexts < 1 || contexts > 16) { fprintf(stderr, "r0h_prove: --contexts must be 1..16\n"); return 1; }

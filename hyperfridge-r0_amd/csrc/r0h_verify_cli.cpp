@@ -5,7 +5,10 @@
 //          r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --control-root <po2>:<w0,..,w7> [--control-root ..]
 //          r0h_verify --image-id-of <guest.elf>          prints the image id in the reference's IMAGE_ID.hex form (`host show-image-id`)
 //          r0h_verify --receipt <receipt.json> <circuit.r0c> --elf <guest.elf> --control-root ...   (the image id computed from the ELF:
-//                     r0h_compute_image_id, what risc0_build embeds as HYPERFRIDGE_ID)
+//                     r0h_compute_image_id, what risc0_build embeds as HYPERFRIDGE_ID).  A receipt over the trace circuit binds its
+//                     program through the session-wide memory argument, which the verifier completes with the ELF's own words
+//                     (r0h_receipt_verify_elf): for such a receipt --elf is the way to an "accepted"; --image-id alone leaves the
+//                     session sum unchecked and is reported as not accepted ("program_bound": "no: ...")
 //                     `receipt.verify(image_id)` for a composite receipt (r0h_receipt_verify): seals against the control roots, claims
 //                     named by the seals, segment chain, journal digest, image id; then the commitment (verifier/src/main.rs:124-128).
 //                     Without --control-root the roots are derived from the circuit itself (r0h_control_root_host; a circuit with a
@@ -57,10 +60,10 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
   if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); return 2; }
   uint8_t image_id[32];
   char hex_of_elf[65];
+  std::vector<uint8_t> elf;
   if (elf_path && !image_hex) {
     FILE* e = fopen(elf_path, "rb");
     if (!e) { fprintf(stderr, "r0h_verify: cannot open %s\n", elf_path); r0h_receipt_free(rc); return 2; }
-    std::vector<uint8_t> elf;
     for (size_t got; (got = fread(buf, 1, sizeof buf, e)) > 0;) elf.insert(elf.end(), buf, buf + got);
     fclose(e);
     err = r0h_compute_image_id(elf.data(), elf.size(), image_id);
@@ -83,6 +86,9 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
       err = r0h_receipt_segment(rc, i, &seal, &words, nullptr);
       if (!err) err = r0h_verify_seal(blob.data(), blob.size(), nullptr, nullptr, seal, words, &sv, &po2);
       if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
+      // a root is derived only for a seal that verifies by itself (a bogus seal naming po2 = 24 must not make this verifier commit
+      // sixteen million rows before it says no): r0h_receipt_verify reports the seal's own verdict below
+      if (sv != R0H_VERIFY_OK) continue;
       bool have = false;
       for (size_t k = 0; k + 9 <= roots.size(); k += 9) have = have || roots[k] == po2;
       if (have || po2 == 0) continue;
@@ -100,7 +106,8 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
   const char* reason = "";
   bool seals_valid = false;
   if (bound) {
-    err = r0h_receipt_verify(rc, blob.data(), blob.size(), roots.data(), roots.size() / 9, image_id, &verdict, &at, &seal_verdict);
+    if (!elf.empty()) err = r0h_receipt_verify_elf(rc, blob.data(), blob.size(), roots.data(), roots.size() / 9, elf.data(), elf.size(), &verdict, &at, &seal_verdict);
+    else err = r0h_receipt_verify(rc, blob.data(), blob.size(), roots.data(), roots.size() / 9, image_id, &verdict, &at, &seal_verdict);
     if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
     reason = verdict == R0H_RECEIPT_V_SEAL ? r0h_verify_reason(seal_verdict) : r0h_receipt_verify_reason(verdict);
     seals_valid = verdict != R0H_RECEIPT_V_SEAL && verdict != R0H_RECEIPT_V_NOT_COMPOSITE && verdict != R0H_RECEIPT_V_NO_CONTROL_ROOT;
@@ -121,8 +128,12 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
   (void)r0h_receipt_journal(rc, &journal, &jn);
   err = r0h_journal_commitment_span(journal, jn, &off, &len);
   if (err) { r0h_free_error(err); len = 0; }
-  printf("{\"accepted\": %s, \"seals_valid\": %s, \"journal_bound\": %s, \"segments\": %zu, \"segment_at_fault\": %zu, \"reason\": \"%s\", \"control_roots\": \"%s\", \"commitment\": ",
-         accepted ? "true" : "false", seals_valid ? "true" : "false", accepted ? "true" : "false", n_seg, at, accepted ? "ok" : reason,
+  // what ties the receipt to a program: the session sum completed with the ELF's own words (trace circuit), or -- synthetic circuits --
+  // only the chain of claims from the image id (their seals prove that a satisfying trace naming the claim exists, not that the program ran)
+  const char* program_bound = !accepted ? (verdict == R0H_RECEIPT_V_NEEDS_IMAGE ? "no: the receipt binds its program through the session sum; give --elf" : "no")
+                                        : !elf.empty() ? "yes: image id and, for a trace-circuit receipt, the session sum over the ELF's image words" : "by the claims' chain from the image id";
+  printf("{\"accepted\": %s, \"seals_valid\": %s, \"journal_bound\": %s, \"program_bound\": \"%s\", \"segments\": %zu, \"segment_at_fault\": %zu, \"reason\": \"%s\", \"control_roots\": \"%s\", \"commitment\": ",
+         accepted ? "true" : "false", seals_valid ? "true" : "false", accepted ? "true" : "false", program_bound, n_seg, at, accepted ? "ok" : reason,
          derived_roots ? "derived from the circuit" : roots.empty() ? "none" : "given");
   print_json_string(journal + off, len);
   printf("}\n");

@@ -43,6 +43,8 @@ void tagged_struct(const char* tag, const uint8_t (*down)[32], size_t n_down, co
 void system_state_digest(const r0h_system_state& st, uint8_t out[32]);
 void claim_digest(const r0h_receipt_claim& c, uint8_t out[32]);
 void claim_globals(const uint8_t digest[32], uint32_t out[8]);
+bool is_trace_circuit(const r0h_circuit& circ);
+bool trace_seal_carries_claim(const uint32_t* seal, const r0h_receipt_claim& claim);
 void session_challenge(const uint32_t* records, size_t n_records, uint32_t out[16]);
 const char* elf_image(const uint8_t* elf, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& image, uint32_t* entry, uint8_t image_id[32]);  // rv32im.cpp
 }  // namespace r0h

@@ -154,6 +154,9 @@ const char* r0h_lift(r0h_recursor* rc, const uint32_t* seal, size_t seal_words, 
   uint32_t publics[16];
   naming_words(*claim, publics);
   R0H_REQUIRE(!memcmp(publics, seal, 32), "r0h_lift: the segment seal's public inputs do not name this claim");
+  // a trace-circuit seal also says where its run starts and stops and how it ends: the claim it is lifted under must say the same
+  // (r0h_receipt_verify refuses a receipt otherwise; a root built from lifted nodes must not carry a claim that check would refuse)
+  if (is_trace_circuit(seg)) R0H_REQUIRE(trace_seal_carries_claim(seal, *claim), "r0h_lift: the segment seal's first / last pc, way of ending or exit code are not this claim's");
   // ... and verifies against the control root of its trace size, when the recursor was given one (else against the circuit alone)
   const uint32_t po2 = dec(seal[seg.n_global]);
   const uint32_t* root = nullptr;

@@ -69,6 +69,18 @@ class DistEnv:
     def sum(self, value):
         return self._reduce(value, "SUM")
 
+    def sum_array(self, array):
+        """element-wise sum over the ranks of an int64 numpy array (all-reduce; the array itself with one rank)"""
+        if self.dist is None:
+            return array
+        import numpy as np
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.int64))
+        if self.device is not None:
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
     def close(self):
         if self.dist is not None and self.dist.is_initialized():
             self.dist.destroy_process_group()
@@ -101,13 +113,22 @@ def run_timed(env, step_fn, steps, warmup, device_sync=lambda: None, many_fn=Non
 
 def prove_elf_sharded(env, hal, circuit, elf, input_words, segment_po2=20, max_cycles=0):
     """`prove(env, elf)` on env.world GPUs: every rank executes the guest (deterministic, a tenth of a second per ten million cycles)
-    and proves segments rank, rank + world, ... (r0h_prove_elf_part); the ranks' receipts travel to rank 0 as JSON over point-to-point
-    send / recv (hyperfridge-r0_amd/recursion.py torch_transport: RCCL under "nccl", gloo otherwise) and are merged there
-    (r0h_receipt_merge).  No collective on the data path; the merged receipt is the one a single GPU would have produced, seal for
-    seal.  Returns (Receipt on rank 0 / None elsewhere, image id, cycles)."""
+    and commits segments rank, rank + world, ... (r0h_session_begin); with the trace circuit the segments of a session share ONE
+    challenge derived from all their DATA roots, so the ranks exchange their records -- 28 words per segment, one all-reduce of a
+    table every rank fills its own rows of (RCCL under "nccl", gloo otherwise: the one collective of the path) -- and finish their
+    proofs under it (r0h_session_finish).  The ranks' receipts travel to rank 0 as JSON over point-to-point send / recv
+    (hyperfridge-r0_amd/recursion.py torch_transport) and are merged there (r0h_receipt_merge): the merged receipt is the one a single
+    GPU would have produced, seal for seal.  Returns (Receipt on rank 0 / None elsewhere, image id, cycles)."""
     import numpy as np
     import hyperfridge_r0_amd as r0
-    mine, image_id, cycles = hal.prove_elf(circuit, elf, input_words, segment_po2=segment_po2, max_cycles=max_cycles, part=env.rank, parts=env.world)
+    ses = hal.session_begin(circuit, elf, input_words, segment_po2=segment_po2, max_cycles=max_cycles, part=env.rank, parts=env.world)
+    idx, rec = ses.records()
+    table = np.zeros((ses.n_segments, r0.SESSION_RECORD_WORDS), dtype=np.int64)
+    if len(idx):
+        table[idx] = rec
+    table = env.sum_array(table)  # every row is written by exactly one rank (words below 2^31: the sum is exact)
+    mine, image_id, cycles = ses.finish(table.astype(np.uint32))
+    ses.close()
     if env.world == 1:
         return mine, image_id, cycles
     from .recursion import torch_transport

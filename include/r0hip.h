@@ -573,6 +573,9 @@ const char* r0h_prove_elf_part(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t
  * session challenge; the ranks exchange their records (28 words per segment: an all-gather); `finish` takes the records of ALL
  * segments in index order, derives the challenge, finishes this rank's proofs and returns their receipt (r0h_receipt_merge joins
  * the ranks' receipts).  A session holds device memory (about 3 GiB per 2^20-row segment) until it is finished or freed. */
+/* the challenge itself (public inputs R0H_TRACE_GAMMA .. +16 of every seal of the session): alpha_g, gamma, gamma^2, gamma^3 drawn
+ * from the Poseidon2 digest of all records in index order -- what r0h_session_finish and r0h_receipt_verify[_elf] both compute */
+const char* r0h_session_challenge(const uint32_t* records, size_t n_records, uint32_t challenge_out[16]);
 typedef struct r0h_session r0h_session;
 const char* r0h_session_begin(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words,
                               size_t n_input, uint32_t segment_po2, uint64_t max_cycles, uint32_t part, uint32_t parts,

@@ -112,8 +112,9 @@ def test_batch_of_receipts_on_a_work_queue(tmp_path):
 def test_compiled_hosts_prove_the_guest_and_verify_the_receipt_like_host_and_verifier(tmp_path):
     """The reference's flow with compiled programs only (host/src/main.rs:420-423 + :251-252, verifier/src/main.rs:118-128):
     `r0h_prove <trace circuit> --elf <guest> --input <ExecutorEnv words>` executes the hand-assembled hyperfridge guest on the
-    reference's fixture and writes the receipt; `r0h_verify --receipt .. --image-id .. --control-root ..` accepts it and prints the
-    commitment -- which is the commitment inside the reference's own receipt file."""
+    reference's fixture and writes the receipt; `r0h_verify --receipt .. --elf .. --control-root ..` accepts it and prints the
+    commitment -- which is the commitment inside the reference's own receipt file.  (A receipt over the trace circuit binds its program
+    through the session sum, which the verifier completes with the ELF's own words: with the image id alone it is NOT accepted.)"""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import __graft_entry__ as entry
@@ -129,14 +130,19 @@ def test_compiled_hosts_prove_the_guest_and_verify_the_receipt_like_host_and_ver
     assert out.returncode == 0, out.stderr[-2000:]
     info = json.loads(out.stdout.strip().splitlines()[-1])
     assert info["segments"] >= 11 and info["cycles"] > 11_000_000 and len(info["image_id"]) == 64
-    bind = ["--image-id", info["image_id"]]
+    assert info["receipts"] == 1 and info["receipts_verified_with_the_elf"] == 1
+    bind = ["--elf", elf_path]
     for root in info["control_roots"]:
         bind += ["--control-root", root]
     out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace")] + bind, capture_output=True, text=True, timeout=600)
     report = json.loads(out.stdout)
-    assert out.returncode == 0 and report["accepted"] is True and report["journal_bound"] is True and report["segments"] == info["segments"]
+    assert out.returncode == 0 and report["accepted"] is True and report["journal_bound"] is True and report["segments"] == info["segments"] and report["program_bound"].startswith("yes")
     want = bytes(json.load(open(os.path.join(ROOT, "tests", "golden", "reference_receipt_6bb95807_latest.json")))["journal"]["bytes"])
     assert report["commitment"] == r0.journal_commitment(want).decode()
+    # the image id alone: everything it can check holds, but the session sum is unchecked -- not accepted, and the report says why
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", info["image_id"]] + bind[2:], capture_output=True, text=True, timeout=600)
+    report = json.loads(out.stdout)
+    assert out.returncode == 1 and report["accepted"] is False and report["seals_valid"] is True and "program image" in report["reason"] and report["program_bound"].startswith("no")
     other = "0" * 64
     out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", other] + bind[2:], capture_output=True, text=True, timeout=600)
     assert out.returncode == 1 and "image id" in json.loads(out.stdout)["reason"]
@@ -158,13 +164,19 @@ def test_compiled_hosts_prove_the_guest_and_verify_the_receipt_like_host_and_ver
     named = str(tmp_path / ("test.xml-Receipt-%s-latest.json" % info["image_id"]))
     assert json.loads(out.stdout.strip().splitlines()[-1])["receipt"] == named and open(named).read() == open(receipt).read()
     # no control roots given: the verifier derives them from the circuit blob itself (r0h_control_root_host, seconds per trace size)
-    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", info["image_id"]], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--elf", elf_path], capture_output=True, text=True, timeout=900)
     report = json.loads(out.stdout)
     assert out.returncode == 0 and report["accepted"] is True and report["control_roots"] == "derived from the circuit"
-    # the verifier given the ELF instead of the id (what `methods/build.rs` embeds as HYPERFRIDGE_ID): the same verdict; another ELF: refused
-    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--elf", elf_path] + bind[2:], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and json.loads(out.stdout)["accepted"] is True
+    # another ELF: refused
     other_elf = str(tmp_path / "other.elf")
     open(other_elf, "wb").write(open(elf_path, "rb").read()[:-4] + bytes(4))
     out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--elf", other_elf] + bind[2:], capture_output=True, text=True, timeout=600)
     assert out.returncode == 1 and "image id" in json.loads(out.stdout)["reason"]
+    # BASELINE.json configs[3] on the real workload, in small: three sessions of the guest, two in flight, one receipt file each, every one verified
+    out = subprocess.run([CLI, circuit_path("trace"), "--code-object", entry.code_object_path("trace"), "--elf", elf_path, "--input", str(words), "--po2", "20",
+                          "--receipts", "3", "--contexts", "2", "--receipt-dir", str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    batch = json.loads(out.stdout.strip().splitlines()[-1])
+    assert batch["receipts"] == 3 and batch["contexts"] == 2 and batch["receipts_verified_with_the_elf"] == 3 and batch["segments"] == info["segments"]
+    for k in range(3):
+        assert open(str(tmp_path / ("receipt_%04d.json" % k))).read() == open(receipt).read()  # the same session, the same receipt

@@ -51,12 +51,37 @@ def _session(n=7):
     return r0.serde_encode_str('{"iban":"X"}'), [np.arange(300, dtype=np.uint32) * (i + 3) for i in range(n)], claims
 
 
-class _ShareOnlyHal:
-    """stands where Hal.prove_elf stands (the proofs need a GPU): hands out this rank's share of the made-up session"""
-    def prove_elf(self, circuit, elf, input_words, segment_po2=20, max_cycles=0, part=0, parts=1):
+def _record(i):
+    """the record segment i of the made-up session contributes to the session challenge (28 field words)"""
+    import numpy as np
+    return (np.arange(28, dtype=np.int64) * 7919 + 104729 * (i + 1)) % 2013265921
+
+
+class _ShareOnlySession:
+    def __init__(self, part, parts):
+        self.part, self.parts, self.n_segments = part, parts, len(_session()[1])
+
+    def records(self):
+        import numpy as np
+        idx = np.arange(self.part, self.n_segments, self.parts)
+        return idx, np.stack([_record(i) for i in idx]).astype(np.uint32)
+
+    def finish(self, all_records):
+        import numpy as np
         import hyperfridge_r0_amd as r0
+        # the exchange brought every rank's rows: the whole table, in index order, on every rank
+        assert np.array_equal(np.asarray(all_records, dtype=np.int64), np.stack([_record(i) for i in range(self.n_segments)]))
         journal, seals, claims = _session()
-        return r0.Receipt.new(journal, seals[part::parts], claims[part::parts], indices=list(range(part, len(seals), parts))), bytes(32), 123
+        return r0.Receipt.new(journal, seals[self.part::self.parts], claims[self.part::self.parts], indices=list(range(self.part, len(seals), self.parts))), bytes(32), 123
+
+    def close(self):
+        pass
+
+
+class _ShareOnlyHal:
+    """stands where Hal.session_begin stands (the proofs need a GPU): hands out this rank's share of the made-up session"""
+    def session_begin(self, circuit, elf, input_words, segment_po2=20, max_cycles=0, part=0, parts=1):
+        return _ShareOnlySession(part, parts)
 
 
 def _sharded_worker(rank, world, port, out):
@@ -70,8 +95,10 @@ def _sharded_worker(rank, world, port, out):
 
 
 def test_a_session_sharded_over_two_ranks_arrives_whole_on_rank_zero():
-    """driver.prove_elf_sharded over gloo, world_size 2: rank r holds segments r, r + 2, ...; rank 1's receipt travels to rank 0 as
-    JSON over send / recv and the merged receipt is the whole session's (the proofs themselves are stood in for: they need a GPU)."""
+    """driver.prove_elf_sharded over gloo, world_size 2: rank r holds segments r, r + 2, ...; between the two phases of the session
+    the ranks exchange their segments' records (one all-reduce of a table every rank fills its own rows of: each rank then holds
+    the whole table); rank 1's receipt travels to rank 0 as JSON over send / recv and the merged receipt is the whole session's
+    (the proofs themselves are stood in for: they need a GPU)."""
     import hyperfridge_r0_amd as r0
     world = 2
     ctx = mp.get_context("spawn")

@@ -268,9 +268,15 @@ def test_the_last_segment_of_the_real_run_proves_on_the_cpu(orc):
     blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
     oc = orc.circuit(blob)
     data, glob = vm.trace_witness(k, 19, claim_globals=vm.claims()[k].globals())
-    assert [orc.dec(int(g)) for g in glob[8:]] == [seg.pre.pc, seg.post.pc, seg.user_cycles, 1, 1, 0, 0]
+    bl = vm.boundary(k)
+    assert seg.closing == 1 and [orc.dec(int(g)) for g in glob[8:20]] == [seg.pre.pc, seg.post.pc, seg.user_cycles, 1, 1, 0, 0, k + 1, 1, 0, bl[0].addr, bl[-1].addr]
+    # the rows that close the session: every word of the image among them, each with the word the ELF holds there
+    image = {b.addr: b.init_value for b in bl if b.flags & 1}
+    assert len(image) > 3000 and all(b.init_value == 0 for b in bl if not b.flags & 1) and any(b.prev_seg == 0 for b in bl) and max(b.prev_seg for b in bl) == k
     code = oc.witgen(19, 0)[0]
     root = oc.code_root(code, 19)
+    glob[r0.TRACE_GAMMA:r0.TRACE_GAMMA + 16] = [orc.enc(v) for v in range(7, 23)]  # one seal outside its session: any challenge will do
+    glob = oc.logup_totals(19, code, data, glob)
     seal = oc.prove(19, code, data, glob)
     assert oc.verify(seal, code_root=root) == (0, "ok") and r0.verify_seal(blob, seal, code_root=root)[:2] == (0, "ok")
 
@@ -278,7 +284,10 @@ def test_the_last_segment_of_the_real_run_proves_on_the_cpu(orc):
 @pytest.mark.gpu
 def test_the_proved_receipt_carries_the_references_journal(hal, orc):
     """`prove(env, elf)` over this guest with the trace circuit: twelve 2^20-row segments expanded and proved on the device; the
-    receipt verifies against the image id and its journal is the reference's committed receipt's journal."""
+    receipt verifies with the ELF -- THIS program produced THIS journal: seals, claims, the session's challenge, and the balance of
+    the segments' sums with the ELF's image words and the journal's words -- and its journal is the reference's committed
+    receipt's journal.  Parity at the headline size on the real workload: the run's FIRST segment (a full 2^20 rows) and its last
+    one, expanded on the host and proved by the CPU oracle under the seals' own public inputs, give the device's seals word for word."""
     import __graft_entry__ as entry
     image, stream, _ = guest_camt53.elf_and_input(form=1)
     blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
@@ -294,7 +303,14 @@ def test_the_proved_receipt_carries_the_references_journal(hal, orc):
             cc = hal.code_commit(gc, size)
             roots[size] = cc.root()
             cc.free()
-    assert len(seals) >= 11 and receipt.verify(blob, roots, image_id)[:2] == (0, "ok")
+    assert len(seals) >= 11 and receipt.verify(blob, roots, None, elf=image)[:2] == (0, "ok") and receipt.verify(blob, roots, image_id)[0] == 15
+    # what `receipt.verify(image_id)` exists to refuse (verifier/src/main.rs:124-126): another program, another journal
+    other = bytearray(image)
+    other[len(other) // 2] ^= 4
+    assert receipt.verify(blob, roots, None, elf=bytes(other))[0] in (8, 14)
+    doc = json.loads(receipt.to_json())
+    doc["journal"]["bytes"][40] ^= 1
+    assert r0.Receipt.parse(json.dumps(doc)).verify(blob, roots, None, elf=image)[0] == 7  # (the output digest no longer matches; with it recomputed the session sum objects: tests/test_trace_circuit.py)
     oc = orc.circuit(blob)
     assert oc.verify(seals[-1][1], code_root=roots[r0.verify_seal(blob, seals[-1][1])[2]]) == (0, "ok")
     # parity at full size on the real workload: the run's last segment -- what is left of 11.8 M cycles after eleven full segments, and
@@ -305,9 +321,21 @@ def test_the_proved_receipt_carries_the_references_journal(hal, orc):
     seg = vm.segments()[k]
     assert seg.user_cycles + seg.boundary_rows <= 1 << size and size >= 17
     data, glob = vm.trace_witness(k, size, claim_globals=vm.claims()[k].globals())
-    assert np.array_equal(glob, seals[k][1][:r0.TRACE_GLOBALS])
+    assert np.array_equal(glob[:20], seals[k][1][:20])
     ocode = oc.witgen(size, 0)[0]
-    assert np.array_equal(oc.prove(size, ocode, data, glob), seals[k][1])
+    assert np.array_equal(oc.prove(size, ocode, data, seals[k][1][:r0.TRACE_GLOBALS]), seals[k][1])
+    del data
+    # ... and the first segment, a full 2^20-row trace of the real workload
+    vm0 = r0.Vm()
+    vm0.load_elf(image)
+    vm0.set_input(stream)
+    assert vm0.run_segment(segment_po2=20, keep_trace=True, boundary_rows=True)[0] is False
+    s0 = vm0.segments()[0]
+    assert r0.verify_seal(blob, seals[0][1])[2] == 20 and (1 << 19) < s0.user_cycles + s0.boundary_rows <= 1 << 20
+    data, glob = vm0.trace_witness(0, 20, claim_globals=vm0.claims()[0].globals())
+    assert np.array_equal(glob[:20], seals[0][1][:20])
+    ocode = oc.witgen(20, 0)[0]
+    assert np.array_equal(oc.prove(20, ocode, data, seals[0][1][:r0.TRACE_GLOBALS]), seals[0][1])
     # the reference's own envelope around it: a receipt file whose journal.bytes are the fixture's
     doc = json.loads(receipt.to_json())
     assert doc["journal"]["bytes"] == json.load(open(os.path.join(GOLDEN, "reference_receipt_6bb95807_latest.json")))["journal"]["bytes"]

@@ -92,8 +92,9 @@ def test_sha256_of_the_guest_on_every_padding_length(guest):
 @pytest.mark.gpu
 def test_the_guest_run_is_proved_segment_by_segment_with_the_trace_circuit(hal, orc):
     """`prove(env, elf)` over the guest-shaped program on the reference's inputs: ten 2^20-row segments, each expanded on the device
-    from its compact preflight rows and proved with circuits/trace.r0c; the receipt verifies against the image id and carries the
-    known digest; the CPU oracle's verifier accepts the first and the last seal bound to their control roots."""
+    from its compact preflight rows and proved with circuits/trace.r0c; the receipt verifies with the ELF (the session sum over its
+    image words and the journal included) and carries the known digest; the CPU oracle's verifier accepts the first and the last seal
+    bound to their control roots."""
     import __graft_entry__ as entry
     image, stream, _ = guest_rsa.elf_and_input()
     blob = np.fromfile(circuit_path("trace"), dtype=np.uint32)
@@ -110,7 +111,7 @@ def test_the_guest_run_is_proved_segment_by_segment_with_the_trace_circuit(hal, 
             cc = hal.code_commit(gc, size)
             roots[size] = cc.root()
             cc.free()
-    assert receipt.verify(blob, roots, image_id)[:2] == (0, "ok")
+    assert receipt.verify(blob, roots, None, elf=image)[:2] == (0, "ok") and receipt.verify(blob, roots, image_id)[0] == 15
     oc = orc.circuit(blob)
     for _, seal in (seals[0], seals[-1]):
         assert oc.verify(seal, code_root=roots[r0.verify_seal(blob, seal)[2]]) == (0, "ok")

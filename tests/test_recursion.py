@@ -226,6 +226,30 @@ def test_the_segments_of_a_proved_run_join_into_one_root_with_the_receipts_claim
     lifted = [rec.lift(seals[0], claims[0]), rec.lift(seals[1], claims[1])]
     with pytest.raises(r0.R0HipError, match="do not follow one another"):
         rec.join(lifted[1], lifted[0])
+    # a segment proved for a claim that says something else than its run (round 3's advisor): the seal is valid and NAMES that claim, but
+    # its own public inputs -- first / last pc, the way it ends, the exit code -- are the run's: lift refuses what r0h_receipt_verify would
+    vm = r0.Vm()
+    vm.load_elf(elf_of(_guest(2000), 0x400))
+    vm.set_input([7, 0x01020304])
+    assert vm.run(segment_po2=11, keep_trace=True, boundary_rows=True) == (0, 0)
+    k = len(vm.segments()) - 1
+    seg, honest = vm.segments()[k], vm.claims()[k]
+    size = r0.TRACE_MIN_PO2
+    code_cols, synthetic, _ = hal.witgen(gc, size, 0)
+    synthetic.free()
+    cc = hal.code_commit(gc, size, code_cols)
+    rows, bounds = vm.preflight_arrays(k)
+    for forged in (r0.ReceiptClaim.make(honest.pre, r0.SystemState.make(honest.post.pc + 4, bytes(honest.post.merkle_root)), 0, 0, bytes(honest.output_digest)),
+                   r0.ReceiptClaim.make(honest.pre, honest.post, 0, 7, bytes(honest.output_digest)),
+                   r0.ReceiptClaim.make(honest.pre, honest.post, 2, 0, None)):
+        dev, glob = hal.trace_witgen(rows, bounds, size, claim_globals=forged.globals(), number=k + 1, closing=bool(seg.closing), idle_pc=seg.pre.pc, circuit=gc)
+        glob[r0.TRACE_GAMMA:r0.TRACE_GAMMA + 16] = seals[0][r0.TRACE_GAMMA:r0.TRACE_GAMMA + 16]
+        seal = hal.prove_segment(gc, size, cc, dev, hal.logup_totals(gc, size, code_cols, dev, glob))
+        dev.free()
+        assert r0.verify_seal(blob, seal, code_root=roots[size])[:2] == (0, "ok") and np.array_equal(seal[:8], forged.globals())
+        with pytest.raises(r0.R0HipError, match="first / last pc, way of ending or exit code"):
+            rec.lift(seal, forged)
+    cc.free(); code_cols.free()
     rec.close()
     gc.free()
 

@@ -302,8 +302,8 @@ def test_an_io_ecall_moves_one_word_per_cycle_and_can_be_cut_anywhere():
     moves word j - 1 of the buffer and writes a1 = j - 1, with a1 = 0 the ecall falls through (n + 1 cycles for n words, no state
     outside the registers -- what the trace circuit constrains).  A cycle has one memory access, pays for at most its own pages,
     and a transfer of any length is cut between two segments like any other stretch of the run; the journal and the memory come
-    out in stream order."""
-    buf = 0x40000
+    out in stream order.  Round 4: the journal is a window of memory -- COMMIT names the words at R0H_JOURNAL_BASE + 4 i, each once."""
+    buf = r0.JOURNAL_BASE - 4  # (so that buf + 4, the source of the COMMIT below, is the head of the journal window)
     def prog(n_words):
         return flat([ADDI(T0, T0, 1)] * 40, LI(A0, buf), LI(A1, n_words), ADDI(A7, 0, 1), ECALL,   # 40 cheap cycles, then READ_WORDS(buf, n)
                     LI(A0, buf + 4), LI(A1, n_words - 2), ADDI(A7, 0, 2), ECALL,                     # COMMIT(buf + 4, n - 2 words)
@@ -344,6 +344,23 @@ def test_an_io_ecall_moves_one_word_per_cycle_and_can_be_cut_anywhere():
     vm.set_pc(0x1000)
     with pytest.raises(r0.R0HipError, match="count too large"):
         vm.run()
+    # the journal window: a COMMIT from anywhere else, of a word twice, or one that leaves a hole is a guest trap -- a verifier who
+    # knows only the journal's bytes must know which (address, word) pairs the COMMIT rows named
+    jb = r0.JOURNAL_BASE
+    halt = [ADDI(A0, 0, 0), ADDI(A7, 0, 0), ECALL]
+    for body, why in (([LI(A0, 0x3000), ADDI(A1, 0, 1), ADDI(A7, 0, 2), ECALL], "outside the journal window"),
+                      ([LI(A0, jb), ADDI(A1, 0, 2), ADDI(A7, 0, 2), ECALL, LI(A0, jb + 4), ADDI(A1, 0, 1), ADDI(A7, 0, 2), ECALL], "committed twice"),
+                      ([LI(A0, jb + 8), ADDI(A1, 0, 1), ADDI(A7, 0, 2), ECALL], "hole in the journal")):
+        vm = r0.Vm()
+        vm.load(0x1000, flat(*body, *halt))
+        vm.set_pc(0x1000)
+        with pytest.raises(r0.R0HipError, match=why):
+            vm.run()
+    vm = r0.Vm()  # two commits in any order that together cover [0, 3): fine
+    vm.load(0x1000, flat(LI(A0, jb), ADDI(A1, 0, 3), ADDI(A7, 0, 1), ECALL, LI(A0, jb + 4), ADDI(A1, 0, 2), ADDI(A7, 0, 2), ECALL, LI(A0, jb), ADDI(A1, 0, 1), ADDI(A7, 0, 2), ECALL, *halt))
+    vm.set_pc(0x1000)
+    vm.set_input([5, 6, 7])
+    assert vm.run() == (0, 0) and vm.journal == struct.pack("<III", 5, 6, 7)
 
 
 def test_guest_memory_is_the_low_gibibyte():

@@ -406,9 +406,7 @@ def check_trace_rows(data, globals_, first_only=True, session_extra=None):
         if len(where):
             bad.append((name, where[:8].tolist() if first_only else where.tolist()))
     for name, rows, _ in check_fractions(data, globals_, session_extra if session_extra is not None else ()):
-        if name.startswith("session:") and session_extra is None:
-            continue
-        if name == "extra" and session_extra is None:
+        if (name.startswith("session:") or name == "extra") and session_extra is None:
             continue
         bad.append(("sum:" + name, rows))
     return bad

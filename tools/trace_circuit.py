@@ -142,18 +142,18 @@ class LF:
         return acc
 
     def evaluate(self, data, code, globals_):
-        """numpy: the form on every row (canonical integers mod p)"""
+        """numpy: the form on every row (canonical integers mod p, int64)"""
         import numpy as np
         n = data.shape[1]
-        acc = np.zeros(n, dtype=object)
+        acc = np.zeros(n, dtype=np.int64)
         for (g, c), v in self.t.items():
             k = v * (int(globals_[g]) if g is not None else 1) % P
             if c is None:
-                acc = acc + k
+                acc = (acc + k) % P
             else:
                 src = data[c & 0xFFFFF] if (c >> 28) == G_DATA else code[c & 0xFFFFF]
-                acc = acc + k * src.astype(object)
-        return acc % P
+                acc = (acc + k * (src.astype(np.int64) % P)) % P  # both factors below 2^31
+        return acc
 
 
 ONE = LF.of(1)
@@ -694,32 +694,54 @@ def code_columns(n):
     return [(rows == 0).astype(np.int64), (rows == n - 1).astype(np.int64), rows, np.zeros(n, dtype=np.int64), t16, tand]
 
 
+_HASH = [[(0x9E3779B97F4A7C15 * (i + 1) ** 3 + 12345 * j) % P for i in range(8)] for j in range(2)]
+
+
 def check_fractions(data, globals_, session_extra=()):
     """The log-derivative argument, exactly: the chained fractions must cancel as rational functions -- per distinct denominator the
     numerators sum to zero -- and so must the session fractions together with `session_extra` [(addr, lo, hi, t, numerator)] (what the
-    other segments and the verifier contribute).  -> [(fraction name, rows)] of what does not cancel."""
+    other segments and the verifier contribute).  -> [(fraction name, rows, key)] of what does not cancel.  (Denominators are told
+    apart by two 31-bit hashes of their forms' values: a collision would hide a mismatch with probability 2^-62.)"""
     import numpy as np
     n = data.shape[1]
     code = code_columns(n)
     chained, session = fractions()
     bad = []
     for group, extra in ((chained, ()), (session, session_extra)):
-        net, where = {}, {}
-        for f in group:
+        keys, nums, rows, which = [], [], [], []
+        for fi, f in enumerate(group):
             num = f.num.evaluate(data, code, globals_)
-            key_parts = [lf.evaluate(data, code, globals_) for _, lf in f.parts[1:]]
-            rows = np.nonzero(num)[0]
-            for r in rows:
-                key = tuple(int(kp[r]) for kp in key_parts) + (len(key_parts),)
-                net[key] = (net.get(key, 0) + int(num[r])) % P
-                where.setdefault(key, []).append((f.name, int(r)))
+            r = np.nonzero(num)[0]
+            if not len(r):
+                continue
+            parts = [lf.evaluate(data, code, globals_)[r] for _, lf in f.parts[1:]]
+            h = [np.full(len(r), len(parts) * _HASH[j][7] % P, dtype=np.int64) for j in range(2)]
+            for i, pv in enumerate(parts):
+                for j in range(2):
+                    h[j] = (h[j] + pv * _HASH[j][i]) % P
+            keys.append(h[0] * (1 << 31) + h[1])
+            nums.append(num[r])
+            rows.append(r)
+            which.append(np.full(len(r), fi, dtype=np.int64))
         for addr, lo, hi, t, num in extra:
-            key = ((-addr) % P, (-lo) % P, (-hi) % P, (-t) % P, 4)
-            net[key] = (net.get(key, 0) + num) % P
-            where.setdefault(key, []).append(("extra", -1))
-        for key, v in net.items():
-            if v:
-                bad.append((where[key][0][0], sorted({r for _, r in where[key]})[:8], key))
+            parts = [(-addr) % P, (-lo) % P, (-hi) % P, (-t) % P]
+            h = [(4 * _HASH[j][7] + sum(pv * _HASH[j][i] for i, pv in enumerate(parts))) % P for j in range(2)]
+            keys.append(np.array([h[0] * (1 << 31) + h[1]], dtype=np.int64))
+            nums.append(np.array([num % P], dtype=np.int64))
+            rows.append(np.array([-1], dtype=np.int64))
+            which.append(np.array([-1], dtype=np.int64))
+        if not keys:
+            continue
+        keys, nums, rows, which = map(np.concatenate, (keys, nums, rows, which))
+        uniq, inv = np.unique(keys, return_inverse=True)
+        # numerators are +-1 or multiplicities: sum them as signed integers (values above p / 2 stand for negatives)
+        signed = np.where(nums > P // 2, nums - P, nums)
+        net = np.zeros(len(uniq), dtype=np.int64)
+        np.add.at(net, inv, signed)
+        for u in np.nonzero(net % P)[0][:64]:
+            members = np.nonzero(inv == u)[0]
+            names = sorted({group[int(fi)].name if fi >= 0 else "extra" for fi in which[members]})
+            bad.append(("|".join(names[:4]), sorted({int(x) for x in rows[members]})[:8], int(uniq[u])))
     return bad
 
 
@@ -736,7 +758,7 @@ def multiplicities(data, globals_):
         value = (-f.parts[1][1].evaluate(data, code, globals_)) % P
         num = f.num.evaluate(data, code, globals_)
         assert (num == 1).all()
-        idx = np.array([int(x) for x in value], dtype=np.int64)
+        idx = value.astype(np.int64)
         if f.table == TABLE_AND:
             idx = idx - TAG_AND
             ok = (idx >= 0) & (idx < (1 << 24)) & (((idx & 255) & ((idx >> 8) & 255)) == (idx >> 16))
