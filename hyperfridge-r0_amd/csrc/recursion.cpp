@@ -177,8 +177,12 @@ const char* r0h_lift(r0h_recursor* rc, const uint32_t* seal, size_t seal_words, 
 const char* r0h_join(r0h_recursor* rc, const r0h_node* a, const r0h_node* b, r0h_node** out) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(rc && a && b && out, "r0h_join: NULL argument");
-  // risc0 `ReceiptClaim::join`: a must stop in a system split exactly where b starts
-  R0H_REQUIRE(a->claim.exit_system == 2 && a->claim.exit_user == 0, "r0h_join: the left node does not end in SystemSplit: nothing can follow it");
+  // risc0 `ReceiptClaim::join`: a must stop in a system split exactly where b starts.  One more case here: b is a node of closing rows
+  // only (the trace circuit's session may end in segments without cycles: pre == post, SystemSplit, no output) -- it follows whatever
+  // a ends in, the run's last segment included, and the composed claim ends the way a does
+  static const uint8_t no_output[32] = {0};
+  const bool b_idle = same_state(b->claim.pre, b->claim.post) && b->claim.exit_system == 2 && b->claim.exit_user == 0 && !memcmp(b->claim.output_digest, no_output, 32);
+  R0H_REQUIRE(b_idle || (a->claim.exit_system == 2 && a->claim.exit_user == 0), "r0h_join: the left node does not end in SystemSplit: nothing can follow it");
   R0H_REQUIRE(same_state(a->claim.post, b->claim.pre), "r0h_join: the left node's post-state is not the right node's pre-state: these two do not follow one another");
   uint32_t names[16];
   for (int side = 0; side < 2; side++) {  // each child's seal names the claim it is carried with
@@ -189,10 +193,12 @@ const char* r0h_join(r0h_recursor* rc, const r0h_node* a, const r0h_node* b, r0h
   }
   std::unique_ptr<r0h_node> node(new r0h_node());
   node->claim = a->claim;             // pre, input from the left ...
-  node->claim.post = b->claim.post;   // ... post, exit code, output from the right
-  node->claim.exit_system = b->claim.exit_system;
-  node->claim.exit_user = b->claim.exit_user;
-  memcpy(node->claim.output_digest, b->claim.output_digest, 32);
+  node->claim.post = b->claim.post;   // ... post, exit code, output from the right (a node of closing rows only leaves the left's)
+  if (!(b_idle && a->claim.exit_system != 2)) {
+    node->claim.exit_system = b->claim.exit_system;
+    node->claim.exit_user = b->claim.exit_user;
+    memcpy(node->claim.output_digest, b->claim.output_digest, 32);
+  }
   uint32_t publics[16], children[16];
   naming_words(node->claim, publics);
   R0H_TRY(r0h_seal_digest(a->seal.data(), a->seal.size(), children));

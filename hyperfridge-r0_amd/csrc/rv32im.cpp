@@ -938,7 +938,8 @@ const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* 
   out->post = s.post;
   out->exit_system = s.exit_system;
   out->exit_user = s.exit_user;
-  if (vm->finished && i + 1 == vm->segments.size() && s.exit_system <= 1) R0H_TRY(r0h_output_digest(vm->journal.data(), vm->journal.size(), nullptr, out->output_digest));
+  // the segment that ends the run (Halted / Paused) carries the journal's digest -- the last one, unless segments of closing rows follow it
+  if (vm->finished && s.exit_system <= 1) R0H_TRY(r0h_output_digest(vm->journal.data(), vm->journal.size(), nullptr, out->output_digest));
   return nullptr;
 }
 

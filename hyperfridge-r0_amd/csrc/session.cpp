@@ -190,8 +190,9 @@ const char* r0h_session_begin(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t*
   R0H_REQUIRE(ctx && c && elf && session_out && (input_words || !n_input), "r0h_prove_elf: NULL argument");
   R0H_REQUIRE(parts >= 1 && part < parts, "r0h_prove_elf_part: part %u of %u", part, parts);
   const bool trace_mode = !memcmp(c->info, "R0HIP_TRACE:v4__", 16);
-  R0H_REQUIRE(segment_po2 >= (trace_mode ? R0H_TRACE_MIN_PO2 : 9) && segment_po2 <= (trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2), "r0h_prove_elf: segment_po2 %u outside [%u, %u]", segment_po2,
-              (unsigned)(trace_mode ? R0H_TRACE_MIN_PO2 : 9), (unsigned)(trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2));
+  // (a trace-circuit segment of fewer than 2^16 rows is proved at 2^16: the lookup tables' size)
+  R0H_REQUIRE(segment_po2 >= 9 && segment_po2 <= (trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2), "r0h_prove_elf: segment_po2 %u outside [9, %u]", segment_po2,
+              (unsigned)(trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2));
   R0H_REQUIRE(c->has_column_program, "r0h_prove_elf: the circuit has no column program (CODE columns, accumulation)");
   R0H_REQUIRE(c->n_global >= 8, "r0h_prove_elf: the circuit exposes %u public inputs, a claim needs 8", c->n_global);
   if (trace_mode)

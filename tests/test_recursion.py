@@ -210,7 +210,9 @@ def test_the_segments_of_a_proved_run_join_into_one_root_with_the_receipts_claim
     receipt, image_id, cycles = hal.prove_elf(gc, elf_of(_guest(2000), 0x400), [7, 0x01020304], segment_po2=11)
     seals, claims = [s for _, s in receipt.seals()], receipt.claims()
     assert len(seals) >= 8
-    seals, claims = seals[-8:], claims[-8:]  # the last eight segments (the last one halts and carries the journal's digest)
+    seals, claims = seals[-8:], claims[-8:]  # the last eight segments: the one that halts carries the journal's digest; segments of closing rows follow it
+    halting = max(k for k, cl in enumerate(claims) if cl.exit_system == 0)
+    assert halting < 7  # (2^11-row segments: the rows that close the session do not fit beside the last cycles)
     roots = {}
     for s in seals:
         size = r0.verify_seal(blob, s)[2]
@@ -220,8 +222,8 @@ def test_the_segments_of_a_proved_run_join_into_one_root_with_the_receipts_claim
             cc.free()
     rec = recursion.Recursor(hal, rec_blob, blob, entry.code_object_path("recursion"), po2=12, segment_roots=roots)
     root = rec.fold([rec.lift(s, cl) for s, cl in zip(seals, claims)])
-    want = r0.ReceiptClaim.make(claims[0].pre, claims[-1].post, claims[-1].exit_system, claims[-1].exit_user, bytes(claims[-1].output_digest))
-    assert rec.verify(root) and root.claim.digest() == want.digest() and bytes(root.claim.output_digest) == r0.output_digest(receipt.journal)
+    want = r0.ReceiptClaim.make(claims[0].pre, claims[-1].post, claims[halting].exit_system, claims[halting].exit_user, bytes(claims[halting].output_digest))
+    assert rec.verify(root) and root.claim.digest() == want.digest() and bytes(root.claim.output_digest) == r0.output_digest(receipt.journal) and root.claim.exit_system == 0
     assert orc.circuit(rec_blob).verify(root.seal, code_root=rec.control_root) == (0, "ok")
     lifted = [rec.lift(seals[0], claims[0]), rec.lift(seals[1], claims[1])]
     with pytest.raises(r0.R0HipError, match="do not follow one another"):
@@ -232,7 +234,7 @@ def test_the_segments_of_a_proved_run_join_into_one_root_with_the_receipts_claim
     vm.load_elf(elf_of(_guest(2000), 0x400))
     vm.set_input([7, 0x01020304])
     assert vm.run(segment_po2=11, keep_trace=True, boundary_rows=True) == (0, 0)
-    k = len(vm.segments()) - 1
+    k = max(i for i, sg in enumerate(vm.segments()) if sg.user_cycles)  # the segment that halts
     seg, honest = vm.segments()[k], vm.claims()[k]
     size = r0.TRACE_MIN_PO2
     code_cols, synthetic, _ = hal.witgen(gc, size, 0)

@@ -10,8 +10,9 @@ host milliseconds per segment (executor thread; it overlaps the device), device-
 generation and proof.  The receipt is verified against the image id before the line is printed.
 usage: python tools/bench_session.py [--po2 20] [--cycles 8000000] [--guest loop|rsa|camt53] [--repeat 2]
 Several GPUs: launch it under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... tools/bench_session.py ...`:
-every rank executes the guest and proves segments rank, rank + N, ... (r0h_prove_elf_part); rank 0 collects the receipts
-(driver.prove_elf_sharded: point-to-point, no collective on the data path), merges and verifies them and prints the line.
+every rank executes the guest and commits segments rank, rank + N, ...; the ranks exchange their segments' records (28 words each: one
+all-reduce -- the session challenge depends on every segment), finish their proofs, and rank 0 collects the receipts
+(driver.prove_elf_sharded), merges and verifies them with the ELF and prints the line.
 --backend gloo --share-device rehearses that on one GPU."""
 import argparse
 import json
@@ -76,7 +77,7 @@ def main():
         elf, stream, what = mod.elf_and_input()
     else:
         from test_rv32im import ADDI, A0, A1, A7, B, ECALL, I, LI, R, S, S0, T0, T1, T2, flat
-        buf, scratch, n_loop = 0x10000, 0x20000, max(1, (args.cycles - 40) // 7)
+        buf, scratch, n_loop = r0.JOURNAL_BASE, 0x20000, max(1, (args.cycles - 40) // 7)  # (COMMIT names words of the journal window)
         # reads two input words, then n_loop times: store the counter at scratch + ((t1 & 0x7fc) << 4) (a 32 KiB window, 32 pages), count
         prog = flat(LI(A0, buf), ADDI(A1, 0, 2), ADDI(A7, 0, 1), ECALL, LI(S0, scratch), LI(T2, n_loop), ADDI(T1, 0, 0),
                     I(0x7FC, T1, 7, T0, 0x13), I(4, T0, 1, T0, 0x13), R(0, S0, T0, 0, T0), S(0, T1, T0, 2), ADDI(T1, T1, 4), ADDI(T2, T2, -1), B(-24, 0, T2, 1),
@@ -111,7 +112,7 @@ def main():
             cc = hal.code_commit(gc, size)
             roots[size] = cc.root()
             cc.free()
-    verdict = receipt.verify(blob, roots, image_id)
+    verdict = receipt.verify(blob, roots, None, elf=elf)  # with the ELF: image id, seals, claims, the session's challenge and balance
     assert verdict[:2] == (0, "ok"), verdict
     if args.oracle_check:
         import orc_binding

@@ -97,7 +97,7 @@ def main():
     oc, gc = orc.circuit(blob), hal.load_circuit(blob)
     rng = np.random.default_rng(2026)
     fixed = {}
-    t0, n, rows_total, taken, tampered, lied = time.time(), 0, 0, 0, 0, 0
+    t0, n, rows_total, taken, tampered, lied, parity = time.time(), 0, 0, 0, 0, 0, 0
     while time.time() - t0 < budget:
         prog = random_program(rng, int(rng.integers(40, 990)))  # the closing branch reaches back at most 4 KiB
         vm = r0.Vm()
@@ -108,39 +108,44 @@ def main():
         vm.set_input([int(v) for v in rng.integers(0, 1 << 32, 8)])
         assert vm.run(segment_po2=20, keep_trace=True, boundary_rows=True) == (0, 0)
         rows, bounds = vm.preflight_arrays(0)
-        po2 = max(9, int(np.ceil(np.log2(len(rows) + len(bounds)))))
+        po2 = max(r0.TRACE_MIN_PO2, int(np.ceil(np.log2(len(rows) + len(bounds)))))
         if po2 not in fixed:
             code, synthetic, _ = hal.witgen(gc, po2, 0)
             synthetic.free()
-            fixed[po2] = (hal.code_commit(gc, po2, code), oc.witgen(po2, 0)[0])
-            code.free()
-        cc, ocode = fixed[po2]
+            fixed[po2] = (hal.code_commit(gc, po2, code), oc.witgen(po2, 0)[0], code)
+        cc, ocode, code = fixed[po2]
         root = cc.root()
         data, glob = vm.trace_witness(0, po2)
-        dev, dglob = hal.trace_witgen(rows, bounds, po2)
+        dev, dglob = hal.trace_witgen(rows, bounds, po2, circuit=gc)
         if not np.array_equal(dev.to_host(), data) or not np.array_equal(dglob, glob):
             print("FAILED on program %d: the device's witness differs from the host reference" % n)
             sys.exit(1)
+        glob[r0.TRACE_GAMMA:r0.TRACE_GAMMA + 16] = [orc.enc(int(v)) for v in rng.integers(0, 2013265921, 16)]  # one seal outside a session: any challenge
+        glob = hal.logup_totals(gc, po2, code, dev, glob)
         seal = hal.prove_segment(gc, po2, cc, dev, glob)
-        want = oc.prove(po2, ocode, data, glob)
-        if not np.array_equal(seal, want) or oc.verify(seal, code_root=root)[0] != 0 or r0.verify_seal(blob, seal, code_root=root)[0] != 0:
-            print("FAILED on program %d (%d rows, po2 %d)" % (n, len(rows), po2))
+        if oc.verify(seal, code_root=root)[0] != 0 or r0.verify_seal(blob, seal, code_root=root)[0] != 0:
+            print("FAILED on program %d (%d rows, po2 %d): a verifier refuses the device's seal" % (n, len(rows), po2))
             sys.exit(1)
+        if n % 10 == 0:  # (the oracle takes seconds per 2^16-row proof: every tenth program is proved by it as well)
+            if not np.array_equal(oc.logup_totals(po2, ocode, data, glob), glob) or not np.array_equal(seal, oc.prove(po2, ocode, data, glob)):
+                print("FAILED on program %d (%d rows, po2 %d): the device's seal is not the oracle's" % (n, len(rows), po2))
+                sys.exit(1)
+            parity += 1
         if n % 8 == 0:  # a register read that does not return what was written: refused by both verifiers
             reads = [r for r in range(len(rows)) if (rows[r, 2] >> 15) & 31]
             bad = rows.copy()
             bad[reads[len(reads) // 2], 4] ^= 1 << int(rng.integers(0, 32))
-            hal.trace_witgen(bad, bounds, po2, into=dev)
-            forged = hal.prove_segment(gc, po2, cc, dev, glob)
+            hal.trace_witgen(bad, bounds, po2, into=dev, circuit=gc)
+            forged = hal.prove_segment(gc, po2, cc, dev, hal.logup_totals(gc, po2, code, dev, glob))
             if oc.verify(forged, code_root=root)[0] != 4 or r0.verify_seal(blob, forged, code_root=root)[0] != 4:
                 print("FAILED on program %d: an inconsistent register read was accepted" % n)
                 sys.exit(1)
             tampered += 1
-        if n % 8 == 4:  # an instruction that computes something else, memory kept consistent around the lie: refused by both verifiers
+        if n % 8 == 4:  # a register whose value changes between a dead write and the next write of it: refused by both verifiers
             lie = dead_write_lie(rows, bounds, rng)
             if lie is not None:
-                hal.trace_witgen(lie[0], lie[1], po2, into=dev)
-                forged = hal.prove_segment(gc, po2, cc, dev, glob)
+                hal.trace_witgen(lie[0], lie[1], po2, into=dev, circuit=gc)
+                forged = hal.prove_segment(gc, po2, cc, dev, hal.logup_totals(gc, po2, code, dev, glob))
                 if oc.verify(forged, code_root=root)[0] != 4 or r0.verify_seal(blob, forged, code_root=root)[0] != 4:
                     print("FAILED on program %d: a wrong result was accepted" % n)
                     sys.exit(1)
@@ -151,9 +156,9 @@ def main():
         taken += int((np.isin(rows[:, 2] & 0x7f, (0x63, 0x6f)) & (rows[:, 3] != rows[:, 1] + 4)).sum())
         if n % 50 == 0:
             print("%d executions proved (%d cycles, %d taken branches and jumps) after %.0f s" % (n, rows_total, taken, time.time() - t0), flush=True)
-    print("soak ok: %d random executions (%d cycles, %d taken branches and jumps): device witness == host reference and device seal == oracle seal word for word, "
-          "both verifiers accept bound to the control root; %d tampered runs (a register read back wrong) and %d runs with a wrong result in a dead register (memory consistent, "
-          "the instruction not) refused by both" % (n, rows_total, taken, tampered, lied))
+    print("soak ok: %d random executions (%d cycles, %d taken branches and jumps): device witness == host reference word for word, both verifiers accept every seal "
+          "bound to the control root, %d seals proved by the oracle too and equal word for word; %d tampered runs (a register read back wrong) and %d runs with a "
+          "dead register's value altered refused by both" % (n, rows_total, taken, parity, tampered, lied))
 
 
 if __name__ == "__main__":
