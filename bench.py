@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: segments/sec at po2 = 20 through the C-ABI segment prover, one process per GPU.
+"""Headline benchmark: segments/sec at po2 = 20 proving the camt53 guest, one process per GPU (BASELINE.json metric, configs[1]).
 
-A step = one pass of the hot path (r0h_prove_segment: commit CODE/DATA/ACCUM, eval_check, DEEP, FRI, queries -> seal)
-over one synthetic segment per in-flight context, witness already resident in HBM.  Segments are independent, so ranks
-shard them with no data-path collective ("weak" scaling: every rank proves its own segments); torch.distributed (RCCL)
-is used only for the barrier and the reductions of the timing.
+A step = one pass of the whole path over one batch: every session context of the rank runs `prove(env, elf)` once -- the
+hand-assembled hyperfridge guest (tools/guest_camt53.py: RSA-2048 x3, SHA-256, AES-128-CBC, inflate, unzip, camt.053 fields; its
+journal is the reference's committed receipt's) is EXECUTED on a host thread, its compact preflight rows are uploaded and expanded
+into the trace circuit's DATA group on the device, and its twelve 2^20-row segments are proved in two phases (commit every DATA
+group, derive the session challenge, finish every proof) -- executor, witness generation and proofs all inside the timed region.
+Sessions are independent receipts, so ranks run their own with no data-path collective ("weak" scaling: BASELINE configs[3]'s
+batch of receipts); torch.distributed (RCCL) carries the barrier and the reductions of the timing.  `--sharded-session` proves
+ONE session on all ranks instead (configs[2]: segments rank, rank + N, ...; the ranks exchange 28 words per segment between the
+phases -- the one collective of the path).
 
-Workload (BASELINE.json configs[1] shape): the bundled camt53 trace does not exist as a file
-and cannot be produced without the risc0 3.0.5 executor (Rust, absent), so the segment is synthetic: circuit blob
-circuits/bench.r0c, W = (16 CODE, 192 DATA, 48 ACCUM) = 256 columns, 2^20 rows, ~20k mul + ~22.6k add/sub per point.
+Kept beside it on the same line so that the series r01..r04 stays readable: `synthetic_bench_circuit` (the rounds 1-3 headline:
+a resident 256-column synthetic segment per context, r0h_prove_segment alone) and `trace_circuit_resident` (the same protocol
+on segments of the real run).  `--circuit bench|small ...` or `--segments S` run that synthetic benchmark as the whole job.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel family (largest share of device time): algorithmic HBM bytes / its HIP-event time,
+  roofline      dominant kernel family of a session (largest share of device time): algorithmic HBM bytes / its HIP-event time,
                 `traffic` = PMC-measured HBM bytes per launch (profiles/*/pmc_traffic.json, separate rocprofv3 --pmc passes)
-  cpu_baseline  the oracle (CPU restatement, OpenMP, every host core of the affinity mask) proving the same 2^20-row segment
-                ("port": the risc0 CPU prover itself cannot be built here); rank 0, N = 1 only
+  cpu_baseline  the oracle (CPU restatement, OpenMP, as many threads as the cgroup lets run) proving the session's first segment --
+                a full 2^20-row trace of the real run -- itself ("port": the risc0 CPU prover cannot be built here); rank 0, N = 1 only
 """
 import argparse
 import glob
@@ -206,8 +211,12 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--po2", type=int, default=20)
-    ap.add_argument("--circuit", default="bench")
-    ap.add_argument("--contexts", type=int, default=8, help="segments in flight per GPU (one context + host thread each)")
+    ap.add_argument("--circuit", default="camt53", help="camt53 (default): the real workload -- sessions of the camt53 guest over the trace circuit; "
+                                                       "bench / small / ...: the synthetic benchmark of rounds 1-3 on that circuit blob")
+    ap.add_argument("--contexts", type=int, default=0, help="camt53: sessions in flight per GPU (default 2; each has an executor thread and two prover lanes); "
+                                                          "synthetic: segments in flight per GPU (default 8; one context + host thread each)")
+    ap.add_argument("--sharded-session", action="store_true", help="camt53: all ranks prove ONE session together (segments rank, rank + N, ...; records exchanged "
+                                                                    "between the two phases) instead of a session each -- BASELINE configs[2], strong scaling")
     ap.add_argument("--cpu-po2", type=int, default=-1, help="po2 of the CPU-baseline sample: default = --po2 (the headline segment itself, about half a minute "
                                                               "on 16 cores, no scaling); smaller = a bounded sample scaled by rows; 0 disables")
     ap.add_argument("--segments", type=int, default=0, help="BASELINE configs[2]/[3]: prove a fixed batch of this many segments, sharded "
@@ -216,7 +225,7 @@ def main():
     ap.add_argument("--keep-every", type=int, default=8)
     ap.add_argument("--profile-mode", action="store_true", help="for tools/collect_profiles.sh: no prove_elf session and no re-committing comparison, so that "
                                                                  "the process holds warm-up + timed + witgen + accounting segments of ONE configuration")
-    ap.add_argument("--no-session", action="store_true", help="skip the prove(env, elf) run reported in prove_elf_session")
+    ap.add_argument("--no-session", action="store_true", help="(no longer used: the session IS the headline; kept so that older command lines parse)")
     ap.add_argument("--recommit-code", action="store_true", help="commit the CODE group inside every proof (rounds 1-2 behaviour) instead of once per (circuit, po2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rehearsing ranks on one box)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses device 0")
@@ -255,7 +264,24 @@ def main():
     env.barrier()  # local rank 0 may have been building: nobody loads the library before it is finished
     import hyperfridge_r0_amd as r0
 
-    po2, n_ctx = args.po2, max(1, args.contexts)
+    if args.circuit == "camt53" and args.segments:
+        args.circuit = "bench"  # a fixed batch of synthetic segments (BASELINE configs[2] on the synthetic circuit: tests/test_gpu_configs.py)
+    if args.circuit == "camt53":
+        return session_bench(args, env, entry, torch, local_rank, numa)
+    line = synthetic_bench(args, env, entry, torch, local_rank, numa)
+    if env.rank == 0:
+        emit_result(line)
+    env.close()
+
+
+def synthetic_bench(args, env, entry, torch, local_rank, numa, embedded=False):
+    """The benchmark of rounds 1-3: a step = one r0h_prove_segment per in-flight context over a resident synthetic segment of
+    circuits/<circuit>.r0c (bench: W = (16 CODE, 192 DATA, 48 ACCUM) = 256 columns, ~20k mul + ~22.6k add/sub per point).  Returns the
+    JSON line (rank 0) / None; embedded = True: a short run inside the camt53 benchmark, no CPU baseline and no variants."""
+    import numpy as np
+    import hyperfridge_r0_amd as r0
+    from hyperfridge_r0_amd import driver
+    po2, n_ctx = args.po2, max(1, args.contexts or 8)
     if args.cpu_po2 < 0:
         args.cpu_po2 = min(po2, 20)
     blob = np.fromfile(entry.circuit_blob_path(args.circuit), dtype=np.uint32)
@@ -350,7 +376,7 @@ def main():
         elapsed, units = driver.run_timed(env, step, args.steps, args.warmup, device_sync, many_fn=steps_back_to_back if n_ctx > 1 else None)
         scaling = "weak"
         uncached = None
-        if code_commit is not None and not args.profile_mode:  # the same K steps with CODE committed inside every proof, for comparison.  Not `value`.
+        if code_commit is not None and not args.profile_mode and not embedded:  # the same K steps with CODE committed inside every proof, for comparison.  Not `value`.
             use_commit[0] = False
             el1, un1 = driver.run_timed(env, step, args.steps, 1, device_sync, many_fn=steps_back_to_back if n_ctx > 1 else None)
             uncached = un1 / el1
@@ -368,8 +394,10 @@ def main():
             counter[0] += n
             return got
 
-        el2, un2 = driver.run_timed(env, lambda i: steps_with_witgen(1), args.steps, 0, device_sync, many_fn=steps_with_witgen if n_ctx > 1 else None)
-        incl = un2 / el2
+        incl = None
+        if not embedded:
+            el2, un2 = driver.run_timed(env, lambda i: steps_with_witgen(1), args.steps, 0, device_sync, many_fn=steps_with_witgen if n_ctx > 1 else None)
+            incl = un2 / el2
     # per-kernel accounting: HIP events around every launch, on one context running alone, over as many segments as were
     # timed (outside the timed region, so the events neither perturb `value` nor see another context's kernels)
     lanes[0]["hal"].kernel_timing(True)
@@ -382,16 +410,12 @@ def main():
     # `prove(env, elf)` end to end, once, beside the headline (rank 0 of a single-GPU run): the hand-assembled guest of
     # tools/guest_camt53.py on the reference's EBICS fixture, executed on a host thread, its compact preflight rows expanded on the device,
     # every segment proved with circuits/trace.r0c -- executor, witness generation and proofs all inside the timed region
-    session = None
-    if env.rank == 0 and env.world == 1 and not args.segments and not args.no_session and not args.profile_mode and po2 == 20:
+    trace_resident = None
+    if embedded and env.rank == 0 and po2 == 20:  # the same protocol (witnesses resident, one segment in flight per context) on segments of the real run
         try:
-            session = prove_elf_session(lanes[0]["hal"], entry)
-        except Exception as exc:  # noqa: BLE001 -- the headline does not depend on it
-            session = {"error": str(exc)[:300]}
-        try:  # ... and the headline's own protocol (witnesses resident, one segment in flight per context) on that circuit and that run
-            session["trace_circuit_resident"] = trace_circuit_resident([ln["hal"] for ln in lanes], entry, args.steps)
+            trace_resident = trace_circuit_resident([ln["hal"] for ln in lanes], entry, args.steps)
         except Exception as exc:  # noqa: BLE001
-            session["trace_circuit_resident"] = {"error": str(exc)[:300]}
+            trace_resident = {"error": str(exc)[:300]}
 
     if env.rank == 0:
         steps = max(args.steps, 1)
@@ -405,7 +429,7 @@ def main():
             achieved = st["alg_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name, launches / steps, args.circuit),
-                        "launches_per_step": launches / steps, "avg_launch_ms": round(st["total_ms"] / launches, 4),
+                        "launches_per_segment": launches / steps, "avg_launch_ms": round(st["total_ms"] / launches, 4),
                         "alg_bytes_per_launch": round(st["alg_bytes"] / launches),
                         "share_of_device_time": round(st["total_ms"] / max(sum(v["total_ms"] for v in kstats.values()), 1e-9), 4),
                         "note": "this kernel is VALU-integer bound (Poseidon2: ~1.36k Montgomery products per permutation, "
@@ -439,7 +463,7 @@ def main():
         cols = sum(circuit.group_size)
         seg_bytes = (68 * cols + 3132) * (1 << po2)  # Bytes(C) = 68 MiB*C + 3132 MiB at 2^20 rows
         line = {
-            "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
+            "metric": "segments/sec (po2=%d) through r0h_prove_segment on a resident synthetic segment of %s.r0c (the rounds 1-3 headline)" % (po2, args.circuit),
             "value": round(value, 4), "unit": "segments/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "value_with_witgen_in_timed_region": round(value, 4) if incl is None else round(incl, 4),
@@ -455,69 +479,186 @@ def main():
                        "segments_per_step_per_gpu": n_ctx, "fixed_batch_segments": args.segments or None,
                        "parallelism": "segment-parallel x%d" % env.world, "host_threads": "rank 0: " + numa},
             "roofline": roofline,
-            "cpu_baseline": cpu_baseline(blob, args.cpu_po2, po2) if (args.cpu_po2 and env.world == 1) else None,
+            "cpu_baseline": cpu_baseline(blob, args.cpu_po2, po2) if (args.cpu_po2 and env.world == 1 and not embedded) else None,
             "segment_hbm_model": {"alg_bytes_per_segment": seg_bytes, "achieved_GBs_per_gpu": round(seg_bytes * value / env.world / 1e9, 2),
                                   "frac_of_8TBs": round(seg_bytes * value / env.world / 1e9 / HBM_PEAK_GBS, 5)},
-            "prove_elf_session": session,
+            "trace_circuit_resident": trace_resident,
             "phases_ms_last_segment": {n: round(ms, 3) for n, ms in phases},
             "kernels_ms_per_segment": {k: round(v["total_ms"] / steps, 3) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
             # algorithmic bytes / device time of each kernel family (per-kernel achieved GB/s)
             "kernels_alg_GBs": {k: round(v["alg_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])
                                 if v["total_ms"] > 0 and v.get("alg_bytes")},
         }
-        emit_result(line)
+    else:
+        line = None
     if code_commit is not None:
         code_commit.free()
     for ln in lanes:
         for key in ("code", "data", "circuit"):
             ln[key].free()
         ln["hal"].close()
-    env.close()
+    return line
 
 
-def prove_elf_session(hal, entry):
-    """r0h_prove_elf over the hand-assembled hyperfridge pipeline (tools/guest_camt53.py: RSA x3, SHA-256, AES-128-CBC, inflate, unzip,
-    camt.053 fields) on the reference's fixture with the trace circuit at po2 = 20, timed as one call (the second of two: the first
-    pays for the code object, the CODE commitment, the pools).  Its journal is compared with the reference's committed receipt's."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+def session_bench(args, env, entry, torch, local_rank, numa):
+    """The headline: sessions of the camt53 guest, end to end (module docstring)."""
     import numpy as np
-    import guest_camt53
     import hyperfridge_r0_amd as r0
+    from hyperfridge_r0_amd import driver
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import guest_camt53
+    po2 = args.po2
     image, stream, what = guest_camt53.elf_and_input(form=1)
     want_journal = bytes(json.load(open(os.path.join(ROOT, "tests", "golden", "reference_receipt_6bb95807_latest.json")))["journal"]["bytes"])
     blob = np.fromfile(entry.circuit_blob_path("trace"), dtype=np.uint32)
-    gc = hal.load_circuit(blob, entry.code_object_path("trace"))
-    try:
-        for _ in range(2):
-            t0 = time.perf_counter()
-            receipt, image_id, cycles = hal.prove_elf(gc, image, stream, segment_po2=20)
-            wall = time.perf_counter() - t0
-            st = hal.last_session_stats()
+    n_ses = 1 if args.sharded_session else max(1, args.contexts or 2)
+    lanes = []
+    for k in range(n_ses):
+        hal = r0.Hal(local_rank)
+        lanes.append(dict(hal=hal, gc=hal.load_circuit(blob, entry.code_object_path("trace")), segments=0, walls=[], receipt=None))
+
+    def one_session(lane):
+        t0 = time.perf_counter()
+        if args.sharded_session:
+            receipt, image_id, cycles = driver.prove_elf_sharded(env, lane["hal"], lane["gc"], image, stream, segment_po2=po2)
+            n = lane["hal"].last_session_stats()["segments"]  # this rank's share
+        else:
+            receipt, image_id, cycles = lane["hal"].prove_elf(lane["gc"], image, stream, segment_po2=po2)
+            n = lane["hal"].last_session_stats()["segments"]
+        lane["walls"].append(time.perf_counter() - t0)
+        lane["receipt"], lane["cycles"], lane["segments"] = receipt, cycles, lane["segments"] + n
+        return n
+
+    def run_lanes(n_each):
+        """every session context runs n_each sessions back to back on its own host thread (a context starts its next session as
+        soon as its previous receipt is out); returns the segments proved; a failed lane re-raises here"""
+        before = sum(ln["segments"] for ln in lanes)
+        errors = []
+
+        def guarded(lane):
+            try:
+                for _ in range(n_each):
+                    one_session(lane)
+            except BaseException as exc:  # noqa: BLE001 -- reported below
+                errors.append(exc)
+
+        if len(lanes) == 1:
+            guarded(lanes[0])
+        else:
+            ts = [threading.Thread(target=guarded, args=(ln,)) for ln in lanes]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        if errors:
+            raise errors[0]
+        return sum(ln["segments"] for ln in lanes) - before
+
+    def device_sync():
+        for ln in lanes:
+            ln["hal"].sync()
+        torch.cuda.synchronize()
+
+    elapsed, units = driver.run_timed(env, lambda i: run_lanes(1), args.steps, args.warmup, device_sync, many_fn=run_lanes if n_ses > 1 else None)
+    timed_walls = sorted(w for ln in lanes for w in ln["walls"][-args.steps:])
+    stats = lanes[0]["hal"].last_session_stats()
+    line = None
+    if env.rank == 0:
+        # ---- outside the timed region: every lane's last receipt verified the way the reference's verifier would, with the ELF
+        receipt = lanes[0]["receipt"]
+        seals = receipt.seals()
         roots = {}
-        for _, seal in receipt.seals():
+        for _, seal in seals:
             size = r0.verify_seal(blob, seal)[2]
             if size not in roots:
-                cc = hal.code_commit(gc, size)
+                cc = lanes[0]["hal"].code_commit(lanes[0]["gc"], size)
                 roots[size] = cc.root()
                 cc.free()
-        verdict = receipt.verify(blob, roots, image_id)
-        n = st["segments"]
-        return {"value": round(n / wall, 3), "unit": "segments/s (executor thread + two prover lanes on the one GPU; execution, device witness generation and proofs inside the timed call)",
-                "segments": n, "cycles": cycles, "wall_s": round(wall, 4), "guest": what,
-                "executor_MHz_with_trace_kept": round(cycles / st["executor_s"] / 1e6, 1), "executor_host_ms_per_segment": round(1e3 * st["executor_s"] / n, 2),
-                "witgen_ms_per_segment": round(st["witgen_ms"] / n, 2), "prove_ms_per_segment": round(st["prove_ms"] / n, 2),
-                "circuit": "trace.r0c W=(%d accum, %d code, %d data): one contiguous run, every instruction's semantics (RV32IM, the ecalls' register and memory effects), memory consistency" % tuple(gc.group_size),
-                "receipt_verified_against_image_id": verdict[:2] == (0, "ok"),
-                "journal_is_the_reference_receipt_fixtures": receipt.journal == want_journal,
-                "journal": r0.journal_commitment(receipt.journal).decode()[:80] + " ..."}
-    finally:
-        gc.free()
+        verified = all(ln["receipt"].verify(blob, roots, None, elf=image)[:2] == (0, "ok") for ln in lanes if ln["receipt"] is not None)
+        n_seg = len(seals)
+        # ---- per-kernel accounting: one session alone on one context with ONE prover lane (so that every launch is on the context
+        # whose HIP events are read), outside the timed region
+        os.environ["R0H_SESSION_LANES"] = "1"
+        try:
+            lanes[0]["hal"].kernel_timing(True)
+            lanes[0]["hal"].prove_elf(lanes[0]["gc"], image, stream, segment_po2=po2)
+            kstats = lanes[0]["hal"].kernel_stats()
+            phases = lanes[0]["hal"].last_profile()
+            lanes[0]["hal"].kernel_timing(False)
+        finally:
+            del os.environ["R0H_SESSION_LANES"]
+        gs = lanes[0]["gc"].group_size
+        roofline = None
+        if kstats:
+            name, st = max(kstats.items(), key=lambda kv: kv[1]["total_ms"])
+            launches = max(st["launches"], 1)
+            achieved = st["alg_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": pmc_traffic(name, launches / n_seg, "trace"), "launches_per_segment": round(launches / n_seg, 3), "avg_launch_ms": round(st["total_ms"] / launches, 4),
+                        "alg_bytes_per_launch": round(st["alg_bytes"] / launches),
+                        "share_of_device_time": round(st["total_ms"] / max(sum(v["total_ms"] for v in kstats.values()), 1e-9), 4),
+                        "note": "measured over one whole session (%d segments) on one context with one prover lane; this kernel is VALU-integer bound "
+                                "(Poseidon2: ~1.36k Montgomery products per permutation); its HBM fraction is reported because the metric asks for it: DESIGN.md 6" % n_seg}
+        # ---- the series of rounds 1-3, kept readable: the synthetic 256-column circuit and the resident trace segments (short runs)
+        synthetic = None
+        if env.world == 1 and not args.profile_mode and po2 == 20:
+            for ln in lanes:  # (the sessions' pooled buffers go back to the device first)
+                ln["hal"].sync()
+            import copy
+            sargs = copy.copy(args)
+            sargs.circuit, sargs.contexts, sargs.steps, sargs.warmup, sargs.cpu_po2, sargs.segments = "bench", 8, 3, 1, 0, 0
+            try:
+                sl = synthetic_bench(sargs, env, entry, torch, local_rank, numa, embedded=True)
+                synthetic = {"value": sl["value"], "unit": sl["unit"], "ms_per_step": sl["ms_per_step"], "steps": 3, "segments_in_flight": 8, "workload": sl["config"]["workload"],
+                             "roofline": sl["roofline"], "trace_circuit_resident": sl["trace_circuit_resident"]}
+            except Exception as exc:  # noqa: BLE001 -- the headline does not depend on it
+                synthetic = {"error": str(exc)[:300]}
+        cols = sum(gs)
+        seg_bytes = (68 * cols + 3132) * (1 << po2)  # SURVEY.md 8(d): Bytes(C) = 68 MiB*C + 3132 MiB at 2^20 rows
+        value = units / elapsed
+        steps = max(args.steps, 1)
+        line = {
+            "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
+            "value": round(value, 4), "unit": "segments/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.sharded_session else "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "configs[1]: the camt53 guest at po2 = 20 -- prove(env, elf) end to end: %s; executed on a host thread (%d cycles, %d segments of at most 2^20 rows), rows "
+                                   "expanded on the device, proved with circuits/trace.r0c W=(%d accum, %d code, %d data) in two phases under the session challenge; %s; every receipt "
+                                   "verified with the ELF after the timed region.  data is 'synthetic' in the contract's sense only: the guest is hand-assembled (the reference ships no ELF) and its "
+                                   "input is the reference's own EBICS fixture" % (what, lanes[0]["cycles"], n_seg, gs[0], gs[1], gs[2],
+                                   "ONE session sharded over all ranks (records all-reduced between the phases)" if args.sharded_session else "%d session(s) in flight per GPU, each with an executor thread and two prover lanes; a step = every session context proves one session" % n_ses),
+                       "po2": po2, "columns": cols, "segments_per_session": n_seg, "sessions_per_step_per_gpu": n_ses, "seal_words": int(seals[0][1].size),
+                       "parallelism": ("one session over %d GPUs" if args.sharded_session else "independent sessions x%d GPUs") % env.world, "host_threads": "rank 0: " + numa},
+            "receipts_verified_with_the_elf": bool(verified),
+            "journal_is_the_reference_receipt_fixtures": receipt.journal == want_journal,
+            "journal": r0.journal_commitment(receipt.journal).decode()[:80] + " ...",
+            "per_session_wall_s": {"median": round(timed_walls[len(timed_walls) // 2], 4), "min": round(timed_walls[0], 4), "max": round(timed_walls[-1], 4), "sessions_timed": len(timed_walls)},
+            "session_stages": {"executor_MHz_with_trace_kept": round(stats["cycles"] / max(stats["executor_s"], 1e-9) / 1e6, 1), "executor_host_ms_per_segment": round(1e3 * stats["executor_s"] / max(stats["segments"], 1), 2),
+                               "witgen_ms_per_segment": round(stats["witgen_ms"] / max(stats["segments"], 1), 2), "prove_ms_per_segment_on_a_lane": round(stats["prove_ms"] / max(stats["segments"], 1), 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline_trace(blob, image, stream, po2) if (args.cpu_po2 and env.world == 1) else None,
+            "segment_hbm_model": {"alg_bytes_per_segment": seg_bytes, "achieved_GBs_per_gpu": round(seg_bytes * value / env.world / 1e9, 2),
+                                  "frac_of_8TBs": round(seg_bytes * value / env.world / 1e9 / HBM_PEAK_GBS, 5)},
+            "synthetic_bench_circuit": synthetic,
+            "phases_ms_last_segment": {n: round(ms, 3) for n, ms in phases},
+            "kernels_ms_per_segment": {k: round(v["total_ms"] / n_seg, 3) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
+            "kernels_alg_GBs": {k: round(v["alg_bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])
+                                if v["total_ms"] > 0 and v.get("alg_bytes")},
+        }
+        emit_result(line)
+    for ln in lanes:
+        ln["receipt"] = None
+        ln["gc"].free()
+        ln["hal"].close()
+    env.close()
+    return 0
 
 
 def trace_circuit_resident(hals, entry, steps):
-    """`value`'s protocol on the real circuit: the first len(hals) segments of the camt53 guest's run (2^20 rows each), their witnesses
-    expanded once and resident in HBM, one in flight per context, each proved `steps` times back to back with circuits/trace.r0c.  No
-    executor and no witness generation in the timed region -- what is left is the device's rate on 308 columns of real trace."""
+    """The synthetic benchmark's protocol on the real circuit: the first len(hals) segments of the camt53 guest's run (2^20 rows each), their
+    witnesses expanded once and resident in HBM, one in flight per context, each proved `steps` times back to back with circuits/trace.r0c
+    under a fixed challenge.  No executor, no witness generation and no session phases in the timed region -- what is left is the device's
+    rate on 138 + 40 columns of real trace."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import threading
     import numpy as np
@@ -534,17 +675,21 @@ def trace_circuit_resident(hals, entry, steps):
         if finished:
             break  # the last segment is a short one: left out
         rows, bounds = vm.preflight_arrays(k)
-        traces.append((rows.copy(), bounds.copy(), vm.claims()[k].globals()))
+        traces.append((rows.copy(), bounds.copy(), vm.claims()[k].globals(), k + 1))
         vm.release_trace(k)
     blob = np.fromfile(entry.circuit_blob_path("trace"), dtype=np.uint32)
-    lanes, cc = [], None
+    lanes, cc, code = [], None, None
     try:
-        for hal, (rows, bounds, claim) in zip(hals, traces):
+        for hal, (rows, bounds, claim, number) in zip(hals, traces):
             gc = hal.load_circuit(blob, entry.code_object_path("trace"))
             lanes.append(dict(hal=hal, gc=gc))
             if cc is None:
-                cc = hal.code_commit(gc, 20)
-            lanes[-1]["data"], lanes[-1]["glob"] = hal.trace_witgen(rows, bounds, 20, claim_globals=claim)
+                code, synthetic, _ = hal.witgen(gc, 20, 0)
+                synthetic.free()
+                cc = hal.code_commit(gc, 20, code)
+            data, glob = hal.trace_witgen(rows, bounds, 20, claim_globals=claim, number=number, closing=False, circuit=gc)
+            glob[r0.TRACE_GAMMA:r0.TRACE_GAMMA + 16] = np.arange(3, 19, dtype=np.uint32)  # a fixed challenge: these seals stand outside any session
+            lanes[-1]["data"], lanes[-1]["glob"] = data, hal.logup_totals(gc, 20, code, data, glob)
         errors = []
 
         def run(lane, n):
@@ -572,7 +717,7 @@ def trace_circuit_resident(hals, entry, steps):
         wall = all_lanes(n)
         return {"value": round(len(lanes) * n / wall, 3), "unit": "segments/s", "segments_in_flight": len(lanes), "steps": n, "ms_per_step": round(1e3 * wall / n, 2),
                 "circuit": "trace.r0c W=(%d accum, %d code, %d data)" % tuple(lanes[0]["gc"].group_size), "seal_words": int(lanes[0]["words"]),
-                "workload": "the first %d segments (2^20 rows each) of the camt53 guest's run, witnesses resident in HBM, CODE committed once" % len(lanes)}
+                "workload": "the first %d segments (2^20 rows each) of the camt53 guest's run, witnesses resident in HBM, CODE committed once, a fixed challenge" % len(lanes)}
     finally:
         for ln in lanes:
             if "data" in ln:
@@ -580,6 +725,59 @@ def trace_circuit_resident(hals, entry, steps):
             ln["gc"].free()
         if cc is not None:
             cc.free()
+        if code is not None:
+            code.free()
+
+
+def host_threads():
+    """(threads to use, cores in the affinity mask, cgroup CPU quota): as many threads as the cgroup lets run at once -- a box may expose
+    256 cores in the affinity mask to a job whose share is 16 (round 3 calibrated over 256 threads for 14 s to find that out)"""
+    avail = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
+    return min(avail, quota or avail), avail, quota
+
+
+def cpu_baseline_trace(blob, image, stream, po2):
+    """The oracle (CPU restatement, OpenMP) proving the FIRST segment of the camt53 session -- a full 2^20-row trace of the real run,
+    the unit `value` counts -- from the host reference witness, under a fixed challenge.  Only the proof is timed (the executor and the
+    witness expansion are host work on both sides)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import hyperfridge_r0_amd as r0
+    import orc_binding
+    orc = orc_binding.load()
+    cores, avail, quota = host_threads()
+    orc.L.orc_set_threads(cores)
+    oc = orc.circuit(blob)
+    vm = r0.Vm()
+    vm.load_elf(image)
+    vm.set_input(stream)
+    vm.run_segment(segment_po2=po2, keep_trace=True, boundary_rows=True)
+    seg = vm.segments()[0]
+    size = max(r0.TRACE_MIN_PO2, int(np.ceil(np.log2(seg.user_cycles + seg.boundary_rows))))
+    data, glob = vm.trace_witness(0, size, claim_globals=vm.claims()[0].globals())
+    vm.close()
+    code = oc.witgen(size, 0)[0]
+    glob[r0.TRACE_GAMMA:r0.TRACE_GAMMA + 16] = np.arange(3, 19, dtype=np.uint32)
+    glob = oc.logup_totals(size, code, data, glob)
+    t0 = time.perf_counter()
+    seal = oc.prove(size, code, data, glob)
+    dt = time.perf_counter() - t0
+    ok = oc.verify(seal, code_root=oc.code_root(code, size))[0] == 0
+    return {"value": round(1.0 / dt, 6), "unit": "segments/s", "cores": cores, "kind": "port", "cores_in_affinity_mask": avail, "cgroup_cpu_quota": quota,
+            "sample": "oracle/liborc.so (C, OpenMP) proved the first segment of the camt53 session itself -- %d cycles + %d boundary rows in a 2^%d-row trace of circuits/trace.r0c -- in "
+                      "%.2f s on %d threads (%d cores in the affinity mask, cgroup quota %s); seal %d words, accepted by the oracle's verifier: %s.  No scaling.  The risc0 CPU prover "
+                      "cannot be built here (Rust)." % (seg.user_cycles, seg.boundary_rows, size, dt, cores, avail, quota, seal.size, ok)}
 
 
 def rehearse(args):
@@ -613,33 +811,9 @@ def cpu_baseline(blob, cpu_po2, po2):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc_binding
     orc = orc_binding.load()
-    avail = os.cpu_count() or 1
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    quota = None  # the cgroup's CPU share, when one is set (a GPU box hands one GPU's job a slice of a many-core host)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            quota = max(1, int(round(int(q) / int(per))))
-    except Exception:
-        pass
-    oc = orc.circuit(blob)
-    # every core this process may run on is offered to the port; because a box may expose more cores in the affinity mask than its
-    # share lets run at once, the thread count is calibrated on a small segment first and the fastest one is used (and printed)
-    candidates = sorted({avail, min(avail, quota or avail), min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True)
+    cores, avail, quota = host_threads()  # as many threads as the cgroup lets run at once (no calibration over the whole affinity mask)
     calib = {}
-    if len(candidates) > 1:
-        ccode, cdata, cglob = oc.witgen(12, seed=1)
-        for t in candidates:
-            orc.L.orc_set_threads(t)
-            t0 = time.perf_counter()
-            oc.prove(12, ccode, cdata, cglob)
-            calib[t] = round(time.perf_counter() - t0, 3)
-        cores = min(calib, key=calib.get)
-    else:
-        cores = candidates[0]
+    oc = orc.circuit(blob)
     orc.L.orc_set_threads(cores)
 
     def timed(p):
@@ -653,8 +827,8 @@ def cpu_baseline(blob, cpu_po2, po2):
     out = {"value": round(1.0 / (dt * scale), 6), "unit": "segments/s", "cores": cores, "kind": "port",
            "cores_in_affinity_mask": avail, "cgroup_cpu_quota": quota, "thread_calibration_s_at_po2_12": calib or None,
            "sample": "oracle/liborc.so (C, OpenMP) proved one 2^%d-row segment of the same circuit in %.2f s on %d threads (%d cores in the affinity "
-                     "mask, cgroup quota %s; the thread count is the fastest of a calibration over %s)%s; seal %d words.  The risc0 CPU prover cannot "
-                     "be built here (Rust)." % (cpu_po2, dt, cores, avail, quota, sorted(calib) or [cores],
+                     "mask, cgroup quota %s; threads = what the cgroup lets run at once%s)%s; seal %d words.  The risc0 CPU prover cannot "
+                     "be built here (Rust)." % (cpu_po2, dt, cores, avail, quota, "",
                                                 "" if scale == 1 else "; scaled x%d by rows to 2^%d (favours the CPU: drops the log factor)" % (scale, po2), words)}
     if scale == 1 and po2 > 18:
         dt18, words18 = timed(18)

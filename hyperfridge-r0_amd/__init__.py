@@ -211,10 +211,32 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_PLAIN))
 _lib = None
 
 
+def _torch_runtime_first():
+    """A process that uses both this library and torch's GPU side holds two HIP runtimes: libr0hip.so links /opt/rocm's
+    libamdhip64.so.7, torch ships its own (no soname: the loader cannot share them).  On the GPU box the one that initialises SECOND
+    still finds the device only if it is this library's -- torch's, initialised second, finds none (round 3: gpurun_out/z_sharded2.err).
+    So torch's runtime goes first, always: if torch can be imported it is, and its device count is taken, before libr0hip.so is
+    opened -- whatever order the caller imports things in.  R0H_NO_TORCH=1 skips this (a process that will never touch torch)."""
+    import sys
+    if os.environ.get("R0H_NO_TORCH") == "1":
+        return
+    try:
+        if "torch" not in sys.modules:
+            import importlib.util
+            if importlib.util.find_spec("torch") is None:
+                return
+        import torch
+        if getattr(torch.version, "hip", None):
+            torch.cuda.is_available()  # initialises torch's HIP runtime (a device count, nothing more)
+    except Exception:  # a broken torch install must not take the library down with it
+        pass
+
+
 def lib():
     """Load libr0hip.so; fails loudly when the HIP library has not been built."""
     global _lib
     if _lib is None:
+        _torch_runtime_first()
         if not os.path.exists(LIB_PATH):
             raise R0HipError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                              "There is no CPU fallback." % LIB_PATH)
@@ -1017,14 +1039,7 @@ class Hal:
 
     def __init__(self, device=0):
         self.ctx = _vp()
-        try:
-            _check(lib().r0h_ctx_create(device, ctypes.byref(self.ctx)))
-        except R0HipError as exc:
-            if "no ROCm-capable device" in str(exc) and "torch" in sys.modules:
-                # torch brings its own HIP runtime: loaded AFTER libr0hip.so the process holds two, and the second to initialise finds no
-                # device (hyperfridge-r0_amd/driver.py).  Import torch before the first call into this library.
-                raise R0HipError(str(exc) + "  [torch was imported after libr0hip.so was first used: import torch first]") from None
-            raise
+        _check(lib().r0h_ctx_create(device, ctypes.byref(self.ctx)))  # (lib() has put torch's HIP runtime first: either import order works)
 
     def close(self):
         if self.ctx:

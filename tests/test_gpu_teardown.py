@@ -73,3 +73,18 @@ def test_garbage_collection_in_the_bad_old_order():
         print("collected", seal.size)
     """)
     assert out.returncode == 0 and "collected" in out.stdout and "terminate" not in out.stderr, out.stderr[-2000:]
+
+
+def test_the_library_and_torch_share_a_process_in_either_import_order():
+    """Round 3's verdict, item 5: libr0hip.so links /opt/rocm's HIP runtime, torch ships its own; whichever initialised second found no
+    device when that second one was torch's (gpurun_out/z_sharded2.err under torch.distributed.run).  hyperfridge_r0_amd.lib() now
+    puts torch's runtime first whatever the caller's import order: a child process each way round, a context and a device tensor in
+    both, exit status 0."""
+    orders = {
+        "library first": "import hyperfridge_r0_amd as r0\nhal = r0.Hal(0)\nimport torch\nt = torch.zeros(4, device='cuda') + 1\n",
+        "torch first": "import torch\nt = torch.zeros(4, device='cuda') + 1\nimport hyperfridge_r0_amd as r0\nhal = r0.Hal(0)\n",
+    }
+    tail = "import numpy as np\nb = hal.copy_from(np.arange(64, dtype=np.uint32))\nassert int(t.sum().item()) == 4 and b.to_host()[63] == 63\nhal.close()\nprint('both work')\n"
+    for name, head in orders.items():
+        out = subprocess.run([sys.executable, "-c", "import sys\nsys.path.insert(0, %r)\n" % ROOT + head + tail], capture_output=True, text=True, cwd=ROOT, timeout=600)
+        assert out.returncode == 0 and "both work" in out.stdout, (name, out.stderr[-2000:])
