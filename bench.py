@@ -70,7 +70,8 @@ def pmc_traffic(kernel, launches_per_segment=None, circuit="bench"):
         if not k or doc.get("device_code_sha256") != device_code_fingerprint(circuit):
             return None
         per_segment = doc.get("segments_profiled")
-        if launches_per_segment is not None and per_segment and abs(k["launches"] / per_segment - launches_per_segment) > 1e-9:
+        # (within 2 %: the profiled command commits a CODE group or two more than the accounting session, e.g. for the control roots it verifies against)
+        if launches_per_segment is not None and per_segment and abs(k["launches"] / per_segment - launches_per_segment) > 0.02 * launches_per_segment:
             return None
         return k["hbm_bytes_per_launch"]
     except Exception:

@@ -483,35 +483,45 @@ uint64_t r0h_vm_cycles(const r0h_vm* vm);
 const char* r0h_vm_segment_info(const r0h_vm* vm, size_t i, r0h_vm_segment* out);
 const char* r0h_vm_preflight(const r0h_vm* vm, size_t i, const r0h_preflight_row** rows, size_t* n);
 const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_bound** rows, size_t* n);
-/* ---- the trace circuit (circuits/trace.r0c, tools/gen_circuit.py): a circuit whose DATA group IS the preflight trace of a segment.
- * R0H_TRACE_COLUMNS columns of 2^po2 rows, column-major, Montgomery words: first the cycles (one row each), then the boundary rows
- * (one per register / word touched), then blank rows.  Per cycle: pc, next pc, the instruction word bit by bit with its one-hot
- * opcode and funct3, five accesses -- x[rs1], x[rs2], x[rd], the memory word, the fetched word -- each as (address, value, timestamp
- * of the previous access, own timestamp), and the work words of the arithmetic units: two operands bit by bit (U, V), two words in
- * radix-4 digits (Z, W), carries.  What the circuit constrains (tools/gen_circuit.py trace_constraints, 499 polynomials of
- * degree <= 5; csrc/trace.hpp fills the columns):
+/* ---- the trace circuit, version 4 (circuits/trace.r0c, tools/trace_circuit.py): a circuit whose DATA group IS the preflight trace of a
+ * segment.  R0H_TRACE_COLUMNS columns of 2^po2 rows (po2 >= 16: two 2^16-row lookup tables sit in the CODE group), column-major,
+ * Montgomery words: first the cycles (one row each), then the boundary rows (one per register / word touched; in a closing segment
+ * one per word the whole session touched and per image word), then blank rows.  Per cycle: pc, next pc, the instruction word as
+ * decoded fields with a one-hot opcode and funct3, five accesses -- the fetch, x[rs1], x[rs2], x[rd], the memory word, in this order of
+ * timestamps (5 c + 1..5) -- each with the timestamp of the access it follows, and the work words of the arithmetic units: two
+ * operands byte by byte with their AND (U, V), two words as 16-bit halves (Z, W), carries.  What the circuit constrains
+ * (tools/trace_circuit.py trace_constraints: 312 polynomials of degree <= 5 over 203 taps; csrc/trace.hpp fills the columns):
  *   - the cycles form one contiguous run from the public first pc to the public last pc in the public number of cycles;
  *   - WHAT EVERY INSTRUCTION DOES: the word decodes to exactly one RV32IM instruction (an illegal encoding has no satisfying row);
  *     the value written to rd, the word written to memory, the address of a load / store and the next pc are the ones the ISA
  *     prescribes for the operands read -- a 32-bit adder over 16-bit halves (ADD[I], AUIPC, addresses, JALR; backwards for SUB,
- *     SLT[I][U] and the branches), bit-sliced AND / OR / XOR, a byte-limb multiplier with a range-checked carry chain (MUL[H[S]U],
- *     the shifts as products with 2^s or 2^(32-s), DIV[U] / REM[U] as quotient x divisor + remainder = dividend with
- *     |remainder| < |divisor|), byte and half lanes of the narrow loads and stores; an ecall reads a7 and a0, and what it writes
+ *     SLT[I][U] and the branches), AND / OR / XOR through a byte-AND lookup table, a byte-limb multiplier with a range-checked carry
+ *     chain (MUL[H[S]U], the shifts as products with 2^s or 2^(32-s), DIV[U] / REM[U] as quotient x divisor + remainder = dividend
+ *     with |remainder| < |divisor|), byte and half lanes of the narrow loads and stores; an ecall reads a7 and a0, and what it writes
  *     (a1 counted down and one word of the buffer for the transfers, a0 for CYCLES, nothing for HALT / PAUSE) is where its
- *     function says.  Every word written to a register or to memory is range-checked or composed of range-checked parts;
- *   - MEMORY CONSISTENCY over registers and memory as one address space (offline memory checking): every access reads the tuple
- *     (address, value, timestamp) the previous access to that address wrote and writes a new one with a larger timestamp; the
- *     boundary rows write each address's first tuple (timestamp 0) and read its last; the multiset of tuples read equals the
- *     multiset written, checked as a grand product over r0h_prefix_products in the ACCUM group; boundary addresses (below
- *     2^28 + 32) strictly increase, so an address has ONE history.  Hence a register or word read returns what was last written
- *     to it, the instruction word at a pc is the word in memory, x0 reads as zero, rs1 / rs2 / rd are the registers the word names.
- * What it does NOT constrain: the WORDS an I/O ecall moves (input words are the host's to choose, as in risc0; the journal is bound
- * by the claim's output digest outside the circuit) and the value CYCLES returns; that the first values of the boundary rows
- * are the pre-state's memory and the last ones the post-state's (risc0 pages memory in and out through in-circuit Merkle proofs:
- * SHA-256 in the circuit).  It is this library's circuit for this library's executor, not risc0's rv32im circuit.  Public inputs
+ *     function says.  Every word written to a register or to memory is range-checked (16-bit lookups) or composed of such parts;
+ *   - MEMORY CONSISTENCY over registers (x0 included: a register nothing ever writes) and memory: every access consumes the tuple
+ *     (address, value, timestamp, space) the previous access to that address produced and produces one with a larger timestamp; the
+ *     boundary rows produce each address's first tuple (timestamp 0) and consume its last; consumed = produced as multisets, by a
+ *     log-derivative argument: every tuple is a fraction +-1 / (alpha - address - b1 lo - b2 hi - b3 t - b4 space) of ONE running
+ *     sum through the ACCUM group that wraps around the trace, together with the lookups' fractions and the tables' multiplicities
+ *     (csrc/logup.hip).  Boundary addresses (below 2^28 + 32) strictly increase, so an address has ONE history.  Hence a register
+ *     or word read returns what was last written to it, and the instruction word at a pc is the word in memory;
+ *   - THE SESSION (round 4): a boundary row consumes (address, value found, number of the segment that held the address before --
+ *     an EARLIER one) and produces (address, value left, own number); the rows of a closing segment produce the address's initial
+ *     tuple (address, initial value, 0) instead -- zero unless the row says "image word", then it also names (address, word) as an
+ *     image tuple; an active COMMIT row names (address, word read) as a journal tuple.  These are fractions under a challenge all
+ *     segments share (late public inputs R0H_TRACE_GAMMA..: derived from every segment's DATA root, r0h_session_challenge); their
+ *     sum over the segment is the public input at R0H_TRACE_SUM.  r0h_receipt_verify_elf adds the segments' sums and compares with
+ *     the sum over the ELF's image words and the journal's words: the tuples balance iff every first touch finds the image (or
+ *     zero), every later one what the previous holder left, and the journal is what the COMMIT rows read.
+ * What it does NOT constrain: the WORDS READ_WORDS moves (input words are the host's to choose, as in risc0) and the value CYCLES
+ * returns.  It is this library's circuit for this library's executor, not risc0's rv32im circuit.  Public inputs
  * (R0H_TRACE_GLOBALS): 8 words naming the segment's ReceiptClaim (r0h_claim_globals), first pc, pc after the last cycle, number of
  * cycles, how the segment ends (0: cut, 1: HALT, 2: PAUSE -- such an ecall is the last cycle of its segment), that being non-zero,
- * the two halves of the exit code (a0); r0h_receipt_verify holds them against the claim's pcs and ExitCode.  Trace sizes up to 2^21 rows (timestamps < 2^24). ---- */
+ * the two halves of the exit code (a0), the segment's number (index + 1), whether it closes the session, number x (1 - closing), the
+ * first and last boundary address; LATE (absorbed after the DATA commitment): the session challenge (16 words), the segment's sum
+ * (4).  r0h_receipt_verify[_elf] holds them against the claims and against one another.  Trace sizes 2^16..2^21 rows (timestamps < 2^24). ---- */
 #define R0H_TRACE_COLUMNS 138
 #define R0H_TRACE_GLOBALS 40
 #define R0H_TRACE_LATE_GLOBALS 20 /* the last 20 public inputs: the session's challenge (16 words) and the segment's sum under it (4) */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs into profiles/<round>/pmc_traffic.json.
-usage: summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<how it was collected>" [segments profiled] [setup launches JSON]
+usage: summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<how it was collected>" [segments profiled] [setup launches JSON] [circuit]
 The last argument, e.g. '{"hash_rows_kernel": 1}', names launches that belong to the one-off setup of the run (the CODE group committed once
 per (circuit, po2) before any segment is proved): that many of a kernel's FIRST dispatches are left out, so that launches / segments
 profiled is the per-segment count bench.py compares with its own."""
@@ -32,11 +32,12 @@ def load(path, counter, skip):
 
 def main():
     skip = json.loads(sys.argv[6]) if len(sys.argv) > 6 else {}
+    circuit = sys.argv[7] if len(sys.argv) > 7 else "bench"
     f, w = load(sys.argv[1], "FETCH_SIZE", skip), load(sys.argv[2], "WRITE_SIZE", skip)
     out = {"_about": sys.argv[4] + "  Counters are in KB.  fetch_corrected doubles FETCH_SIZE (gfx950 tallies the 128-B requests of coalesced "
                      "streaming reads at 64 B: MI355X_MICROARCH.md, HBM section).  Calibrated on this code's own access patterns: every in-place pass "
                      "(ntt_strided16 with its 128-byte tile rows, bit_reverse_tiled, the in-place ntt_local16) reads exactly what it writes and shows "
-                     "raw FETCH_SIZE = WRITE_SIZE / 2, so the factor applies to all kernels here.  All byte figures are per launch.", "device_code_sha256": bench.device_code_fingerprint(), "kernels": {}}
+                     "raw FETCH_SIZE = WRITE_SIZE / 2, so the factor applies to all kernels here.  All byte figures are per launch.", "device_code_sha256": bench.device_code_fingerprint(circuit), "circuit": circuit, "kernels": {}}
     for k, (n, fs) in f.items():
         wn, ws = w.get(k, [0, 0.0])
         if not n:
