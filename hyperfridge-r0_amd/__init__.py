@@ -75,6 +75,7 @@ _SIGNATURES = {
     "r0h_witgen": [_vp, _vp, _u32, _u64, _vp, _vp, _vp],
     "r0h_witgen_public": [_vp, _vp, _u32, _u64, _vp, _vp, _vp],
     "r0h_seal_digest": [_vp, _sz, _vp],
+    "r0h_sponge_trace": [_vp, _sz, _u32, _vp],
     "r0h_accum": [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
     "r0h_eval_check": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "r0h_prove_segment": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)],
@@ -440,6 +441,18 @@ def seal_digest(seal):
     a, pa = _u32arr(seal)
     out = np.zeros(8, dtype=np.uint32)
     _check(lib().r0h_seal_digest(pa, a.size, out.ctypes.data_as(_vp)))
+    return out
+
+
+SPONGE_DATA_COLUMNS = 65
+
+
+def sponge_trace(words, po2):
+    """The rows of the recursion circuit's in-circuit Poseidon2 sponge over `words` (r0h_sponge_trace): [65][2^po2] -- st[24], aux[24],
+    in[16], act.  What r0h_lift / r0h_join plant into a node's witness."""
+    a, pa = _u32arr(words)
+    out = np.zeros((SPONGE_DATA_COLUMNS, 1 << po2), dtype=np.uint32)
+    _check(lib().r0h_sponge_trace(pa, a.size, po2, out.ctypes.data_as(_vp)))
     return out
 
 

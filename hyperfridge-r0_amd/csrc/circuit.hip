@@ -12,6 +12,7 @@
 #include <hip/hiprtc.h>
 
 #include <map>
+#include <memory>
 #include <sstream>
 
 #include "../../include/r0hip_circuit.h"
@@ -80,6 +81,16 @@ const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
         R0H_REQUIRE(len == 1, "circuit blob: LATE must be 1 word");
         c->n_late = p[0];
         break;
+      case R0H_SEC_PERIODIC:
+        R0H_REQUIRE(len >= 2 && p[0] && (uint64_t)p[0] * p[1] + 2 == len, "circuit blob: PERIODIC length mismatch");
+        c->period = p[0];
+        c->periodic.assign(p + 2, p + len);
+        for (uint32_t v : c->periodic) R0H_REQUIRE(v < P, "circuit blob: PERIODIC value is not a canonical field word");
+        break;
+      case R0H_SEC_SPONGE:
+        R0H_REQUIRE(len == 3, "circuit blob: SPONGE must be 3 words");
+        c->has_sponge = true; c->sponge_code = p[0]; c->sponge_data = p[1]; c->sponge_global = p[2];
+        break;
       case R0H_SEC_LOGUP: {
         size_t at = 0;
         auto word = [&](uint32_t* out) -> bool { if (at >= len) return false; *out = p[at++]; return true; };
@@ -125,6 +136,12 @@ const char* parse_blob(r0h_circuit* c, const uint32_t* w, size_t n_words) {
   R0H_REQUIRE(seen[R0H_SEC_WITGEN] == any_accum && (int)seen[R0H_SEC_ACCUM] + (int)seen[R0H_SEC_ACCUM_FP] + (int)seen[R0H_SEC_LOGUP] <= 1,
               "circuit blob: WITGEN comes with exactly one of ACCUM / ACCUM_FP / LOGUP");
   R0H_REQUIRE(c->n_late <= c->n_global, "circuit blob: more late public inputs than public inputs");
+  for (const CodeCol& cc : c->code_cols)
+    if (cc.kind == 6) R0H_REQUIRE(c->period && (uint64_t)cc.param * c->period + c->period <= c->periodic.size(), "circuit blob: a periodic CODE column names no column of the PERIODIC section");
+  if (c->has_sponge)
+    R0H_REQUIRE(c->has_column_program && c->period == R0H_SPONGE_PERIOD && (uint64_t)c->sponge_code + R0H_SPONGE_CODE_COLUMNS <= c->group_size[R0H_GROUP_CODE] &&
+                    (uint64_t)c->sponge_data + R0H_SPONGE_DATA_COLUMNS <= c->group_size[R0H_GROUP_DATA] && (uint64_t)c->sponge_global + 8 <= c->n_global && c->global_cols.size() == c->n_global,
+                "circuit blob: SPONGE names columns or public inputs outside the circuit");
   if (c->has_column_program) {
     R0H_REQUIRE(c->code_cols.size() == c->group_size[R0H_GROUP_CODE] && c->data_cols.size() == c->group_size[R0H_GROUP_DATA],
                 "circuit blob: group sizes disagree with the column programs");
@@ -596,7 +613,7 @@ static uint64_t splitmix64_host(uint64_t x) {
 }
 
 __global__ void witgen_fixed_kernel(uint32_t* __restrict__ buf, const uint32_t* __restrict__ kinds /* (kind, stream) per col */,
-                                    uint32_t po2, uint64_t seed_mixed) {
+                                    uint32_t po2, uint64_t seed_mixed, const uint32_t* __restrict__ periodic /* Montgomery */, uint32_t period) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << po2, col = blockIdx.y;
   const uint32_t kind = kinds[2 * col], stream = kinds[2 * col + 1];
   uint32_t v;
@@ -606,6 +623,7 @@ __global__ void witgen_fixed_kernel(uint32_t* __restrict__ buf, const uint32_t* 
   else if (kind == 3) v = synth_word(seed_mixed, stream, r);
   else if (kind == 4) v = r < 65536u ? enc(r) : 0u;                                                     // the 16-bit range table
   else if (kind == 5) v = enc(R0H_TAG_AND + (r < 65536u ? r + 65536u * ((r & 255u) & (r >> 8)) : 0u));  // the byte-AND table
+  else if (kind == 6) v = r < (n / period) * period ? periodic[stream * period + r % period] : 0u;      // a periodic schedule (stream = its column)
   else return;  // derived column: filled later
   buf[((size_t)col << po2) + r] = v;
 }
@@ -723,6 +741,28 @@ uint32_t r0h_circuit_n_global(const r0h_circuit* c) { return c ? c->n_global : 0
 uint32_t r0h_circuit_n_mix(const r0h_circuit* c) { return c ? c->n_mix : 0; }
 uint32_t r0h_circuit_n_taps(const r0h_circuit* c) { return c ? (uint32_t)c->taps.size() : 0; }
 
+}  // extern "C"
+namespace r0h {
+const char* sponge_plant(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const uint32_t* words, size_t n_words, r0h_buf* data) {
+  R0H_REQUIRE(ctx && c && data && c->has_sponge && (words || !n_words), "sponge_plant: NULL argument, or a circuit without the sponge component");
+  const size_t n = (size_t)1 << po2, n_perm = n_words ? (n_words + P2_RATE - 1) / P2_RATE : 1, rows = n_perm * R0H_SPONGE_PERIOD;
+  R0H_REQUIRE(rows < n, "the in-circuit sponge over %zu words takes %zu rows: the recursion trace has 2^%u", n_words, rows, po2);
+  R0H_REQUIRE(((size_t)c->group_size[R0H_GROUP_DATA] << po2) * 4 <= data->bytes, "sponge_plant: DATA buffer too small for 2^%u rows", po2);
+  for (size_t i = 0; i < n_words; i++) R0H_REQUIRE(words[i] < P, "sponge_plant: word %zu is not a canonical field element", i);
+  std::unique_ptr<P2Consts> k(new P2Consts);
+  p2_default_host(*k);
+  std::vector<uint32_t> cols((size_t)R0H_SPONGE_DATA_COLUMNS * rows);
+  size_t used = 0;
+  p2_sponge_rows_host(*k, words, n_words, cols.data(), rows, &used);
+  uint32_t* first = u32(data) + ((size_t)c->sponge_data << po2);
+  R0H_TRY_HIP(hipMemsetAsync(first, 0, (size_t)R0H_SPONGE_DATA_COLUMNS * n * 4, ctx->stream));
+  R0H_TRY_HIP(hipMemcpy2DAsync(first, n * 4, cols.data(), rows * 4, rows * 4, R0H_SPONGE_DATA_COLUMNS, hipMemcpyHostToDevice, ctx->stream));
+  R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));  // `cols` is pageable and goes out of scope
+  return nullptr;
+}
+}  // namespace r0h
+extern "C" {
+
 static const char* witgen_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, uint64_t seed, const uint32_t* global_in, r0h_buf* code,
                                r0h_buf* data, uint32_t* global_out) {
   R0H_GUARD_BEGIN
@@ -732,13 +772,27 @@ static const char* witgen_impl(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2,
   const uint32_t n = 1u << po2, threads = n < 256 ? n : 256, nc = (uint32_t)c->code_cols.size(), nd = (uint32_t)c->data_cols.size();
   R0H_REQUIRE(((size_t)nc << po2) * 4 <= code->bytes && ((size_t)nd << po2) * 4 <= data->bytes, "r0h_witgen: buffers too small for 2^%u rows", po2);
   std::vector<uint32_t> kinds(2 * (size_t)(nc + nd));
-  for (uint32_t k = 0; k < nc; k++) { kinds[2 * k] = c->code_cols[k].kind; kinds[2 * k + 1] = (1u << 16) | k; }
+  for (uint32_t k = 0; k < nc; k++) { kinds[2 * k] = c->code_cols[k].kind; kinds[2 * k + 1] = c->code_cols[k].kind == 6 ? c->code_cols[k].param : (1u << 16) | k; }
   for (uint32_t k = 0; k < nd; k++) { kinds[2 * (nc + k)] = c->data_cols[k].kind == 0 ? 3u : 99u; kinds[2 * (nc + k) + 1] = (2u << 16) | k; }
+  const size_t table_at = kinds.size();
+  for (uint32_t v : c->periodic) kinds.push_back(enc(v));
   R0H_TRY(ensure_scratch(ctx, kinds.size() * 4));
   R0H_TRY(stage_h2d(ctx, ctx->scratch, kinds.data(), kinds.size() * 4));
   const uint32_t* dk = (const uint32_t*)ctx->scratch;
-  hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nc), dim3(threads), 0, ctx->stream, u32(code), dk, po2, splitmix64_host(0xC0DEull));
-  hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nd), dim3(threads), 0, ctx->stream, u32(data), dk + 2 * nc, po2, splitmix64_host(seed));
+  hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nc), dim3(threads), 0, ctx->stream, u32(code), dk, po2, splitmix64_host(0xC0DEull), dk + table_at, c->period);
+  hipLaunchKernelGGL(witgen_fixed_kernel, dim3(n / threads, nd), dim3(threads), 0, ctx->stream, u32(data), dk + 2 * nc, po2, splitmix64_host(seed), dk + table_at, c->period);
+  if (c->has_sponge) {
+    // the sponge's columns hold the sponge over no words at all, and -- unless the caller names the public inputs -- the inputs its
+    // digest is tied to are that digest (a caller who names them plants the rows of what it hashed instead: r0h_lift / r0h_join)
+    R0H_TRY(sponge_plant(ctx, c, po2, nullptr, 0, data));
+    if (!global_in) {
+      std::unique_ptr<P2Consts> k(new P2Consts);
+      p2_default_host(*k);
+      uint32_t digest[8];
+      p2_hash_elems_host(*k, nullptr, 0, digest);
+      for (uint32_t j = 0; j < 8; j++) R0H_TRY(stage_h2d(ctx, u32(data) + ((size_t)c->global_cols[c->sponge_global + j] << po2), digest + j, 4));
+    }
+  }
   if (global_in) {  // caller-chosen public inputs: row 0 of the (free) columns the globals are read from, before anything is derived from them
     for (uint32_t k = 0; k < c->n_global; k++) {
       R0H_REQUIRE(global_in[k] < P, "r0h_witgen_public: global %u is not a canonical field word", k);

@@ -50,6 +50,10 @@ struct r0h_circuit {
   std::vector<r0h::AccCol> acc_cols;
   std::vector<r0h::AccFp> acc_fp;
   r0h::Logup logup;
+  uint32_t period = 0;               // R0H_SEC_PERIODIC: what CODE columns of kind 6 repeat, [n_periodic][period] canonical values
+  std::vector<uint32_t> periodic;
+  bool has_sponge = false;           // R0H_SEC_SPONGE: the in-circuit Poseidon2 sponge, its first CODE / DATA column, the first public input of its digest
+  uint32_t sponge_code = 0, sponge_data = 0, sponge_global = 0;
   uint32_t n_late = 0;  // the last n_late public inputs enter the transcript after the DATA commitment (R0H_SEC_LATE)
   bool has_column_program = false;  // WITGEN + ACCUM present (synthetic circuits); imported circuits bring their own witness
   std::vector<uint32_t> blob;
@@ -63,5 +67,7 @@ namespace r0h {
 // fills the host tables of `c` from a blob (no device work); validates every index the sequencer and the verifier follow
 const char* parse_blob(r0h_circuit* c, const uint32_t* blob, size_t n_words);
 // the log-derivative accumulation on the device (logup.hip): multiplicities into DATA, the ACCUM group, totals of the public accumulators
+// the rows of the in-circuit sponge over `words` written into the circuit's sponge columns of `data` (recursion.cpp: sponge_plant)
+const char* sponge_plant(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const uint32_t* words, size_t n_words, r0h_buf* data);
 const char* logup_accum(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, const r0h_buf* code, const r0h_buf* data, const uint32_t* global, const uint32_t* mix, r0h_buf* accum);
 }  // namespace r0h

@@ -92,6 +92,51 @@ void p2_mix_host(const P2Consts& k, uint32_t* c) {
     m_ext_host(c);
   }
 }
+// The sponge below (p2_hash_elems_host) laid out row by row for the recursion circuit's in-circuit hash (include/r0hip_circuit.h SPONGE,
+// tools/sponge_component.py): 30 rows per permutation -- absorb + external layer, then one round per row -- in 65 columns of `stride`
+// words: st[24] the state after the row's step, aux[24] the cubes (x + rc)^3 of the lanes the round's S-box touches, in[16] the words
+// absorbed on a permutation's first row, act = 1.  Only rows [0, *rows_used) are written; the caller clears the rest.
+void p2_sponge_rows_host(const P2Consts& k, const uint32_t* words, size_t n_words, uint32_t* cols, size_t stride, size_t* rows_used) {
+  const size_t n_perm = n_words ? (n_words + P2_RATE - 1) / P2_RATE : 1;
+  uint32_t st[P2_CELLS] = {0};
+  size_t row = 0;
+  auto put_state = [&] {
+    for (int j = 0; j < P2_CELLS; j++) cols[(size_t)j * stride + row] = st[j];
+    cols[(size_t)64 * stride + row] = ONE;
+  };
+  for (size_t q = 0; q < n_perm; q++) {
+    for (int j = 0; j < P2_CELLS; j++) cols[(size_t)(24 + j) * stride + row] = 0;
+    for (size_t j = 0; j < P2_RATE; j++) {
+      st[j] = q * P2_RATE + j < n_words ? words[q * P2_RATE + j] : 0u;
+      cols[(48 + j) * stride + row] = st[j];
+    }
+    m_ext_host(st);
+    put_state();
+    row++;
+    for (int r = 0; r < 2 * P2_HALF_FULL + P2_PARTIAL; r++, row++) {
+      const bool full = r < P2_HALF_FULL || r >= P2_HALF_FULL + P2_PARTIAL;
+      const uint32_t* rc = full ? k.rc_full[r < P2_HALF_FULL ? r : r - P2_PARTIAL] : &k.rc_partial[r - P2_HALF_FULL];
+      for (int j = 0; j < P2_CELLS; j++) {
+        uint32_t cube = 0;
+        if (full || j == 0) {
+          const uint32_t t = add(st[j], rc[j]);
+          cube = mul(mul(t, t), t);
+          st[j] = mul(mul(cube, cube), t);
+        }
+        cols[(size_t)(24 + j) * stride + row] = cube;
+      }
+      if (full) m_ext_host(st);
+      else {
+        uint32_t sum = 0;
+        for (int i = 0; i < P2_CELLS; i++) sum = add(sum, st[i]);
+        for (int i = 0; i < P2_CELLS; i++) st[i] = add(sum, mul(k.diag[i], st[i]));
+      }
+      for (size_t j = 0; j < P2_RATE; j++) cols[(48 + j) * stride + row] = 0;
+      put_state();
+    }
+  }
+  *rows_used = row;
+}
 void p2_hash_elems_host(const P2Consts& k, const uint32_t* elems, size_t n, uint32_t digest[8]) {
   uint32_t st[P2_CELLS] = {0};
   size_t used = 0;

@@ -181,4 +181,5 @@ void p2_mix_host(const P2Consts& k, uint32_t* cells);
 void fill_p2(P2Consts& k, const uint32_t* rc, const uint32_t* diag_m1);
 void p2_default_host(P2Consts& k);
 void p2_hash_elems_host(const P2Consts& k, const uint32_t* elems, size_t n, uint32_t digest[8]);
+void p2_sponge_rows_host(const P2Consts& k, const uint32_t* words, size_t n_words, uint32_t* cols, size_t stride, size_t* rows_used);
 }  // namespace r0h

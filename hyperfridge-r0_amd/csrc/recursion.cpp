@@ -4,12 +4,15 @@
 // input: a.input, output: b.output}, refused unless a ends in SystemSplit exactly where b starts -- and the folds form the binary tree
 // whose levels are the one inter-GPU exchange of the whole path (hyperfridge-r0_amd/recursion.py moves the nodes; nothing else).
 //
-// What a node's proof is, stated plainly: one STARK over a recursion-SHAPED circuit (circuits/recursion.r0c) made with the same
-// kernels as a segment proof, whose 16 public inputs are (a) the 8 words naming the node's composed ReceiptClaim
-// (r0h_claim_globals) and (b) the Poseidon2 digest of what it consumed (the segment seal, or the two child seals' digests).  The
-// children are verified BESIDE the proof -- host threads run the verifier while the device proves -- not inside it: risc0's recursion
-// circuit (whose programs are downloaded at build time upstream) cannot be reproduced here, so a root node is a checkable tree of
-// seals with a composed claim, not a succinct receipt.  r0h_node_verify checks one node's seal, control root and naming words.
+// What a node's proof is, stated plainly: one STARK over the recursion circuit of this repository (circuits/recursion.r0c) made with the
+// same kernels as a segment proof, whose 16 public inputs are (a) the 8 words naming the node's composed ReceiptClaim
+// (r0h_claim_globals) and (b) the Poseidon2 digest of what it consumed (the segment seal, or the two child seals' digests).  (b) is
+// computed INSIDE the proof: the circuit's sponge component (tools/sponge_component.py, blob section SPONGE) hashes the consumed words,
+// held in witness cells, one Poseidon2 round per row, and ties the result to those public inputs -- a node whose witness holds other
+// words than its digest names has no satisfying trace.  That is the first in-circuit step and the only one: the children's SEALS are
+// still verified BESIDE the proof -- host threads run the verifier while the device proves -- because risc0's recursion circuit (whose
+// programs are downloaded at build time upstream) cannot be reproduced here; a root node is a checkable tree of seals with a composed
+// claim, not a succinct receipt.  r0h_node_verify checks one node's seal, control root and naming words.
 #include <string.h>
 
 #include <memory>
@@ -51,7 +54,7 @@ void naming_words(const r0h_receipt_claim& claim, uint32_t out[8]) {
 }
 
 // one recursion-circuit proof with the given 16 public inputs, on the recursor's context, while `checks` run on host threads
-const char* prove_node(r0h_recursor* rc, const uint32_t publics[16], std::vector<uint32_t>& seal) {
+const char* prove_node(r0h_recursor* rc, const uint32_t publics[16], const uint32_t* consumed, size_t n_consumed, std::vector<uint32_t>& seal) {
   r0h_ctx* ctx = rc->ctx;
   const size_t n = (size_t)1 << rc->po2;
   r0h_buf *code = nullptr, *data = nullptr;
@@ -60,6 +63,8 @@ const char* prove_node(r0h_recursor* rc, const uint32_t publics[16], std::vector
   // the rest of the witness is the circuit's synthetic column program: any deterministic seed
   const uint64_t seed = (uint64_t)publics[0] | (uint64_t)publics[8] << 32;
   if (!err) err = r0h_witgen_public(ctx, rc->circuit, rc->po2, seed, publics, code, data);
+  // the sponge rows over what this node consumes: the digest the circuit computes from them is publics[8..16)
+  if (!err) err = sponge_plant(ctx, rc->circuit, rc->po2, consumed, n_consumed, data);
   seal.resize((size_t)1 << 19);
   size_t words = 0;
   if (!err) err = r0h_prove_segment_committed(ctx, rc->circuit, rc->po2, rc->code, data, publics, seal.data(), seal.size(), &words);
@@ -77,10 +82,11 @@ struct Check {  // a seal this step consumes, verified on a host thread while th
   void run() { err = r0h_verify_seal_bound(blob, blob_words, nullptr, nullptr, seal, seal_words, root, &verdict, nullptr, nullptr); }
 };
 
-const char* prove_checked(r0h_recursor* rc, std::vector<Check>& checks, const uint32_t publics[16], std::vector<uint32_t>& seal) {
+const char* prove_checked(r0h_recursor* rc, std::vector<Check>& checks, const uint32_t publics[16], const uint32_t* consumed, size_t n_consumed,
+                          std::vector<uint32_t>& seal) {
   std::vector<std::thread> threads;
   for (Check& c : checks) threads.emplace_back([&c] { c.run(); });
-  const char* err = prove_node(rc, publics, seal);
+  const char* err = prove_node(rc, publics, consumed, n_consumed, seal);
   for (std::thread& t : threads) t.join();
   for (Check& c : checks) {
     if (c.err && !err) err = c.err;
@@ -113,6 +119,7 @@ const char* r0h_recursor_new(r0h_ctx* ctx, const uint32_t* recursion_blob, size_
   R0H_TRY(r0h_circuit_load(ctx, recursion_blob, recursion_words, code_object_path, &rc->circuit));
   R0H_REQUIRE(rc->circuit->n_global == 16 && rc->circuit->has_column_program, "r0h_recursor_new: a recursion circuit exposes 16 public inputs (claim words, digest of what it consumed) and carries a column program; this one has %u",
               rc->circuit->n_global);
+  R0H_REQUIRE(rc->circuit->has_sponge && rc->circuit->sponge_global == 8, "r0h_recursor_new: a recursion circuit computes the digest of what a node consumed in-circuit (blob section SPONGE, public inputs 8..15); this one does not");
   const size_t n = (size_t)1 << po2;
   r0h_buf *code = nullptr, *data = nullptr;
   R0H_TRY(buf_alloc_pooled(ctx, (size_t)rc->circuit->group_size[R0H_GROUP_CODE] * n * 4, &code));
@@ -168,7 +175,7 @@ const char* r0h_lift(r0h_recursor* rc, const uint32_t* seal, size_t seal_words, 
   checks[0] = Check{rc->segment_blob.data(), rc->segment_blob.size(), seal, seal_words, root, "lift"};
   std::unique_ptr<r0h_node> node(new r0h_node());
   node->claim = *claim;
-  R0H_TRY(prove_checked(rc, checks, publics, node->seal));
+  R0H_TRY(prove_checked(rc, checks, publics, seal, seal_words, node->seal));
   *out = node.release();
   return nullptr;
   R0H_GUARD_END
@@ -207,7 +214,7 @@ const char* r0h_join(r0h_recursor* rc, const r0h_node* a, const r0h_node* b, r0h
   std::vector<Check> checks(2);
   checks[0] = Check{rc->recursion_blob.data(), rc->recursion_blob.size(), a->seal.data(), a->seal.size(), rc->root, "join (left)"};
   checks[1] = Check{rc->recursion_blob.data(), rc->recursion_blob.size(), b->seal.data(), b->seal.size(), rc->root, "join (right)"};
-  R0H_TRY(prove_checked(rc, checks, publics, node->seal));
+  R0H_TRY(prove_checked(rc, checks, publics, children, 16, node->seal));
   *out = node.release();
   return nullptr;
   R0H_GUARD_END

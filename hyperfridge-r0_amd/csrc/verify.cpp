@@ -395,6 +395,24 @@ const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t di
   R0H_GUARD_END
 }
 
+// The rows of the recursion circuit's in-circuit sponge over `words` (include/r0hip_circuit.h SPONGE): R0H_SPONGE_DATA_COLUMNS columns
+// of 2^po2 rows, zero behind the last permutation.  Pure host code; what r0h_lift / r0h_join plant into a node's witness.
+const char* r0h_sponge_trace(const uint32_t* words, size_t n_words, uint32_t po2, uint32_t* cols_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE((words || n_words == 0) && cols_out, "r0h_sponge_trace: NULL argument");
+  R0H_REQUIRE(po2 >= 6 && po2 <= R0H_MAX_PO2, "r0h_sponge_trace: po2 %u outside [6, %u]", po2, R0H_MAX_PO2);
+  const size_t n = (size_t)1 << po2, n_perm = n_words ? (n_words + P2_RATE - 1) / P2_RATE : 1;
+  R0H_REQUIRE(n_perm * R0H_SPONGE_PERIOD < n, "r0h_sponge_trace: %zu words take %zu rows, the trace has 2^%u", n_words, n_perm * R0H_SPONGE_PERIOD, po2);
+  for (size_t i = 0; i < n_words; i++) R0H_REQUIRE(words[i] < P, "r0h_sponge_trace: word %zu is not a canonical field element", i);
+  std::unique_ptr<P2Consts> k(new P2Consts);
+  p2_default_host(*k);
+  memset(cols_out, 0, (size_t)R0H_SPONGE_DATA_COLUMNS * n * 4);
+  size_t used = 0;
+  p2_sponge_rows_host(*k, words, n_words, cols_out, n, &used);
+  return nullptr;
+  R0H_GUARD_END
+}
+
 static const char* verify_entry(const uint32_t* blob, size_t blob_words, const uint32_t* p2_round_constants, const uint32_t* p2_diag_m1,
                                 const uint32_t* seal, size_t seal_words, const uint32_t* expected_code_root, int* verdict_out, uint32_t* po2_out,
                                 uint32_t* code_root_out, uint32_t* data_root_out = nullptr) {
@@ -509,13 +527,15 @@ const char* r0h_control_root_host(const uint32_t* blob, size_t blob_words, const
   for (uint32_t col = 0; col < count; col++) {
     uint32_t* a = &evals[(size_t)col * m];
     const uint32_t kind = c.code_cols[col].kind, stream = (1u << 16) | col;  // the stream r0h_witgen draws CODE column `col` from
-    R0H_REQUIRE(kind <= 5, "r0h_control_root_host: CODE column %u has kind %u", col, kind);
+    R0H_REQUIRE(kind <= 6, "r0h_control_root_host: CODE column %u has kind %u", col, kind);
+    const size_t whole = c.period ? (n / c.period) * c.period : 0;  // kind 6: rows below the last whole period
     for (size_t r = 0; r < n; r++) {
       if (kind == 0) a[r] = r == 0 ? ONE : 0u;
       else if (kind == 1) a[r] = r == n - 1 ? ONE : 0u;
       else if (kind == 2) a[r] = enc((uint32_t)r);
       else if (kind == 4) a[r] = r < 65536 ? enc((uint32_t)r) : 0u;
       else if (kind == 5) a[r] = enc(R0H_TAG_AND + (r < 65536 ? (uint32_t)r + 65536u * (((uint32_t)r & 255u) & ((uint32_t)r >> 8)) : 0u));
+      else if (kind == 6) a[r] = r < whole ? enc(c.periodic[(size_t)c.code_cols[col].param * c.period + r % c.period]) : 0u;
       else {
         const uint64_t h = splitmix64_h(seed ^ (((uint64_t)stream << 32) | (uint32_t)r));
         a[r] = (uint32_t)(((h >> 32) * (uint64_t)P) >> 32);

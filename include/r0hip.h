@@ -233,6 +233,11 @@ const char* r0h_verify_reason(int verdict); /* static string, do not free */
 /* Poseidon2 sponge (compiled-in table) over a seal's words (all canonical field elements, else an error): the 8-word name a
  * recursion step commits to */
 const char* r0h_seal_digest(const uint32_t* seal, size_t seal_words, uint32_t digest_out[8]);
+/* The same sponge laid out as the rows of the recursion circuit's in-circuit hash (r0hip_circuit.h SPONGE; tools/sponge_component.py):
+ * 65 columns (st[24], aux[24], in[16], act) of 2^po2 rows, 30 rows per permutation, zero behind the last one.  Host code; r0h_lift /
+ * r0h_join plant exactly this into a node's witness, so that the digest among the node's public inputs is computed inside its proof.
+ * Refused: words that are not canonical field elements, more words than the trace has rows for (30 rows per 16 words). */
+const char* r0h_sponge_trace(const uint32_t* words, size_t n_words, uint32_t po2, uint32_t* cols_out /* [65][2^po2] */);
 
 /* ---- data formats either side of the path (SURVEY.md 8(a) a0', a0'', a18): pure host code ----
  * serde word stream of a String: [u32 LE length][utf8][zero padding to 4] -- what `ExecutorEnv::builder().write(&s)` feeds the
@@ -606,10 +611,15 @@ const char* r0h_last_session_stats(r0h_ctx* ctx, r0h_session_stats* out);
  * configs[4]).  `lift` stands one recursion-circuit proof for one segment seal and its claim; `join` folds two nodes into one whose
  * claim is the composition {pre: a.pre, post: b.post, exit_code: b.exit_code, input: a.input, output: b.output}, and refuses two
  * nodes that do not follow one another (a must end in SystemSplit with a.post == b.pre).  A node's 16 public inputs are the 8 words
- * naming its composed claim (r0h_claim_globals) and the Poseidon2 digest of what it consumed.
- * NOT risc0's recursion circuit: every node is a proof over a recursion-SHAPED circuit (circuits/recursion.r0c) made with the
- * same kernels, and the seals it consumes are verified BESIDE that proof (host threads, while the device proves), not inside it --
- * a root is a checkable tree of seals carrying the end-to-end claim, not a succinct receipt.  Moving nodes between ranks
+ * naming its composed claim (r0h_claim_globals) and the Poseidon2 digest of what it consumed -- the segment seal's words for a lift,
+ * the two child seals' digests for a join.  That digest is computed INSIDE the node's proof: the circuit's sponge component runs the
+ * permutation one round per row over witness cells holding the consumed words and ties the result to public inputs 8..15, so a
+ * witness holding other words than the digest names satisfies no trace.  A lift of a 2^20-row trace-circuit seal (61k words: 3.8k
+ * permutations of 30 rows) needs a recursion trace of 2^17 rows or more.
+ * NOT risc0's recursion circuit: that in-circuit hash is the first and only in-circuit step.  Every node is a proof over this
+ * repository's recursion circuit (circuits/recursion.r0c) made with the same kernels, and the SEALS it consumes are verified BESIDE
+ * that proof (host threads, while the device proves), not inside it -- a root is a checkable tree of seals carrying the end-to-end
+ * claim, not a succinct receipt.  Moving nodes between ranks
  * (the tree's levels) is the caller's: hyperfridge-r0_amd/recursion.py does it over torch.distributed point-to-point. ---- */
 typedef struct r0h_recursor r0h_recursor;
 typedef struct r0h_node r0h_node;

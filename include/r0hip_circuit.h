@@ -17,7 +17,9 @@
  *                  8 AND_EQZ a=mix var, b=fp var                          9 AND_COND a=mix var, b=fp var, c=inner mix var
  *                fp vars and mix vars are numbered separately in creation order (risc0-zkp adapter.rs PolyExtStep)
  *   WITGEN  (5): [optional, with ACCUM: the synthetic column program; circuits imported from risc0 omit both] n_code, (kind, param) per CODE column: 0 first-row flag, 1 last-row flag, 2 row counter, 3 fixed random,
- *                4 the 16-bit range table (row r < 2^16: r, else 0), 5 the byte-AND table (row r = a + 256 b < 2^16: 2^24 + r + 65536 (a & b), else 2^24);
+ *                4 the 16-bit range table (row r < 2^16: r, else 0), 5 the byte-AND table (row r = a + 256 b < 2^16: 2^24 + r + 65536 (a & b), else 2^24),
+ *                6 a periodic schedule (param = a column of the PERIODIC section: row r holds values[param][r mod period] while a whole period
+ *                still fits below the trace's end, else 0);
  *                n_data, (kind, a, b, c, e) per DATA column: 0 seeded random, 1 a*b+e, 2 a*b*c+e with refs
  *                ref = group<<28 | back<<20 | column (group 1 or 2; DATA refs point at lower-numbered columns)
  *   INFO    (7): optional, 4 words = the circuit's 16-byte ProtocolInfo tag committed into the transcript (risc0 `CIRCUIT_INFO`)
@@ -40,6 +42,10 @@
  *                0, column ref + 1 or 0 for the constant one), ref = group << 28 | column.  Extension column j (ACCUM columns
  *                4j..4j+3): chain links run ONE sum through the row's accumulators and on through the rows, wrapping around the
  *                end of the trace (so its total is zero); an accumulator with a public total runs alone and wraps with it
+ *   PERIODIC (11): period, n_cols, then n_cols x period canonical values: what CODE columns of kind 6 repeat
+ *   SPONGE (12): [the in-circuit Poseidon2 sponge of the recursion circuit: tools/sponge_component.py] first CODE column (28 columns: rc[24],
+ *                sel_mix, sel_full, sel_part, sel_last), first DATA column (65 columns: st[24], aux[24], in[16], act), first of the 8 public
+ *                inputs the sponge's digest is tied to.  The prover fills the DATA columns from the words it hashes (r0h_sponge_trace)
  */
 #ifndef R0HIP_CIRCUIT_H
 #define R0HIP_CIRCUIT_H
@@ -54,6 +60,11 @@
 #define R0H_SEC_ACCUM_FP 8
 #define R0H_SEC_LATE 9
 #define R0H_SEC_LOGUP 10
+#define R0H_SEC_PERIODIC 11
+#define R0H_SEC_SPONGE 12
+#define R0H_SPONGE_DATA_COLUMNS 65
+#define R0H_SPONGE_CODE_COLUMNS 28
+#define R0H_SPONGE_PERIOD 30
 #define R0H_TABLE_R16 1
 #define R0H_TABLE_AND 2
 #define R0H_TAG_AND (1u << 24)

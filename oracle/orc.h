@@ -56,6 +56,7 @@ void orc_zk_shift(uint32_t* io, uint32_t count, uint32_t po2);
 void orc_poseidon2_consts(uint32_t* rc_canonical /*24*29*/, uint32_t* diag_m1_canonical /*24*/);
 void orc_poseidon2_mix(uint32_t cells[ORC_CELLS]);
 void orc_hash_elem_slice(const uint32_t* elems, size_t n, uint32_t digest[8]);
+int orc_sponge_trace(const uint32_t* words, size_t n_words, uint32_t po2, uint32_t* cols /* [65][2^po2] */);
 void orc_hash_pair(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]);
 void orc_hash_rows(uint32_t* digests, const uint32_t* matrix, size_t rows, size_t cols);
 void orc_hash_fold(uint32_t* nodes, size_t output_size); /* nodes[o..2o) = H(nodes[2i],nodes[2i+1]) */

@@ -18,7 +18,7 @@
 #include <string.h>
 
 #define BLOB_MAGIC 0x31433052u
-enum { SEC_GROUPS = 1, SEC_TAPS = 2, SEC_GLOBALS = 3, SEC_POLY = 4, SEC_WITGEN = 5, SEC_ACCUM = 6, SEC_INFO = 7, SEC_ACCUM_FP = 8, SEC_LATE = 9, SEC_LOGUP = 10 };
+enum { SEC_GROUPS = 1, SEC_TAPS = 2, SEC_GLOBALS = 3, SEC_POLY = 4, SEC_WITGEN = 5, SEC_ACCUM = 6, SEC_INFO = 7, SEC_ACCUM_FP = 8, SEC_LATE = 9, SEC_LOGUP = 10, SEC_PERIODIC = 11, SEC_SPONGE = 12 };
 #define TAG_AND (1u << 24)
 
 uint32_t orc_circuit_group_size(const orc_circuit_t* c, uint32_t g) { return c->group_size[g]; }
@@ -31,7 +31,7 @@ uint32_t orc_circuit_n_combos(const orc_circuit_t* c) { return c->n_combos; }
 void orc_circuit_free(orc_circuit_t* c) {
   if (!c) return;
   free(c->taps); free(c->regs); free(c->combo_begin); free(c->combo_backs); free(c->steps);
-  free(c->code_cols); free(c->data_cols); free(c->acc_cols); free(c->acc_fp); free(c->global_cols); free(c->logup); free(c->logup_words); free(c);
+  free(c->code_cols); free(c->data_cols); free(c->acc_cols); free(c->acc_fp); free(c->global_cols); free(c->logup); free(c->logup_words); free(c->periodic); free(c);
 }
 
 static void derive_regs_and_combos(orc_circuit_t* c) {
@@ -121,6 +121,17 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
         if (len != 1) goto bad;
         c->n_late = p[0];
         break;
+      case SEC_PERIODIC:
+        if (len < 2 || !p[0] || (uint64_t)p[0] * p[1] + 2 != len || c->periodic) goto bad;
+        c->period = p[0]; c->n_periodic = p[1];
+        c->periodic = (uint32_t*)malloc(sizeof(uint32_t) * (len - 1));
+        memcpy(c->periodic, p + 2, sizeof(uint32_t) * (len - 2));
+        for (uint32_t k = 0; k + 2 < len; k++) if (c->periodic[k] >= ORC_P) goto bad;
+        break;
+      case SEC_SPONGE:
+        if (len != 3) goto bad;
+        c->has_sponge = 1; c->sponge_code = p[0]; c->sponge_data = p[1]; c->sponge_global = p[2];
+        break;
       case SEC_LOGUP: {
         if (len < 2 || c->logup_words) goto bad;
         c->logup_words = (uint32_t*)malloc(4 * (size_t)len);
@@ -167,6 +178,9 @@ orc_circuit_t* orc_circuit_parse(const uint32_t* w, size_t n_words) {
   /* WITGEN/ACCUM (the synthetic column program) are optional: circuits imported from risc0 tables omit both */
   if ((c->code_cols || c->acc_cols || c->acc_fp || c->logup) && (c->n_code != c->group_size[ORC_GROUP_CODE] || c->n_data != c->group_size[ORC_GROUP_DATA])) goto bad;
   if (c->n_late > c->n_global) goto bad;
+  for (uint32_t k = 0; c->code_cols && k < c->n_code; k++)
+    if (c->code_cols[k].kind == 6 && (!c->periodic || c->code_cols[k].param >= c->n_periodic)) goto bad;
+  if (c->has_sponge && ((uint64_t)c->sponge_code + 28 > c->n_code || (uint64_t)c->sponge_data + 65 > c->n_data || (uint64_t)c->sponge_global + 8 > c->n_global || c->period != 30)) goto bad;
   if (c->logup) {  /* every reference of the log-derivative argument stays inside the circuit */
     if (c->acc_cols || c->acc_fp || 4 * c->n_logup != c->group_size[ORC_GROUP_ACCUM] || !c->n_chain) goto bad;
     for (uint32_t k = 0; k < c->n_tables; k++)
@@ -252,19 +266,30 @@ void orc_witgen_foreign_code(const orc_circuit_t* c, uint32_t po2, uint64_t seed
       else if (kind == 2) v = fp_enc((uint32_t)r);
       else if (kind == 4) v = r < 65536 ? fp_enc((uint32_t)r) : 0;                                                        /* the 16-bit range table */
       else if (kind == 5) v = fp_enc(TAG_AND + (r < 65536 ? (uint32_t)r + 65536u * (((uint32_t)r & 255u) & ((uint32_t)r >> 8)) : 0u));  /* the byte-AND table */
+      else if (kind == 6) v = r < (n / c->period) * c->period ? fp_enc(c->periodic[(size_t)c->code_cols[k].param * c->period + r % c->period]) : 0;  /* a periodic schedule */
       else v = synth_word(code_seed, (1u << 16) | k, (uint32_t)r);
       col[r] = v;
     }
+  }
+  /* a circuit with the in-circuit sponge: its columns hold the sponge over no words at all, and -- unless the caller names the public
+   * inputs -- the inputs its digest is tied to are that digest (a caller who names them plants the rows of what it hashed instead) */
+  uint32_t* sponge = NULL;
+  if (c->has_sponge) {
+    sponge = (uint32_t*)malloc(65 * n * sizeof(uint32_t));
+    if (orc_sponge_trace(NULL, 0, po2, sponge) != 0) { free(sponge); sponge = NULL; }
   }
   for (uint32_t k = 0; k < c->n_data; k++) {
     fp_t* col = data + (size_t)k * n;
     const orc_data_col_t* d = &c->data_cols[k];
     if (d->kind == 0) {
+      if (sponge && k >= c->sponge_data && k < c->sponge_data + 65) { memcpy(col, sponge + (size_t)(k - c->sponge_data) * n, n * sizeof(uint32_t)); continue; }
 #pragma omp parallel for
       for (size_t r = 0; r < n; r++) col[r] = synth_word(seed, (2u << 16) | k, (uint32_t)r);
-      if (global_in)
-        for (uint32_t g = 0; g < c->n_global; g++)
-          if (c->global_cols[g] == k) col[0] = global_in[g];
+      for (uint32_t g = 0; g < c->n_global; g++)
+        if (c->global_cols[g] == k) {
+          if (global_in) col[0] = global_in[g];
+          else if (sponge && g >= c->sponge_global && g < c->sponge_global + 8) col[0] = sponge[(size_t)(g - c->sponge_global) * n + 29];
+        }
       continue;
     }
     const uint32_t refs[4] = {d->a, d->b, d->c, d->e};
@@ -282,6 +307,7 @@ void orc_witgen_foreign_code(const orc_circuit_t* c, uint32_t po2, uint64_t seed
 #undef AT
     }
   }
+  free(sponge);
   const uint32_t* gcols = c->global_cols;
   for (uint32_t k = 0; k < c->n_global; k++) global[k] = data[(size_t)gcols[k] * n];
 }

@@ -36,6 +36,8 @@ struct orc_circuit {
   orc_logup_acc_t* logup;
   uint32_t table_col[8], table_kind[8];  /* DATA column that holds a table's multiplicities; 1 = range-16, 2 = byte-AND */
   uint32_t* logup_words;                 /* the section itself (the linear forms point into it) */
+  uint32_t period, n_periodic; uint32_t* periodic;  /* CODE columns of kind 6: n_periodic x period canonical values */
+  uint32_t has_sponge, sponge_code, sponge_data, sponge_global;  /* the in-circuit Poseidon2 sponge: its first columns, its digest's inputs */
   uint8_t info[16]; /* circuit ProtocolInfo tag (risc0 `CIRCUIT_INFO`), 16 bytes */
 };
 

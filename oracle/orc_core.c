@@ -252,6 +252,42 @@ void orc_hash_elem_slice(const uint32_t* elems, size_t n, uint32_t digest[8]) {
   poseidon2_setup();
   sponge_strided(elems, n, 1, digest);
 }
+/* The sponge above laid out as the rows of the recursion circuit's in-circuit hash (tools/sponge_component.py; the constraints are in
+ * the circuit blob): 30 rows per permutation -- absorb + external layer, then one round per row -- and 65 columns of n = 2^po2 rows:
+ * st[24] the state after the row's step, aux[24] the cubes (x + rc)^3 of the lanes the round's S-box touches, in[16] the absorbed
+ * words on a permutation's first row, act = 1 on the sponge's rows.  Returns 0, or -1 when the words do not fit the trace. */
+int orc_sponge_trace(const uint32_t* words, size_t n_words, uint32_t po2, uint32_t* cols) {
+  poseidon2_setup();
+  const size_t n = (size_t)1 << po2, n_perm = n_words ? (n_words + ORC_RATE - 1) / ORC_RATE : 1;
+  if (n_perm * 30 >= n) return -1;
+  memset(cols, 0, 65 * n * sizeof(uint32_t));
+  fp_t st[ORC_CELLS];
+  memset(st, 0, sizeof st);
+  size_t row = 0;
+#define COL(k) (cols + (size_t)(k) * n)
+  for (size_t q = 0; q < n_perm; q++) {
+    for (size_t j = 0; j < ORC_RATE; j++) {
+      st[j] = q * ORC_RATE + j < n_words ? words[q * ORC_RATE + j] : 0;
+      COL(48 + j)[row] = st[j];
+    }
+    m_ext(st);
+    for (int j = 0; j < ORC_CELLS; j++) COL(j)[row] = st[j];
+    COL(64)[row++] = ORC_ONE;
+    for (int r = 0; r < 2 * ROUNDS_HALF_FULL + ROUNDS_PARTIAL; r++, row++) {
+      const int full = r < ROUNDS_HALF_FULL || r >= ROUNDS_HALF_FULL + ROUNDS_PARTIAL;
+      for (int j = 0; j < (full ? ORC_CELLS : 1); j++) {
+        fp_t t = fp_add(st[j], g_rc[r * ORC_CELLS + j]), cube = fp_mul(fp_mul(t, t), t);
+        COL(24 + j)[row] = cube;
+        st[j] = fp_mul(fp_mul(cube, cube), t);
+      }
+      if (full) m_ext(st); else m_int(st);
+      for (int j = 0; j < ORC_CELLS; j++) COL(j)[row] = st[j];
+      COL(64)[row] = ORC_ONE;
+    }
+  }
+#undef COL
+  return 0;
+}
 void orc_hash_pair(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
   poseidon2_setup();
   fp_t st[ORC_CELLS];

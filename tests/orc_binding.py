@@ -65,6 +65,8 @@ class Oracle:
         L.orc_hash_fold.argtypes = [_vp, _sz]
         L.orc_merkle_build.argtypes = [_vp, _vp, _sz, _sz]
         L.orc_hash_elem_slice.argtypes = [_vp, _sz, _vp]
+        L.orc_sponge_trace.argtypes = [_vp, _sz, ctypes.c_uint32, _vp]
+        L.orc_sponge_trace.restype = ctypes.c_int
         L.orc_hash_pair.argtypes = [_vp, _vp, _vp]
         L.orc_poseidon2_mix.argtypes = [_vp]
         L.orc_poseidon2_consts.argtypes = [_vp, _vp]
@@ -154,6 +156,14 @@ class Oracle:
         out = np.zeros(8, np.uint32)
         self.L.orc_hash_elem_slice(_ptr(elems), elems.size, _ptr(out))
         return out
+
+    def sponge_trace(self, words, po2):
+        """the rows of the in-circuit sponge over `words` (Montgomery words): [65][2^po2]"""
+        words = u32(words)
+        out = np.zeros(65 << po2, np.uint32)
+        rc = self.L.orc_sponge_trace(_ptr(words), words.size, po2, _ptr(out))
+        assert rc == 0, "the words do not fit a trace of 2^%d rows" % po2
+        return out.reshape(65, -1)
 
     def hash_pair(self, a, b):
         a, b, out = u32(a), u32(b), np.zeros(8, np.uint32)

@@ -110,20 +110,109 @@ def test_two_gloo_ranks_exchange_seals_point_to_point():
     assert got == _expected_root(2).tolist()
 
 
+def _sponge_columns(blob):
+    """(first CODE column, first DATA column, first public input) of the in-circuit sponge: blob section SPONGE (12)"""
+    at = 3
+    for _ in range(int(blob[2])):
+        tag, size = int(blob[at]), int(blob[at + 1])
+        if tag == 12:
+            return tuple(int(x) for x in blob[at + 2:at + 5])
+        at += 2 + size
+    raise AssertionError("no SPONGE section")
+
+
+def _node_witness(c, orc, blob, po2, seed, claim_words, consumed, digest=None):
+    """the oracle's witness of a recursion node that consumed `consumed`: public inputs planted, the sponge's rows over the words"""
+    public = np.concatenate([claim_words, orc.hash_elem_slice(consumed) if digest is None else digest]).astype(np.uint32)
+    code, data, glob = c.witgen(po2, seed, globals_in=public)
+    _, first, _ = _sponge_columns(blob)
+    n = 1 << po2
+    data = data.reshape(-1, n).copy()
+    data[first:first + r0.SPONGE_DATA_COLUMNS] = orc.sponge_trace(consumed, po2)
+    return code, data.reshape(-1), glob
+
+
 def test_oracle_public_inputs_are_planted_and_committed(orc):
-    """orc_witgen_public: the witness still satisfies the circuit, and the seal opens with exactly those 16 words."""
+    """orc_witgen_public + the sponge's rows: the witness satisfies the circuit, and the seal opens with exactly those 16 words."""
     blob = _blob("recursion")
     c = orc.circuit(blob)
-    public = (np.arange(16, dtype=np.uint64) * 123456789 % P).astype(np.uint32)
-    code, data, glob = c.witgen(10, 5, globals_in=public)
-    assert np.array_equal(glob, public)
+    claim = (np.arange(8, dtype=np.uint64) * 123456789 % P).astype(np.uint32)
+    consumed = (np.arange(100, dtype=np.uint64) * 987654321 % P).astype(np.uint32)
+    code, data, glob = _node_witness(c, orc, blob, 10, 5, claim, consumed)
+    assert np.array_equal(glob[:8], claim) and np.array_equal(glob[8:], orc.hash_elem_slice(consumed))
     seal = c.prove(10, code, data, glob)
     assert c.verify(seal) == (0, "ok") and r0.verify_seal(blob, seal) == (0, "ok", 10)
-    assert np.array_equal(seal[:16], public)
+    assert np.array_equal(seal[:16], glob)
     forged = seal.copy()
     forged[3] = (int(forged[3]) + 1) % P  # claim another digest: the transcript no longer matches
     assert c.verify(forged)[0] != 0 and r0.verify_seal(blob, forged)[0] != 0
     assert r0.seal_digest(seal).tolist() == orc.hash_elem_slice(seal % P).tolist()
+
+
+def test_the_consumed_digest_is_computed_inside_the_proof(orc):
+    """public inputs 8..15 of a recursion node are the output of in-circuit Poseidon2 rows over witness cells holding
+    the consumed words.  The rows the library plants are the oracle's and the generator's own restatement's; a witness whose cells hold
+    other words than the digest names -- or the right words hashed wrongly, or a sponge cut short -- has no satisfying trace: whatever
+    the prover emits for it, both verifiers refuse."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sponge_component as sc
+    blob = _blob("recursion")
+    c = orc.circuit(blob)
+    rng = np.random.default_rng(11)
+    po2, n = 10, 1 << 10
+    for count in (0, 1, 15, 16, 17, 100, 16 * 33):
+        words = rng.integers(0, P, count).astype(np.uint32)
+        rows = r0.sponge_trace(words, po2)
+        assert np.array_equal(rows, orc.sponge_trace(words, po2)), count
+        assert np.array_equal(rows[:8, 30 * max(1, -(-count // 16)) - 1], r0.seal_digest(words)), count  # the state after the last round
+    # the generator's restatement (canonical integers) gives the same rows
+    words = rng.integers(0, P, 40).astype(np.uint32)
+    cols, digest = sc.witness([orc.dec(int(w)) for w in words], n)
+    assert np.array_equal(np.array([[orc.enc(v) for v in col] for col in cols], dtype=np.uint32), r0.sponge_trace(words, po2))
+    assert [orc.enc(v) for v in digest] == r0.seal_digest(words).tolist()
+    with pytest.raises(r0.R0HipError, match="rows"):
+        r0.sponge_trace(np.zeros(16 * 35, dtype=np.uint32), po2)  # 35 permutations of 30 rows do not fit 2^10
+    with pytest.raises(r0.R0HipError, match="canonical"):
+        r0.sponge_trace(np.array([P], dtype=np.uint32), po2)
+
+    claim = rng.integers(0, P, 8).astype(np.uint32)
+    consumed = rng.integers(0, P, 16 * 6 + 3).astype(np.uint32)
+    _, first, _ = _sponge_columns(blob)
+    code, data, glob = _node_witness(c, orc, blob, po2, 9, claim, consumed)
+    assert c.verify(c.prove(po2, code, data, glob)) == (0, "ok")
+
+    def refused(data, glob=glob):
+        try:
+            seal = c.prove(po2, code, np.ascontiguousarray(data).reshape(-1), glob)
+        except AssertionError:  # the oracle prover found the quotient is no polynomial
+            return True
+        return c.verify(seal)[0] != 0 and r0.verify_seal(blob, seal)[0] != 0
+
+    # other words in the cells than the public digest names
+    other = consumed.copy()
+    other[40] = (int(other[40]) + 1) % P
+    assert refused(_node_witness(c, orc, blob, po2, 9, claim, other, digest=glob[8:])[1])
+    table = data.reshape(-1, n)
+    # the right words, one state cell of one round off
+    wrong = table.copy()
+    wrong[first + 3, 47] = (int(wrong[first + 3, 47]) + 1) % P
+    assert refused(wrong)
+    # a cube cell that is not the cube
+    wrong = table.copy()
+    wrong[first + 24, 8] = (int(wrong[first + 24, 8]) + 1) % P
+    assert refused(wrong)
+    # the sponge stopped one permutation early, its digest claimed: the cells then hold a prefix of the words
+    early = r0.seal_digest(consumed[:16 * 6])
+    assert not refused(_node_witness(c, orc, blob, po2, 9, claim, consumed[:16 * 6])[1], np.concatenate([claim, early]))  # (honest: that digest, those words)
+    assert refused(_node_witness(c, orc, blob, po2, 9, claim, consumed[:16 * 6], digest=glob[8:])[1])
+    # `act` falling in the middle of a permutation, or never raised
+    wrong = table.copy()
+    wrong[first + 64, 100:] = 0
+    assert refused(wrong)
+    wrong = table.copy()
+    wrong[first:first + 65] = 0
+    assert refused(wrong)
 
 
 def test_contiguous_sharding_keeps_rank_order_equal_to_segment_order():
@@ -149,18 +238,33 @@ def test_lift_and_join_on_the_device(hal, orc):
         code, data, glob = hal.witgen(seg, 10, 1 + k, globals_in=cl.globals())
         seals.append(hal.prove_segment(seg, 10, seg_cc, data, glob))
         code.free(); data.free()
-    rec = recursion.Recursor(hal, rec_blob, seg_blob, po2=12, segment_roots={10: seg_cc.root()})
+    size = 16  # a 2^10-row `small` seal is ~21k words: 1.3k permutations of 30 rows
+    import __graft_entry__ as entry
+    rec = recursion.Recursor(hal, rec_blob, seg_blob, entry.code_object_path("recursion"), po2=size, segment_roots={10: seg_cc.root()})
     lifted = [rec.lift(s, cl) for s, cl in zip(seals, claims)]
     oc = orc.circuit(rec_blob)
     for node, s, cl in zip(lifted, seals, claims):
         assert np.array_equal(node.claim_words, cl.globals()) and np.array_equal(node.consumed_digest, r0.seal_digest(s))
         assert node.claim.digest() == cl.digest() and rec.verify(node)
-        assert r0.verify_seal(rec_blob, node.seal, code_root=rec.control_root) == (0, "ok", 12) and oc.verify(node.seal, code_root=rec.control_root) == (0, "ok")
-    # bit-exact against the oracle proving the same step
+        assert r0.verify_seal(rec_blob, node.seal, code_root=rec.control_root) == (0, "ok", size) and oc.verify(node.seal, code_root=rec.control_root) == (0, "ok")
+    # bit-exact against the oracle proving the same step: the public inputs planted, the sponge's rows over the segment seal's words
     public = np.concatenate([lifted[0].claim_words, lifted[0].consumed_digest])
     seed = int(public[0]) | (int(public[8]) << 32)
-    ocode, odata, oglob = oc.witgen(12, seed, globals_in=public)
-    assert np.array_equal(oc.prove(12, ocode, odata, oglob), lifted[0].seal)
+    ocode, odata, oglob = _node_witness(oc, orc, rec_blob, size, seed, lifted[0].claim_words, seals[0])
+    assert np.array_equal(oglob, public) and np.array_equal(oc.prove(size, ocode, odata, oglob), lifted[0].seal)
+    # a node whose cells hold another seal than its public digest names: the device proves what it is given, and nobody accepts the result
+    rc_circuit = hal.load_circuit(rec_blob, entry.code_object_path("recursion"))
+    dcode, ddata, dglob = hal.witgen(rc_circuit, size, seed, globals_in=public)
+    _, first, _ = _sponge_columns(rec_blob)
+    ddata.upload(r0.sponge_trace(seals[1], size).reshape(-1), offset_words=first << size)
+    try:
+        stray = hal.prove_segment(rc_circuit, size, dcode, ddata, dglob)
+        assert r0.verify_seal(rec_blob, stray)[0] != 0 and oc.verify(stray)[0] != 0
+    except r0.R0HipError:
+        pass
+    ddata.upload(r0.sponge_trace(seals[0], size).reshape(-1), offset_words=first << size)  # (the right rows: the same call succeeds)
+    assert np.array_equal(hal.prove_segment(rc_circuit, size, dcode, ddata, dglob), lifted[0].seal)
+    dcode.free(); ddata.free(); rc_circuit.free()
     root = rec.fold(lifted)  # join(join(l0, l1), join(l2, l3))
     assert rec.verify(root) and oc.verify(root.seal, code_root=rec.control_root) == (0, "ok")
     end_to_end = r0.ReceiptClaim.make(claims[0].pre, claims[-1].post, claims[-1].exit_system, claims[-1].exit_user, bytes(claims[-1].output_digest))
@@ -220,7 +324,7 @@ def test_the_segments_of_a_proved_run_join_into_one_root_with_the_receipts_claim
             cc = hal.code_commit(gc, size)
             roots[size] = cc.root()
             cc.free()
-    rec = recursion.Recursor(hal, rec_blob, blob, entry.code_object_path("recursion"), po2=12, segment_roots=roots)
+    rec = recursion.Recursor(hal, rec_blob, blob, entry.code_object_path("recursion"), po2=17, segment_roots=roots)  # 2^16-row trace seals: ~50k words
     root = rec.fold([rec.lift(s, cl) for s, cl in zip(seals, claims)])
     want = r0.ReceiptClaim.make(claims[0].pre, claims[-1].post, claims[halting].exit_system, claims[halting].exit_user, bytes(claims[halting].output_digest))
     assert rec.verify(root) and root.claim.digest() == want.digest() and bytes(root.claim.output_digest) == r0.output_digest(receipt.journal) and root.claim.exit_system == 0

@@ -131,7 +131,7 @@ def fp4_mul_sym(b, x, y):
     return [b.add(c[0], b.mul(beta, c[4])), b.add(c[1], b.mul(beta, c[5])), b.add(c[2], b.mul(beta, c[6])), c[3]]
 
 
-def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5, comp=16):
+def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5, comp=16, sponge=False):
     """Columns are grouped into components of `comp` DATA columns (as a real circuit's registers belong to one
     instruction/memory/... component): a derived column reads its own or the previous component, and a constraint
     touches the taps of one component plus CODE selectors.  Constraints are emitted component by component."""
@@ -159,8 +159,11 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
     acc_cols = [(0, rng.below(n_data), rng.below(n_data)) for _ in range(n_acc)]
     global_cols = [k for k in range(n_data) if is_free[k]][:n_global]
 
+    # the in-circuit sponge (tools/sponge_component.py) sits behind the synthetic columns of both groups
+    n_code_all = n_code + (sponge_component.SPONGE_CODE if sponge else 0)
+    n_data_all = n_data + (sponge_component.SPONGE_DATA if sponge else 0)
     b = Builder()
-    for g, size in ((G_ACCUM, 4 * n_acc), (G_CODE, n_code), (G_DATA, n_data)):
+    for g, size in ((G_ACCUM, 4 * n_acc), (G_CODE, n_code_all), (G_DATA, n_data_all)):
         for col in range(size):
             b.taps.add((g, col, 0))
 
@@ -206,6 +209,15 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
         want = fp4_mul_sym(b, term, sel)
         tail.extend((b.sub(b.get(G_ACCUM, 4 * j + i, 0), want[i]), 3) for i in range(4))
 
+    sponge_vals = []
+    if sponge:
+        assert n_global == 16, "the sponge's digest is public inputs 8..15"
+        sponge_vals = [(e.v, deg) for e, deg in sponge_component.constraints(
+            b, E, lambda col, back: E(b, b.get(G_DATA, n_data + col, back), 1), lambda col, back: E(b, b.get(G_CODE, n_code + col, back), 1),
+            lambda j: E(b, b.glob(0, 8 + j), 0), E(b, first, 1), E(b, b.get(G_CODE, 1, 0), 1))]
+        code_cols = code_cols + [(6, j) for j in range(sponge_component.SPONGE_CODE)]
+        data_cols = data_cols + [(0, 0, 0, 0, 0)] * sponge_component.SPONGE_DATA
+
     all_vals = [v for q in range(n_comp) for v in by_comp[q]] + tail
     assert max(deg for _, deg in all_vals) <= 5  # check = C / (x^N - 1) must stay below degree 4N
     # constraint chain; every cond_every-th run of 8 constraints sits inside an AndCond gated by a CODE column.
@@ -224,6 +236,9 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
         else:
             for v, _ in chunk:
                 x = b.and_eqz(x, v)
+    for v, _ in sponge_vals:  # never behind a gate
+        x = b.and_eqz(x, v)
+    all_vals = all_vals + sponge_vals
     ret = x
 
     taps = sorted(b.taps)
@@ -237,17 +252,25 @@ def generate(n_code, n_data, n_acc, n_free, n_pad, n_global, seed, cond_every=5,
     def section(tag, words):
         return [tag, len(words)] + list(words)
 
-    words = [MAGIC, 1, 7]
-    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_SYNTH:v1__")))
-    words += section(SEC_GROUPS, [4 * n_acc, n_code, n_data])
+    words = [MAGIC, 1, 9 if sponge else 7]
+    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_RECUR:v2__" if sponge else b"R0HIP_SYNTH:v1__")))
+    words += section(SEC_GROUPS, [4 * n_acc, n_code_all, n_data_all])
     words += section(SEC_TAPS, [len(taps)] + [w for t in taps for w in t])
     words += section(SEC_GLOBALS, [n_global, 8 * n_acc] + global_cols)
     words += section(SEC_POLY, [len(steps), ret] + [w for s in steps for w in s])
-    words += section(SEC_WITGEN, [n_code] + [w for cc in code_cols for w in cc] + [n_data] + [w for d in data_cols for w in d])
+    words += section(SEC_WITGEN, [n_code_all] + [w for cc in code_cols for w in cc] + [n_data_all] + [w for d in data_cols for w in d])
     words += section(SEC_ACCUM, [n_acc] + [w for a in acc_cols for w in a])
+    if sponge:
+        table = sponge_component.schedule()
+        words += section(SEC_PERIODIC, [sponge_component.PERIOD, len(table)] + [v for col in table for v in col])
+        words += section(SEC_SPONGE, [n_code, n_data, 8])
     info = {"taps": len(taps), "steps": len(steps), "constraints": len(all_vals), "mul_per_point": b.n_mul,
-            "addsub_per_point": b.n_add, "groups": [4 * n_acc, n_code, n_data], "components": n_comp}
+            "addsub_per_point": b.n_add, "groups": [4 * n_acc, n_code_all, n_data_all], "components": n_comp}
     return words, info
+
+
+SEC_PERIODIC, SEC_SPONGE = 11, 12
+import sponge_component  # noqa: E402
 
 
 # ---- the trace circuit (tools/trace_circuit.py holds its columns, constraints and log-derivative argument) ------------------------
@@ -419,7 +442,7 @@ SHAPES = {
     "bench": dict(n_code=16, n_data=192, n_acc=12, n_free=24, n_pad=2600, n_global=8, seed=3, comp=16),
     # recursion-SHAPED: a smaller trace (proved at po2 = 18) whose 16 public inputs carry the two 8-word digests a lift/join step
     # stands for (hyperfridge-r0_amd/recursion.py).  It does not verify seals in-circuit: risc0's recursion circuit is not reproducible here.
-    "recursion": dict(n_code=8, n_data=96, n_acc=6, n_free=20, n_pad=900, n_global=16, seed=4, comp=12),
+    "recursion": dict(n_code=8, n_data=96, n_acc=6, n_free=20, n_pad=900, n_global=16, seed=4, comp=12, sponge=True),
 }
 
 
