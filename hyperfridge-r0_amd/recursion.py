@@ -4,7 +4,8 @@ risc0-zkvm `ProverServer::lift(SegmentReceipt)` turns every segment seal into a 
 them into one, and the folds form a binary tree whose levels are the only inter-GPU exchange of the whole path.  The proving side --
 lift, join, the composition of claims ({pre: a.pre, post: b.post, ..}), the refusal of two nodes that do not follow one another --
 lives in the library behind the C ABI (csrc/recursion.cpp: r0h_recursor_new / r0h_lift / r0h_join / r0h_node_*; what a node's
-proof is and is not -- children checked BESIDE the proof, not risc0's recursion circuit -- is stated there and in include/r0hip.h).
+proof is and is not -- the digest of what it consumed computed in-circuit, the children's seals checked BESIDE the proof, not risc0's
+recursion circuit -- is stated there and in include/r0hip.h).
 This module is the transport only: which rank hands its subtree to which, and how a node travels.
 
 Transport: `torch.distributed` point-to-point send/recv (backend "nccl" = RCCL over xGMI on a GPU node, "gloo" on CPU), one

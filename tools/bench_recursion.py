@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4] in shape: every rank proves its share of segments, lifts each seal, folds its own nodes, and the
 ranks join pairwise up a binary tree over torch.distributed point-to-point (RCCL on a GPU node).  Rank 0 prints one JSON
-line with the tree latency.  The recursion circuit is recursion-SHAPED only (hyperfridge-r0_amd/recursion.py): the seals a
-step consumes are checked by the host-side verifier beside the proof, not inside it.
+line with the tree latency.  The recursion circuit is this repository's (hyperfridge-r0_amd/recursion.py): it computes the digest of what
+a step consumes inside the proof (one Poseidon2 round per row); the consumed seals themselves are checked by the host-side verifier
+beside the proof, not inside it.
 
   python tools/bench_recursion.py --segments 8                                    one GPU, whole tree in-process
   python tools/bench_recursion.py --gpus N --segments 64 [--backend gloo --share-device]
@@ -97,6 +98,8 @@ def main():
     barrier()
     t1 = time.perf_counter()
     nodes = [rec.lift(seal, claims[s]) for seal, s in zip(seals, mine)]
+    hal.sync()
+    t_lifted = time.perf_counter()
     node = rec.fold(nodes) if nodes else None
     barrier()
     t2 = time.perf_counter()
@@ -116,9 +119,11 @@ def main():
             open(args.root_out + ".claim.bin", "wb").write(bytes(node.claim))
         steps = len(recursion.tree_schedule(world))
         bench.emit_result({
-            "metric": "lift+join tree over segment seals (configs[4] in shape; recursion-shaped circuit, see hyperfridge-r0_amd/recursion.py)",
+            "metric": "lift+join tree over segment seals (configs[4] in shape; this repository's recursion circuit with the in-circuit digest, see hyperfridge-r0_amd/recursion.py)",
             "n_gpus": world, "segments": args.segments, "segment_po2": args.segment_po2, "recursion_po2": args.recursion_po2,
-            "prove_segments_s": round(t1 - t0, 4), "lift_and_local_fold_s": round(t2 - t1, 4), "cross_rank_joins_s": round(t3 - t2, 4),
+            "prove_segments_s": round(t1 - t0, 4), "lift_and_local_fold_s": round(t2 - t1, 4),
+            "ms_per_lift": round(1e3 * (t_lifted - t1) / max(1, len(mine)), 2), "ms_per_local_join": round(1e3 * (t2 - t_lifted) / max(1, len(mine) - 1), 2),
+            "segment_seal_words": int(seals[0].size) if seals else 0, "cross_rank_joins_s": round(t3 - t2, 4),
             "cross_rank_join_steps": steps, "tree_latency_s": round(t3 - t1, 4), "end_to_end_s": round(t3 - t0, 4),
             "root_verifies": bool(root_ok), "root_claim_is_the_sessions_end_to_end_claim": bool(node.claim.digest() == end_to_end.digest()),
             "root_seal_words": int(node.seal.size), "backend": args.backend if world > 1 else "none",

@@ -12,7 +12,9 @@ Shapes:
   tiny   W=(8 accum, 4 code, 12 data)      unit tests (CPU oracle in milliseconds)
   small  W=(16, 8, 40)                      GPU parity tests
   bench  W=(48, 16, 192) = 256 columns      SURVEY.md 8(d) config 2 (20k mul + 30k add/sub per point, <= 600 taps)
-  recursion  W=(24, 8, 96), 16 public inputs   the second circuit of SURVEY.md 8(a) a19 in shape only (lift/join at po2 = 18)
+  recursion  W=(24, 36, 161), 16 public inputs  the second circuit of SURVEY.md 8(a) a19 (lift/join at po2 = 18): the synthetic columns of
+                                            W=(24, 8, 96) plus the Poseidon2 sponge component (tools/sponge_component.py) that computes the digest
+                                            of what a node consumed -- public inputs 8..15 -- in-circuit
   trace  W=(40, 6, 138)                     columns = the executor's preflight rows (tools/trace_circuit.py): one contiguous run, every instruction's
                                             semantics, memory consistency, lookups, the session-wide memory argument
 """
@@ -440,8 +442,9 @@ SHAPES = {
     # 8 public inputs: enough to name a receipt claim (r0h_claim_globals), as `bench` can
     "small": dict(n_code=8, n_data=40, n_acc=4, n_free=8, n_pad=60, n_global=8, seed=2, comp=10),
     "bench": dict(n_code=16, n_data=192, n_acc=12, n_free=24, n_pad=2600, n_global=8, seed=3, comp=16),
-    # recursion-SHAPED: a smaller trace (proved at po2 = 18) whose 16 public inputs carry the two 8-word digests a lift/join step
-    # stands for (hyperfridge-r0_amd/recursion.py).  It does not verify seals in-circuit: risc0's recursion circuit is not reproducible here.
+    # a smaller trace (proved at po2 = 18) whose 16 public inputs carry the two 8-word digests a lift/join step stands for
+    # (hyperfridge-r0_amd/recursion.py); the second digest is the output of the in-circuit sponge.  It does not verify seals in-circuit:
+    # risc0's recursion circuit is not reproducible here.
     "recursion": dict(n_code=8, n_data=96, n_acc=6, n_free=20, n_pad=900, n_global=16, seed=4, comp=12, sponge=True),
 }
 
