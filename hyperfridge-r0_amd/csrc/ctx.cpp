@@ -285,7 +285,14 @@ const char* r0h_ctx_create(int device, r0h_ctx** out) {
     R0H_TRY(upload_pow_table(&ctx->twb_hi[d], fpow(w26, TWB_SIZE), TWB_SIZE));
     R0H_TRY(upload_pow_table(&ctx->tw_lo[d], w22, TW_SIZE));
     R0H_TRY(upload_pow_table(&ctx->tw_hi[d], fpow(w22, TW_SIZE), TW_SIZE));
-    R0H_TRY(upload_pow_table(&ctx->tw12[d], d == 0 ? rou_fwd(TWL_BITS) : rou_rev(TWL_BITS), 1u << (TWL_BITS - 1)));
+    {  // the in-chunk table, followed by the same words canonical and by their Shoup companions (ntt.hip, R0H_NTT_SHOUP)
+      const uint32_t n12 = 1u << (TWL_BITS - 1), base = d == 0 ? rou_fwd(TWL_BITS) : rou_rev(TWL_BITS);
+      std::vector<uint32_t> t(3 * (size_t)n12);
+      uint32_t cur = ONE;
+      for (uint32_t i = 0; i < n12; i++) { t[i] = cur; t[n12 + i] = dec(cur); t[2 * n12 + i] = shoup_companion(t[n12 + i]); cur = mul(cur, base); }
+      R0H_TRY_HIP(hipMalloc((void**)&ctx->tw12[d], t.size() * 4));
+      R0H_TRY_HIP(hipMemcpy(ctx->tw12[d], t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
   }
   R0H_TRY(upload_pow_table(&ctx->pow3_lo, enc(3), TW_SIZE));
   R0H_TRY(upload_pow_table(&ctx->pow3_hi, fpow(enc(3), TW_SIZE), TW_SIZE));

@@ -130,9 +130,18 @@ __global__ __launch_bounds__(512) void ntt_strided_kernel(uint32_t* io, uint32_t
 // in VGPRs, runs the layers of one 4-bit index field on them, and the block exchanges through LDS between rounds
 // (2 LDS writes + 2 LDS reads per word per pass instead of 2 per layer).  Twiddles of a round are
 // ROU[l]^(low bits) -- one table word per layer and thread -- times a constant 16th root of unity.
+#ifndef R0H_NTT_SHOUP
+#define R0H_NTT_SHOUP 0  // A/B: table and constant twiddles in Shoup form (fp.hpp mul_const); see profiles/r04/ntt_shoup_ab.md
+#endif
 struct W16 {
   uint32_t w[8];  // ROU[4]^k, k < 8 (forward or inverse)
+#if R0H_NTT_SHOUP
+  uint32_t wc[8], ws[8];  // the same constants canonical, and their Shoup companions floor(w 2^32 / p)
+#endif
 };
+#if R0H_NTT_SHOUP
+constexpr uint32_t TW12_WORDS = 1u << (TWL_BITS - 1);  // tw12 is followed by its canonical form and its Shoup companions (ctx.cpp)
+#endif
 
 // Layers of the field at bit B (width W) on 16 >> W independent sets; DIT when DIR == 0 (skipping layers below
 // LO_LAYER), DIF when DIR == 1.  rest0 = index of the thread's first set among the 2^(m-W) sets of the sub-transform.
@@ -148,6 +157,15 @@ __device__ __forceinline__ void field_layers(uint32_t (&x)[16], uint32_t rest0, 
       if (DIR == 0 && l < LO_LAYER) continue;
       uint32_t a_tw = ONE;
       if (B != 0) a_tw = tw12[low << (TWL_BITS - (B + l + 1))];
+#if R0H_NTT_SHOUP
+      uint32_t a_c = 1u, a_s = 0u;  // the table word canonical, and its Shoup companion
+      if (B != 0) { a_c = tw12[TW12_WORDS + (low << (TWL_BITS - (B + l + 1)))]; a_s = tw12[2 * TW12_WORDS + (low << (TWL_BITS - (B + l + 1)))]; }
+      auto times = [&](uint32_t y, int cidx) {  // y times the butterfly's twiddle: one Shoup product per factor that is not one
+        if (B != 0) y = mul_const(y, a_c, a_s);
+        if (cidx != 0) y = mul_const(y, c.wc[cidx], c.ws[cidx]);
+        return y;
+      };
+#endif
 #pragma unroll
       for (int j0 = 0; j0 < (1 << W); j0++) {
         if (j0 & (1 << l)) continue;
@@ -155,6 +173,17 @@ __device__ __forceinline__ void field_layers(uint32_t (&x)[16], uint32_t rest0, 
         uint32_t& u = x[s * (1 << W) + j0];
         uint32_t& v = x[s * (1 << W) + j1];
         const bool trivial = B == 0 && cidx == 0;
+#if R0H_NTT_SHOUP
+        if (DIR == 0) {
+          uint32_t a = u, t = trivial ? v : times(v, cidx);
+          u = add(a, t);
+          v = sub(a, t);
+        } else {
+          uint32_t a = u, t = v;
+          u = add(a, t);
+          v = trivial ? sub(a, t) : times(sub(a, t), cidx);
+        }
+#else
         uint32_t twd = cidx == 0 ? a_tw : (B == 0 ? c.w[cidx] : mul_lazy(a_tw, c.w[cidx]));  // < 2p is fine as a multiplier
         if (DIR == 0) {
           uint32_t a = u, t = trivial ? v : mul(v, twd);
@@ -165,6 +194,7 @@ __device__ __forceinline__ void field_layers(uint32_t (&x)[16], uint32_t rest0, 
           u = add(a, t);
           v = trivial ? sub(a, t) : mul(sub(a, t), twd);
         }
+#endif
       }
     }
   }
@@ -575,7 +605,14 @@ static Split16 split16_for(uint32_t n) {
 static W16 make_w16(bool inverse) {
   W16 c;
   uint32_t w = inverse ? rou_rev(4) : rou_fwd(4), cur = ONE;
-  for (int k = 0; k < 8; k++) { c.w[k] = cur; cur = mul(cur, w); }
+  for (int k = 0; k < 8; k++) {
+    c.w[k] = cur;
+#if R0H_NTT_SHOUP
+    c.wc[k] = dec(cur);
+    c.ws[k] = shoup_companion(c.wc[k]);
+#endif
+    cur = mul(cur, w);
+  }
   return c;
 }
 static size_t local16_lds_bytes(uint32_t L) { return (((size_t)1 << L) + ((size_t)1 << (L - 4))) * 4; }
