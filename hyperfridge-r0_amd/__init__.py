@@ -628,7 +628,7 @@ class ReceiptClaim(ctypes.Structure):
         return claim_globals(self.digest())
 
 
-TRACE_COLUMNS = 138  # R0H_TRACE_COLUMNS
+TRACE_COLUMNS = 128  # R0H_TRACE_COLUMNS
 # R0H_TRACE_GLOBALS: claim words 0..7, first pc, pc after the last cycle, cycles, end kind (0 cut / 1 HALT / 2 PAUSE), kind != 0, exit code halves, segment
 # number, closing, number x (1 - closing), first / last boundary address; LATE (the last 20): the session challenge (16), the segment's sum under it (4)
 TRACE_GLOBALS = 40

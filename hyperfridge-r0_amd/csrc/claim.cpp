@@ -137,7 +137,7 @@ void claim_globals(const uint8_t digest[32], uint32_t out[8]) {
 // what a trace-circuit seal says in its public inputs beyond the claim's name, held against the claim it is carried with: the pc the
 // run starts from and stops at, whether it ends in HALT / PAUSE, and with which exit code (r0h_receipt_verify, r0h_lift)
 bool is_trace_circuit(const r0h_circuit& circ) {
-  return !memcmp(circ.info, "R0HIP_TRACE:v4__", 16) && circ.n_global == R0H_TRACE_GLOBALS && circ.n_late == R0H_TRACE_LATE_GLOBALS;
+  return !memcmp(circ.info, "R0HIP_TRACE:v5__", 16) && circ.n_global == R0H_TRACE_GLOBALS && circ.n_late == R0H_TRACE_LATE_GLOBALS;
 }
 bool trace_seal_carries_claim(const uint32_t* seal, const r0h_receipt_claim& claim) {
   if (seal[8] != enc(claim.pre.pc) || seal[9] != enc(claim.post.pc)) return false;

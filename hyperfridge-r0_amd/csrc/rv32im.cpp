@@ -635,24 +635,24 @@ const char* column_name(uint32_t column) {
     std::vector<std::string> n;
     auto run = [&](const char* stem, int count) { for (int k = 0; k < count; k++) n.push_back(stem + std::to_string(k)); };
     for (const char* s : {"live", "bnd", "cycle", "pc", "next_pc"}) n.push_back(s);
-    for (const char* s : {"lui", "auipc", "jal", "jalr", "branch", "load", "store", "imm", "op", "fence", "system"}) n.push_back(std::string("opc_") + s);
-    run("f3_", 8);
+    for (const char* s : {"lui", "auipc", "jal", "jalr", "branch", "load", "store", "imm", "op", "system"}) n.push_back(std::string("opc_") + s);
+    for (int k = 1; k < 8; k++) n.push_back("f3_" + std::to_string(k));
     for (const char* s : {"alu", "rd0", "rdA", "rdB", "r10", "r1A", "r1B", "r20", "r2A", "r2B", "b25", "f7A", "f7B", "b30", "b31",
-                          "rs1_lo", "rs1_hi", "p0", "dl0", "dh0", "rs2_lo", "rs2_hi", "p1", "dl1", "dh1",
-                          "zrd", "inv_rd", "act2", "old_lo", "old_hi", "p2", "dl2", "dh2",
-                          "mem_act", "mem_wr", "top", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "dl3", "dh3", "p4", "dl4", "dh4"})
+                          "rs1_lo", "rs1_hi", "dl0", "dh0", "rs2_lo", "rs2_hi", "dl1", "dh1",
+                          "zrd", "inv_rd", "act2", "old_lo", "old_hi", "dl2", "dh2",
+                          "mem_wr", "top", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "dl3", "dh3", "dl4", "dh4"})
       n.push_back(s);
     run("u", 4);
-    run("v", 4);
+    for (int k = 1; k < 4; k++) n.push_back("v" + std::to_string(k));
     run("a", 4);
     n.push_back("su");
     n.push_back("sv");
     run("sh", 5);
-    for (const char* s : {"vrd", "vrb", "z_lo", "z_hi", "ob0", "ob1", "zq", "w_lo", "w_hi", "aux0", "aux1",
+    for (const char* s : {"vrd", "vrb", "z_hi", "ob0", "ob1", "zq", "w_lo", "w_hi", "aux0", "aux1",
                           "res_lo", "res_hi", "c0", "c1", "lt", "eq", "zinv", "sb", "sgn", "p8", "sx", "sm"})
       n.push_back(s);
     run("mb", 4);
-    for (const char* s : {"ce0", "ce1a", "ce1b", "ce2", "cb1", "cb2", "cband", "c3", "dv", "ovf", "k0", "a31", "io", "f0", "f1", "f2", "fn_cyc", "cact", "fimg", "m16", "mand"})
+    for (const char* s : {"ce0", "ce1a", "ce1b", "ce2", "cb1", "cb2", "cband", "c3", "dv", "ovf", "k0", "a31", "f0", "f1", "f2", "fn_cyc", "cact", "fimg", "m16", "mand"})
       n.push_back(s);
     return n;
   }();

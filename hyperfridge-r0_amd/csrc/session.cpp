@@ -7,7 +7,7 @@
 // every segment (system states from the run, exit code, the journal's output digest on the last one) is bound to its seal through
 // the public inputs (csrc/claim.cpp).
 //
-// With the trace circuit (circuits/trace.r0c, ProtocolInfo "R0HIP_TRACE:v4__") the seal of a segment attests THAT segment: the
+// With the trace circuit (circuits/trace.r0c, ProtocolInfo "R0HIP_TRACE:v5__") the seal of a segment attests THAT segment: the
 // executor keeps one compact row per cycle plus one per address touched, the device expands them into the DATA group
 // (csrc/trace.hip: 72 bytes per cycle cross PCIe, not the 552 bytes of an expanded row), and the proof is over those columns --
 // contiguity, every instruction's semantics and memory consistency as include/r0hip.h lists them.  The guest runs ahead on its
@@ -189,7 +189,7 @@ const char* r0h_session_begin(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t*
   R0H_GUARD_BEGIN
   R0H_REQUIRE(ctx && c && elf && session_out && (input_words || !n_input), "r0h_prove_elf: NULL argument");
   R0H_REQUIRE(parts >= 1 && part < parts, "r0h_prove_elf_part: part %u of %u", part, parts);
-  const bool trace_mode = !memcmp(c->info, "R0HIP_TRACE:v4__", 16);
+  const bool trace_mode = !memcmp(c->info, "R0HIP_TRACE:v5__", 16);
   // (a trace-circuit segment of fewer than 2^16 rows is proved at 2^16: the lookup tables' size)
   R0H_REQUIRE(segment_po2 >= 9 && segment_po2 <= (trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2), "r0h_prove_elf: segment_po2 %u outside [9, %u]", segment_po2,
               (unsigned)(trace_mode ? R0H_TRACE_MAX_PO2 : R0H_MAX_PO2));

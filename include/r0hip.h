@@ -488,14 +488,17 @@ uint64_t r0h_vm_cycles(const r0h_vm* vm);
 const char* r0h_vm_segment_info(const r0h_vm* vm, size_t i, r0h_vm_segment* out);
 const char* r0h_vm_preflight(const r0h_vm* vm, size_t i, const r0h_preflight_row** rows, size_t* n);
 const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_bound** rows, size_t* n);
-/* ---- the trace circuit, version 4 (circuits/trace.r0c, tools/trace_circuit.py): a circuit whose DATA group IS the preflight trace of a
+/* ---- the trace circuit, version 5 (circuits/trace.r0c, tools/trace_circuit.py): a circuit whose DATA group IS the preflight trace of a
  * segment.  R0H_TRACE_COLUMNS columns of 2^po2 rows (po2 >= 16: two 2^16-row lookup tables sit in the CODE group), column-major,
  * Montgomery words: first the cycles (one row each), then the boundary rows (one per register / word touched; in a closing segment
  * one per word the whole session touched and per image word), then blank rows.  Per cycle: pc, next pc, the instruction word as
  * decoded fields with a one-hot opcode and funct3, five accesses -- the fetch, x[rs1], x[rs2], x[rd], the memory word, in this order of
- * timestamps (5 c + 1..5) -- each with the timestamp of the access it follows, and the work words of the arithmetic units: two
- * operands byte by byte with their AND (U, V), two words as 16-bit halves (Z, W), carries.  What the circuit constrains
- * (tools/trace_circuit.py trace_constraints: 312 polynomials of degree <= 5 over 203 taps; csrc/trace.hpp fills the columns):
+ * timestamps (5 c + 1..5) -- each with the two looked-up limbs of the distance to the access it follows, and the work words of the
+ * arithmetic units: two operands byte by byte with their AND (U, V), two words as 16-bit halves (Z, W), carries.  Ten quantities the
+ * constraints speak of are linear forms of these columns rather than columns (the last flag of each one-hot group, V's low byte, Z's
+ * low half, the memory and transfer flags, four of the five consumed timestamps): 128 columns, eight Poseidon2 permutations per
+ * committed row.  What the circuit constrains (tools/trace_circuit.py trace_constraints: 302 polynomials of degree <= 5 over 193
+ * taps; csrc/trace.hpp fills the columns):
  *   - the cycles form one contiguous run from the public first pc to the public last pc in the public number of cycles;
  *   - WHAT EVERY INSTRUCTION DOES: the word decodes to exactly one RV32IM instruction (an illegal encoding has no satisfying row);
  *     the value written to rd, the word written to memory, the address of a load / store and the next pc are the ones the ISA
@@ -527,7 +530,7 @@ const char* r0h_vm_boundary(const r0h_vm* vm, size_t i, const r0h_preflight_boun
  * the two halves of the exit code (a0), the segment's number (index + 1), whether it closes the session, number x (1 - closing), the
  * first and last boundary address; LATE (absorbed after the DATA commitment): the session challenge (16 words), the segment's sum
  * (4).  r0h_receipt_verify[_elf] holds them against the claims and against one another.  Trace sizes 2^16..2^21 rows (timestamps < 2^24). ---- */
-#define R0H_TRACE_COLUMNS 138
+#define R0H_TRACE_COLUMNS 128
 #define R0H_TRACE_GLOBALS 40
 #define R0H_TRACE_LATE_GLOBALS 20 /* the last 20 public inputs: the session's challenge (16 words) and the segment's sum under it (4) */
 #define R0H_TRACE_GAMMA 20         /* where the session challenge sits among the public inputs; the segment's sum follows at 36 */

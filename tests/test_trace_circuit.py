@@ -44,10 +44,10 @@ def _run(n_loop=60, po2=20):
     return vm, base
 
 
-PRIMARY = (["live", "bnd", "cycle", "pc", "next_pc"] + ["opc_" + n for n, _ in OPCODES] + ["f3_%d" % k for k in range(8)]
+PRIMARY = (["live", "bnd", "cycle", "pc", "next_pc"] + ["opc_" + n for n, _ in OPCODES[:-1]] + ["f3_%d" % k for k in range(1, 8)]
            + ["rd0", "rdA", "rdB", "r10", "r1A", "r1B", "r20", "r2A", "r2B", "b25", "f7A", "f7B", "b30", "b31"]
-           + ["rs1_lo", "rs1_hi", "p0", "dl0", "dh0", "rs2_lo", "rs2_hi", "p1", "dl1", "dh1", "zrd", "inv_rd", "act2", "old_lo", "old_hi", "p2", "dl2", "dh2"]
-           + ["mem_act", "mem_wr", "top", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "p4", "dl4", "dh4", "fimg"])
+           + ["rs1_lo", "rs1_hi", "dl0", "dh0", "rs2_lo", "rs2_hi", "dl1", "dh1", "zrd", "inv_rd", "act2", "old_lo", "old_hi", "dl2", "dh2"]
+           + ["mem_wr", "top", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "dl4", "dh4", "fimg"])
 
 
 def expand(rows, bounds, po2, number=1, closing=True):
@@ -64,10 +64,9 @@ def expand(rows, bounds, po2, number=1, closing=True):
     m[COL["cycle"], L] = cyc
     m[COL["pc"], L] = r[:, F["pc"]]
     m[COL["next_pc"], L] = r[:, F["next_pc"]]
-    for name, code in OPCODES:
+    for name, code in OPCODES[:-1]:  # (FENCE, the last of the list, has no column: it is `live` minus the others)
         m[COL["opc_" + name], L] = (insn & 0x7F) == code
-    m[COL["f3_0"]] = 1
-    for k in range(8):
+    for k in range(1, 8):            # (funct3 = 0 likewise: one minus the others)
         m[COL["f3_%d" % k], L] = ((insn >> 12) & 7) == k
     for stem, shift in (("rd", 7), ("r1", 15), ("r2", 20)):
         idx = (insn >> shift) & 31
@@ -76,10 +75,9 @@ def expand(rows, bounds, po2, number=1, closing=True):
         m[COL[stem + "B"], L] = idx >> 3
     m[COL["b25"], L], m[COL["f7A"], L], m[COL["f7B"], L], m[COL["b30"], L], m[COL["b31"], L] = (insn >> 25) & 1, (insn >> 26) & 3, (insn >> 28) & 3, (insn >> 30) & 1, insn >> 31
     small = np.array([0] + [inv(i) for i in range(1, 32)], dtype=np.int64)
-    for k, (lo, hi, p, dl, dh, val) in enumerate((("rs1_lo", "rs1_hi", "p0", "dl0", "dh0", "rs1"), ("rs2_lo", "rs2_hi", "p1", "dl1", "dh1", "rs2"))):
+    for k, (lo, hi, dl, dh, val) in enumerate((("rs1_lo", "rs1_hi", "dl0", "dh0", "rs1"), ("rs2_lo", "rs2_hi", "dl1", "dh1", "rs2"))):
         m[COL[lo], L] = r[:, F[val]] & 0xFFFF          # every cycle reads two registers, x0 included
         m[COL[hi], L] = r[:, F[val]] >> 16
-        m[COL[p], L] = r[:, F["prev"] + k]
         diff = 5 * cyc + STAMP[k] - r[:, F["prev"] + k] - 1
         assert (diff >= 0).all() and (diff < 1 << 24).all()
         m[COL[dl], L], m[COL[dh], L] = diff & 0xFFFF, diff >> 16
@@ -90,18 +88,15 @@ def expand(rows, bounds, po2, number=1, closing=True):
     m[COL["act2"], L] = wr
     m[COL["old_lo"], L] = np.where(wr, r[:, F["rd_before"]] & 0xFFFF, 0)
     m[COL["old_hi"], L] = np.where(wr, r[:, F["rd_before"]] >> 16, 0)
-    m[COL["p2"], L] = np.where(wr, r[:, F["prev"] + 2], 0)
     diff = np.where(wr, 5 * cyc + STAMP[2] - r[:, F["prev"] + 2] - 1, 0)
     m[COL["dl2"], L], m[COL["dh2"], L] = diff & 0xFFFF, diff >> 16
     mem = r[:, F["mem_kind"]] != 0
-    m[COL["mem_act"], L] = mem
     m[COL["mem_wr"], L] = r[:, F["mem_kind"]] == r0.MEM_WRITE
     m[COL["addr3"], L] = np.where(mem, r[:, F["mem_addr"]] >> 2, 0)
     for name, f in (("before", "mem_before"), ("after", "mem_after")):
         m[COL[name + "_lo"], L] = np.where(mem, r[:, F[f]] & 0xFFFF, 0)
         m[COL[name + "_hi"], L] = np.where(mem, r[:, F[f]] >> 16, 0)
     m[COL["p3"], L] = np.where(mem, r[:, F["prev"] + 3], 0)
-    m[COL["p4"], L] = r[:, F["prev"] + 4]
     diff = 5 * cyc + STAMP[4] - r[:, F["prev"] + 4] - 1
     m[COL["dl4"], L], m[COL["dh4"], L] = diff & 0xFFFF, diff >> 16
     if nb:
@@ -118,8 +113,7 @@ def expand(rows, bounds, po2, number=1, closing=True):
         m[COL["top"], B] = top
         m[COL["dl0"], B], m[COL["dl1"], B] = low & 0xFFFF, low >> 16
         m[COL["dh0"], B] = np.where(top == 1, 8 * (low & 0xFFFF), 0)
-        m[COL["p0"], B] = bb[:, 4]                                                           # the segment that held the address before
-        m[COL["dl2"], B] = number - bb[:, 4] - 1
+        m[COL["dl2"], B] = number - bb[:, 4] - 1                                             # the segment that held the address before: an earlier one
         if closing:
             m[COL["old_lo"], B], m[COL["old_hi"], B] = bb[:, 5] & 0xFFFF, bb[:, 5] >> 16     # the address's initial value
             m[COL["fimg"], B] = bb[:, 6] & 1
@@ -171,7 +165,7 @@ def seal_of(orc, prover, po2, data, glob, seed=3):
 
 
 def test_column_list_is_the_one_the_library_fills():
-    assert r0.trace_column_names() == TRACE_COLUMNS and len(TRACE_COLUMNS) == r0.TRACE_COLUMNS == 138
+    assert r0.trace_column_names() == TRACE_COLUMNS and len(TRACE_COLUMNS) == r0.TRACE_COLUMNS == 128
     assert tc.TRACE_GLOBALS == r0.TRACE_GLOBALS and tc.G_GAMMA == r0.TRACE_GAMMA and tc.G_SUM == r0.TRACE_SUM and tc.MIN_PO2 == r0.TRACE_MIN_PO2
 
 
@@ -260,7 +254,7 @@ def test_an_execution_proves_and_an_altered_one_does_not(orc, prover):
     assert "run:cycle" in B(("cycle", mid, mid + 1))                          # a skipped cycle
     assert "run:after_live" in B(("live", mid, 0))                            # a hole in the run
     assert B(("live", N - 1, 1))                                              # a row smuggled in after the end
-    assert "bit:mem_act" in B(("mem_act", mid, 2))
+    assert "bit:mem_wr" in B(("mem_wr", mid, 2))
     assert "mem:keeps_lo" in B(("after_lo", rd, (rows[rd].mem_after & 0xffff) ^ 1))  # a read that changes the word
     data_m = canonical(data, PO2)
     gl = [int(x) * R_INV % P for x in glob]
@@ -293,15 +287,15 @@ def test_an_execution_proves_and_an_altered_one_does_not(orc, prover):
     assert mem_sum(B(("old_hi", w_row, (rows[w_row].rd_before >> 16) ^ 1)))    # a write that misstates what it overwrote
     st = next(r for r, w in enumerate(rows) if w.mem_kind == r0.MEM_WRITE and r > 20)
     assert B(("after_lo", st, (rows[st].mem_after & 0xffff) ^ 4))              # a store whose word is not what the instruction stores
-    assert mem_sum(B(("p4", mid, rows[mid].prev[4] + 1), ("dl4", mid, 5 * mid + 1 - rows[mid].prev[4] - 2)))  # a made-up previous timestamp (its limbs adjusted)
-    assert "ordered:fetch" in B(("p4", mid, rows[mid].prev[4] + 1))
-    assert "lookup dh4" in B(("p4", mid, 5 * mid + 6), ("dl4", mid, P - 6 & 0xffff), ("dh4", mid, (P - 6) >> 16))  # a tuple from the future: the difference is no 24-bit number
+    assert mem_sum(B(("dl4", mid, 5 * mid + 1 - rows[mid].prev[4] - 2)))       # a made-up previous timestamp (the consumed one IS own - 1 - the limbs)
+    assert "lookup dh4" in B(("dl4", mid, P - 6 & 0xffff), ("dh4", mid, (P - 6) >> 16))  # a tuple from the future: the difference is no 24-bit number
+    ld = next(r for r, w in enumerate(rows) if w.mem_kind == r0.MEM_READ and (w.insn & 0x7f) == 0x03 and r > 20)
+    assert "ordered:mem" in B(("p3", ld, rows[ld].prev[3] + 1))                # (access 3 keeps a column for it: tied to its limbs)
     x0 = next(r for r, w in enumerate(rows) if ((w.insn >> 15) & 31) == 0 and (w.insn & 0x7f) == 0x13)
     assert mem_sum(B(("rs1_lo", x0, 5)))                                       # x0 reads what was last written there: nothing ever is
     bounds = vm.boundary(0)
     b0 = n + 3
-    assert mem_sum(B(("after_lo", b0, (bounds[3].first_value & 0xffff) ^ 1), ("z_lo", b0, (bounds[3].first_value & 0xffff) ^ 1),
-                     ("ob0", b0, (bounds[3].first_value & 1) ^ 1)))            # the first value of an address is what its first access finds
+    assert mem_sum(B(("after_lo", b0, (bounds[3].first_value & 0xffff) ^ 1), ("ob0", b0, (bounds[3].first_value & 1) ^ 1)))  # the first value of an address is what its first access finds
     assert mem_sum(B(("p3", b0, bounds[3].last_ts + 5)))
     assert "bnd:order" in B(("addr3", b0, bounds[2].addr), ("dl0", b0, bounds[2].addr & 0xffff), ("dl1", b0, bounds[2].addr >> 16))  # an address twice among the boundary rows (two histories)
     assert B(("bnd", b0, 0))                                                   # a boundary row dropped
@@ -334,7 +328,7 @@ def forged_result(r, value, word="z"):
     edits = [("res_lo", r, lo), ("res_hi", r, hi)]
     if word == "u":
         return edits + [("u%d" % i, r, (value >> (8 * i)) & 255) for i in range(4)] + [("su", r, value >> 31)]
-    edits += [(word + "_lo", r, lo), (word + "_hi", r, hi)]
+    edits += [(word + "_hi", r, hi)] + ([("w_lo", r, lo)] if word == "w" else [])  # (Z's low half is no column: its two low bits and the rest)
     if word == "z":
         edits += [("ob0", r, value & 1), ("ob1", r, (value >> 1) & 1), ("zq", r, lo >> 2), ("eq", r, int(value == 0)), ("zinv", r, pow(lo + hi, P - 2, P) if value else 0)]
     return edits
@@ -435,14 +429,14 @@ def test_an_ecall_row_does_what_its_function_says(orc):
     assert rows[cm].mem_kind == r0.MEM_READ and "ecall:commit" in B(("cact", cm, 0))                           # ... which the session sum must hear of
     done = sysrows[3][0]     # a1 = 0: falls through, touches nothing
     assert (rows[done].mem_kind, rows[done].next_pc, rows[done].rd, rows[done].rd_after) == (0, rows[done].pc + 4, A1, 0)
-    assert "ecall:mem" in B(("mem_act", done, 1))
+    assert "ecall:mem" in B(("cact", done, 1))
     cyc = sysrows[7][0]
     other = (123456 << 2) | (rows[cyc].rd_after & 3)  # (Z's two low bits also select a byte of U; kept, so nothing else has to follow)
-    got = B(("res_lo", cyc, other & 0xFFFF), ("res_hi", cyc, other >> 16), ("z_lo", cyc, other & 0xFFFF), ("z_hi", cyc, other >> 16), ("zq", cyc, (other & 0xFFFF) >> 2))
+    got = B(("res_lo", cyc, other & 0xFFFF), ("res_hi", cyc, other >> 16), ("z_hi", cyc, other >> 16), ("zq", cyc, (other & 0xFFFF) >> 2))
     assert rows[cyc].rd == A0 and all(x.startswith("sum:") for x in got)                                       # CYCLES: any word (only a later read of a0 would tell)
     assert "ecall:cycles" in B(("fn_cyc", cyc, 0))                                                             # ... into a0: the register the tuple names follows the function
     halt = sysrows[-1][0]
-    assert "ecall:mem" in B(("mem_act", halt, 1))                                                              # HALT does not touch memory
+    assert "ecall:mem" in B(("mem_wr", halt, 1))                                                               # HALT does not touch memory
     assert "ecall:act2" in B(("act2", halt, 1))                                                                # ... nor a register
     # the public inputs say how the segment ends: HALT with exit code 5
     data, glob = vm.trace_witness(0, PO2)
@@ -496,7 +490,7 @@ def test_division_in_all_its_corners(orc):
             q, rem = qq & M32, (sx(a_) - qq * sx(b_)) & M32
         assert w.rd_after == (q if f3 in (4, 5) else rem), (hex(w.insn), a_, b_)
         assert sum(int(m0[COL["u%d" % i], r]) << (8 * i) for i in range(4)) == q                               # U: the quotient
-        assert int(m0[COL["z_lo"], r]) + (int(m0[COL["z_hi"], r]) << 16) == rem                                # Z: the remainder
+        assert int(m0[COL["ob0"], r]) + 2 * int(m0[COL["ob1"], r]) + 4 * int(m0[COL["zq"], r]) + (int(m0[COL["z_hi"], r]) << 16) == rem  # Z: the remainder
         if b_ == 0 or (signed and a_ == 0x80000000 and b_ == M32):
             continue
         # the neighbouring solution of the division identity: quotient + 1, remainder - divisor (the identity's own columns are edited
@@ -504,9 +498,9 @@ def test_division_in_all_its_corners(orc):
         q2, rem2 = (q + 1) & M32, (rem - b_) & M32
         for i in range(4):
             m[COL["u%d" % i], r] = (q2 >> (8 * i)) & 255
-            m[COL["a%d" % i], r] = ((q2 >> (8 * i)) & 255) & int(m0[COL["v%d" % i], r])
+            m[COL["a%d" % i], r] = ((q2 >> (8 * i)) & 255) & ((b_ >> (8 * i)) & 255)
         m[COL["su"], r] = q2 >> 31
-        m[COL["z_lo"], r], m[COL["z_hi"], r], m[COL["zq"], r] = rem2 & 0xFFFF, rem2 >> 16, (rem2 & 0xFFFF) >> 2
+        m[COL["z_hi"], r], m[COL["zq"], r] = rem2 >> 16, (rem2 & 0xFFFF) >> 2
         m[COL["ob0"], r], m[COL["ob1"], r] = rem2 & 1, (rem2 >> 1) & 1
         m[COL["c1"], r] = rem2 >> 31
         m[COL["aux1"], r] = 2 * ((rem2 >> 16) & 0x7FFF)
@@ -608,7 +602,7 @@ def test_the_session_binds_the_segments_the_program_and_the_journal(orc, prover)
         N = 1 << PO2
         row = n1 + j
         v = b1[j].first_value ^ 0x40
-        for col, val in (("after_lo", v & 0xFFFF), ("z_lo", v & 0xFFFF), ("zq", (v & 0xFFFF) >> 2), ("before_lo", v & 0xFFFF)):
+        for col, val in (("after_lo", v & 0xFFFF), ("zq", (v & 0xFFFF) >> 2), ("before_lo", v & 0xFFFF)):
             data[COL[col] * N + row] = orc.enc(val)
         # ... and every read of it inside segment 1 sees the altered word (memory stays consistent within the segment)
         for r, w in enumerate(vm2.preflight(1)):

@@ -358,7 +358,7 @@ def generate_trace():
         return [tag, len(words)] + list(words)
 
     words = [MAGIC, 1, 8]
-    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_TRACE:v4__")))
+    words += section(SEC_INFO, list(struct.unpack("<4I", b"R0HIP_TRACE:v5__")))
     words += section(SEC_GROUPS, [4 * n_acc, n_code, n_data])
     words += section(SEC_TAPS, [len(taps)] + [w for t in taps for w in t])
     words += section(SEC_GLOBALS, [n_global, TRACE_MIX])

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The trace circuit, version 4 (ProtocolInfo "R0HIP_TRACE:v4__"): the circuit whose DATA group is the executor's preflight trace
+"""The trace circuit, version 5 (ProtocolInfo "R0HIP_TRACE:v5__"; v4 with ten columns expressed as linear forms of the others: 128 DATA
+columns): the circuit whose DATA group is the executor's preflight trace
 (include/r0hip.h: r0h_preflight_row / r0h_preflight_bound; csrc/trace.hpp holds the same column list and fills it).
 
 It stands where risc0's rv32im circuit stands (risc0-circuit-rv32im 4.0.4, Cargo.lock:3087-3089); it is NOT
@@ -33,29 +34,34 @@ TABLE_R16, TABLE_AND = 1, 2
 MIN_PO2 = 16
 
 OPCODES = [("lui", 0x37), ("auipc", 0x17), ("jal", 0x6F), ("jalr", 0x67), ("branch", 0x63), ("load", 0x03), ("store", 0x23), ("imm", 0x13),
-           ("op", 0x33), ("fence", 0x0F), ("system", 0x73)]
+           ("op", 0x33), ("system", 0x73), ("fence", 0x0F)]
+# Ten quantities the constraints speak of are LINEAR FORMS of other columns, not columns (DERIVED below): the last flag of each one-hot
+# group, V's low byte (the sum of its bits), Z's low half (its two low bits and the rest), mem_act and io (sums of the flags that
+# imply them), and the timestamps accesses 0, 1, 2 and 4 consume (own timestamp - 1 - the two looked-up limbs of the difference).
+# That is what brings the DATA group to 128 columns: eight Poseidon2 permutations per row of the commitment instead of nine.
 TRACE_COLUMNS = (["live", "bnd", "cycle", "pc", "next_pc"]
-                 + ["opc_" + name for name, _ in OPCODES]                                      # one-hot opcode
-                 + ["f3_%d" % k for k in range(8)]                                             # one-hot funct3
+                 + ["opc_" + name for name, _ in OPCODES[:-1]]                                 # one-hot opcode (FENCE: live minus the others)
+                 + ["f3_%d" % k for k in range(1, 8)]                                          # one-hot funct3 (funct3 = 0: one minus the others)
                  + ["alu"]                                                                     # OP-IMM or base-ISA OP
                  + ["rd0", "rdA", "rdB", "r10", "r1A", "r1B", "r20", "r2A", "r2B"]           # rd / rs1 / rs2: low bit and two radix-4 digits
                  + ["b25", "f7A", "f7B", "b30", "b31"]                                         # funct7: bit 25, bits 26..29 as two digits, bits 30, 31
-                 + ["rs1_lo", "rs1_hi", "p0", "dl0", "dh0"]                                    # access 0: x[rs1] (an ecall: a7)
-                 + ["rs2_lo", "rs2_hi", "p1", "dl1", "dh1"]                                    # access 1: x[rs2] (an ecall: a0)
-                 + ["zrd", "inv_rd", "act2", "old_lo", "old_hi", "p2", "dl2", "dh2"]           # access 2: x[rd] written with res
-                 + ["mem_act", "mem_wr", "top", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "dl3", "dh3"]  # access 3: the memory word / a boundary row
-                 + ["p4", "dl4", "dh4"]                                                        # access 4: the fetch
-                 + ["u%d" % k for k in range(4)] + ["v%d" % k for k in range(4)] + ["a%d" % k for k in range(4)]  # U, V and U & V, byte by byte
+                 + ["rs1_lo", "rs1_hi", "dl0", "dh0"]                                          # access 0: x[rs1] (an ecall: a7)
+                 + ["rs2_lo", "rs2_hi", "dl1", "dh1"]                                          # access 1: x[rs2] (an ecall: a0)
+                 + ["zrd", "inv_rd", "act2", "old_lo", "old_hi", "dl2", "dh2"]                 # access 2: x[rd] written with res
+                 + ["mem_wr", "top", "addr3", "before_lo", "before_hi", "after_lo", "after_hi", "p3", "dl3", "dh3"]  # access 3: the memory word / a boundary row
+                 + ["dl4", "dh4"]                                                              # access 4: the fetch
+                 + ["u%d" % k for k in range(4)] + ["v%d" % k for k in range(1, 4)] + ["a%d" % k for k in range(4)]  # U, V and U & V, byte by byte (V's low byte: its bits)
                  + ["su", "sv"]                                                                # their sign bits
                  + ["sh%d" % k for k in range(5)] + ["vrd", "vrb"]                             # V's low byte: five bits, a digit, a bit
-                 + ["z_lo", "z_hi", "ob0", "ob1", "zq", "w_lo", "w_hi", "aux0", "aux1"]        # words Z and W as halves; Z's two low bits; two spare 16-bit range checks
+                 + ["z_hi", "ob0", "ob1", "zq", "w_lo", "w_hi", "aux0", "aux1"]                # words Z and W as halves; Z's two low bits and the rest of its low half; two spare 16-bit range checks
                  + ["res_lo", "res_hi", "c0", "c1", "lt", "eq", "zinv", "sb", "sgn", "p8", "sx", "sm"]
                  + ["mb%d" % k for k in range(4)]                                              # second multiplier operand, byte limbs
                  + ["ce0", "ce1a", "ce1b", "ce2", "cb1", "cb2", "cband", "c3"]                 # the multiplier's carries (carry 0's low byte sits in dh3)
                  + ["dv", "ovf", "k0", "a31"]                                                  # division
-                 + ["io", "f0", "f1", "f2", "fn_cyc", "cact"]                                  # ecalls: moves words; function bits; CYCLES; an active COMMIT
+                 + ["f0", "f1", "f2", "fn_cyc", "cact"]                                        # ecalls: function bits; CYCLES; an active COMMIT
                  + ["fimg"]                                                                    # a closing boundary row whose word belongs to the program image
                  + ["m16", "mand"])                                                            # multiplicities of the two tables
+assert len(TRACE_COLUMNS) == 128
 COL = {name: i for i, name in enumerate(TRACE_COLUMNS)}
 N_CODE = 6            # first row, last row, row index, one seeded column, R16, AND8
 CODE_T16, CODE_TAND = 4, 5
@@ -172,8 +178,27 @@ class Fraction:
         return out
 
 
+_DERIVED = {}
+
+
+def derived():
+    """name -> linear form, for the quantities that are not columns of their own"""
+    if not _DERIVED:
+        col = LF.col
+        d = _DERIVED
+        d["opc_fence"] = col("live") - sum((col("opc_" + name) for name, _ in OPCODES[:-1]), LF())
+        d["f3_0"] = 1 - sum((col("f3_%d" % k) for k in range(1, 8)), LF())
+        d["v0"] = sum(((1 << k) * col("sh%d" % k) for k in range(5)), LF()) + 32 * col("vrd") + 128 * col("vrb")
+        d["z_lo"] = col("ob0") + 2 * col("ob1") + 4 * col("zq")
+        d["mem_act"] = col("opc_load") + col("mem_wr") + col("cact")   # a load, a store or READ_WORDS moving a word (mem_wr), a COMMIT moving one
+        d["io"] = col("f0") + col("f1") - 2 * col("fn_cyc")            # a7 = 1 or 2 (fn_cyc = f0 f1; f2 excludes both)
+        for k, key in ((0, "rs1"), (1, "rs2"), (2, "rd"), (4, "fetch")):  # the timestamp an access consumes: smaller than its own by 1 + the two looked-up limbs
+            d["p%d" % k] = 5 * col("cycle") + STAMP[key] - 1 - col("dl%d" % k) - 65536 * col("dh%d" % k)
+    return _DERIVED
+
+
 def c(name):
-    return LF.col(name)
+    return derived()[name] if name in derived() else LF.col(name)
 
 
 def mem_tuple(name, num, addr, lo, hi, ts, space):
@@ -248,7 +273,7 @@ def fractions():
     fin, k_nf = LF.glob(G_FIN), LF.glob(G_SEGNF)
     pv = lambda h: c("before_" + h) - fin * c("before_" + h) + fin * c("old_" + h)  # what a boundary row hands on: the last value, or -- closing -- the initial one
     session = [
-        session_tuple("session:consume", bnd, c("addr3"), c("after_lo"), c("after_hi"), c("p0")),          # (address, first value, the segment that left it)
+        session_tuple("session:consume", bnd, c("addr3"), c("after_lo"), c("after_hi"), LF.glob(G_SEG) - 1 - c("dl2")),  # (address, first value, the segment that left it: an EARLIER one, by a looked-up gap)
         session_tuple("session:produce", -bnd, c("addr3"), pv("lo"), pv("hi"), k_nf),                      # (address, last value, this segment) / (address, initial value, 0)
         session_tuple("session:image", c("fimg"), c("addr3"), c("old_lo"), c("old_hi"), TAG_IMG),           # an image word's initial value: the verifier holds the other side
         session_tuple("session:journal", c("cact"), c("addr3"), c("before_lo"), c("before_hi"), TAG_JRN),   # a journal word: likewise
@@ -288,7 +313,14 @@ def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
             b.taps.add((g, cc, 0))
     cons = []
 
+    memo = {}
+
     def d(name, back=0):
+        if name in derived():
+            assert back == 0, name
+            if name not in memo:
+                memo[name] = derived()[name].expr(b, E)
+            return memo[name]
         return E(b, b.get(G_DATA, COL[name], back), 1)
 
     def C(name, e, accum=False):
@@ -330,11 +362,9 @@ def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
     opc = {name: d("opc_" + name) for name, _ in OPCODES}
     for name, v in opc.items():
         bit(v, "opc_" + name)
-    C("opc:one", lin(b, [(1, v) for v in opc.values()]) - live)
     f3 = [d("f3_%d" % k) for k in range(8)]
     for k, v in enumerate(f3):
         bit(v, "f3_%d" % k)
-    C("f3:one", lin(b, [(1, v) for v in f3]) - 1)
     b25, b30, b31, f7A, f7B = d("b25"), d("b30"), d("b31"), d("f7A"), d("f7B")
     bit12, bit13, bit14 = df["bit12"], df["bit13"], df["bit14"]
     alu, mext = d("alu"), opc["op"] * b25
@@ -372,7 +402,6 @@ def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
         bit(sh[k], "sh%d" % k)
     digit(d("vrd"), "vrd")
     bit(d("vrb"), "vrb")
-    C("v0:bits", vb[0] - lin(b, [(1 << k, sh[k]) for k in range(5)]) - 32 * d("vrd") - 128 * d("vrb"))
     z, w = [d("z_lo"), d("z_hi")], [d("w_lo"), d("w_hi")]
     a = [d("rs1_lo"), d("rs1_hi")]
     rs2 = [d("rs2_lo"), d("rs2_hi")]
@@ -389,7 +418,6 @@ def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
     c0, c1, lt, eq, zinv, ob0, ob1 = d("c0"), d("c1"), d("lt"), d("eq"), d("zinv"), d("ob0"), d("ob1")
     for nm, x in (("c0", c0), ("c1", c1), ("lt", lt), ("eq", eq), ("ob0", ob0), ("ob1", ob1)):
         bit(x, nm)
-    C("z:low_bits", z[0] - ob0 - 2 * ob1 - 4 * d("zq"))
     # the zero test looks at Z; on a division row at the divisor; on an ecall row at the register it counts down
     zero_of = z[0] + z[1] + isdiv * (v[0] + v[1] - z[0] - z[1]) + sys_ * (old[0] + old[1] - z[0] - z[1])
     C("eq:zero", eq * zero_of)
@@ -548,20 +576,15 @@ def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
     C("div:less_hi", cmp * (w[1] + (1 - 2 * sr) * z[1] - (1 - 2 * sb_) * v[1] - 65536 * (sb_ - sr) + k0))
     # --- the five accesses.  Timestamp of an access of cycle c: 5 c + (1 fetch, 2 x[rs1], 3 x[rs2], 4 x[rd], 5 memory): larger than
     # the one it consumes by 1 + a 16-bit and an 8-bit limb (both looked up).  The tuples themselves are fractions of the running sum
-    def ordered(name, act, k, key):
-        C("ordered:" + name, act * (5 * cycle + STAMP[key] - d("p%d" % k) - 1 - dl[k] - 65536 * dh[k]))
-
-    ordered("rs1", live, 0, "rs1")
-    ordered("rs2", live, 1, "rs2")
+    # (accesses 0, 1, 2 and 4 have no column for the consumed timestamp: it IS own - 1 - the limbs; access 3 keeps one, a boundary
+    # row's consumed timestamp being free)
     act2, zrd = d("act2"), d("zrd")
     bit(act2, "act2")
     C("rd:zero", zrd * df["rd"])
     C("rd:inv", df["rd"] * d("inv_rd") - (1 - zrd))
     writes = opc["lui"] + opc["auipc"] + link + opc["load"] + opc["imm"] + opc["op"]
     C("rd:act", (1 - sys_) * (act2 - writes * (1 - zrd)))              # an instruction with a destination other than x0 writes it
-    ordered("rd", act2, 2, "rd")
-    ordered("mem", mem_act, 3, "mem")
-    ordered("fetch", live, 4, "fetch")
+    C("ordered:mem", mem_act * (5 * cycle + STAMP["mem"] - d("p3") - 1 - dl[3] - 65536 * dh[3]))
     keeps = 1 - mem_wr - bnd                                            # the word stays as it was unless written (or a boundary row)
     C("mem:keeps_lo", keeps * (after[0] - before[0]))
     C("mem:keeps_hi", keeps * (after[1] - before[1]))
@@ -575,7 +598,6 @@ def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
     C("ecall:fn_hi", sys_ * a[1])
     C("ecall:fn_max", sys_ * f2 * (f0 + f1))
     C("ecall:fn_idle", (1 - sys_) * (f0 + f1 + f2))
-    C("ecall:io", io - sys_ * (f0 + f1 - 2 * f0 * f1) * (1 - f2))
     C("ecall:cycles", fn_cyc - sys_ * f0 * f1)
     active = io * (1 - eq)                                              # eq: a1 = 0
     C("ecall:commit", cact - active * f1)
@@ -595,7 +617,6 @@ def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
     C("bnd:reg_lo", bnd * top * (dh[0] - 8 * dl[0]))
     gap = d("addr3") - d("addr3", 1) - 1 - w[0] - 65536 * w[1]
     C("bnd:order", not_first * bnd * prev_bnd * gap)
-    C("bnd:prev_seg", bnd * (gl(G_SEG) - d("p0") - 1 - dl[2]))
     fimg = d("fimg")
     bit(fimg, "fimg")
     C("fimg:bnd", (1 - bnd) * fimg)
