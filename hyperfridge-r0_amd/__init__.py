@@ -75,6 +75,8 @@ _SIGNATURES = {
     "r0h_witgen": [_vp, _vp, _u32, _u64, _vp, _vp, _vp],
     "r0h_witgen_public": [_vp, _vp, _u32, _u64, _vp, _vp, _vp],
     "r0h_seal_digest": [_vp, _sz, _vp],
+    "r0h_ctx_set_session_resident_limit": [_vp, _u64],
+    "r0h_proof_shrink": [_vp, _vp],
     "r0h_sponge_trace": [_vp, _sz, _u32, _vp],
     "r0h_accum": [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
     "r0h_eval_check": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -667,7 +669,7 @@ class PreflightRow(ctypes.Structure):
 
 
 class SessionStats(ctypes.Structure):
-    _fields_ = [("segments", _u32), ("cycles", _u64), ("executor_s", _c.c_double), ("witgen_ms", _c.c_double), ("prove_ms", _c.c_double), ("wall_s", _c.c_double)]
+    _fields_ = [("segments", _u32), ("lean_segments", _u32), ("cycles", _u64), ("executor_s", _c.c_double), ("witgen_ms", _c.c_double), ("prove_ms", _c.c_double), ("wall_s", _c.c_double)]
 
 
 class PreflightBound(ctypes.Structure):
@@ -1324,6 +1326,11 @@ class Hal:
         h = _vp()
         _check(lib().r0h_session_begin(self.ctx, circuit.handle, elf, len(elf), pw, len(input_words), segment_po2, max_cycles, part, parts, ctypes.byref(h)))
         return Session(h)
+
+    def set_session_resident_limit(self, n_bytes):
+        """bytes of committed DATA evaluations a session on this context keeps between its phases (r0h_ctx_set_session_resident_limit;
+        0 = an eighth of the device's memory); segments beyond it are evaluated again when their proofs are finished -- same seals"""
+        _check(lib().r0h_ctx_set_session_resident_limit(self.ctx, n_bytes))
 
     def last_session_stats(self):
         """Stage timing of the last prove_elf on this context (r0h_last_session_stats)."""

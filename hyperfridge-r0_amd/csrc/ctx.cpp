@@ -426,6 +426,11 @@ const char* r0h_buf_zero(r0h_ctx* ctx, r0h_buf* buf) {
   return nullptr;
 }
 
+const char* r0h_ctx_set_session_resident_limit(r0h_ctx* ctx, uint64_t bytes) {
+  R0H_REQUIRE(ctx, "r0h_ctx_set_session_resident_limit: ctx is NULL");
+  ctx->session_resident_limit = bytes;
+  return nullptr;
+}
 const char* r0h_kernel_timing(r0h_ctx* ctx, int enable) {
   R0H_REQUIRE(ctx, "r0h_kernel_timing: ctx is NULL");
   R0H_TRY_HIP(hipStreamSynchronize(ctx->stream));

@@ -343,6 +343,12 @@ static const char* proof_finish(r0h_proof& st, const r0h_buf* accum, std::vector
   Group* grp[3] = {&g_accum, &g_code, &g_data};
   const std::vector<uint32_t>& mix = st.mix;
   const uint32_t* global = st.global.data();
+  if (!g_data.evaluated) {  // r0h_proof_shrink gave the evaluations back: the same expanding NTT over the kept coefficients
+    phase(ctx, "evaluate_data_again");
+    R0H_TRY(sc.alloc(ctx, ((size_t)g_data.count << (po2 + 2)) * 4, &g_data.evaluated));
+    R0H_TRY(r0h_batch_expand_into_evaluate_ntt(ctx, g_data.evaluated, g_data.coeffs, g_data.count, po2, 2));
+    g_data.tree.matrix = g_data.evaluated;
+  }
   phase(ctx, "commit_accum");
   R0H_TRY(group_from_witness(ctx, sc, g_accum, accum, po2));
   R0H_TRY(tree_commit(ctx, g_accum.tree, io));
@@ -729,6 +735,30 @@ const char* r0h_proof_globals(const r0h_proof* proof, uint32_t* globals_out) {
 const char* r0h_proof_abort(r0h_proof* proof) {
   delete proof;
   return nullptr;
+}
+// Give back the DATA group's evaluations on the 4N coset (4/5 of what a proof holds between its phases): the commitment -- the Merkle
+// nodes -- and the coefficients stay, r0h_proof_finish evaluates again (the same words: one expanding NTT).
+const char* r0h_proof_shrink(r0h_proof* proof, size_t* bytes_freed_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(proof, "r0h_proof_shrink: NULL argument");
+  size_t freed = 0;
+  if (proof->g_data.evaluated) {
+    R0H_TRY_HIP(hipSetDevice(proof->ctx->device));
+    R0H_TRY_HIP(hipStreamSynchronize(proof->ctx->stream));  // the block goes back to the pool: nothing in flight may still read it
+    freed = proof->g_data.evaluated->bytes;
+    proof->sc.release(proof->g_data.evaluated);
+    proof->g_data.evaluated = nullptr;
+    proof->g_data.tree.matrix = nullptr;
+  }
+  if (bytes_freed_out) *bytes_freed_out = freed;
+  return nullptr;
+  R0H_GUARD_END
+}
+size_t r0h_proof_resident_bytes(const r0h_proof* proof) {
+  if (!proof) return 0;
+  size_t total = 0;
+  for (const r0h_buf* b : proof->sc.bufs) total += b->bytes;
+  return total;
 }
 
 // The control root of a program at one trace size: the Merkle root of its committed CODE group (risc0 keeps one such root per

@@ -157,7 +157,8 @@ struct r0h_session {
   std::vector<uint8_t> journal;
   uint8_t image_id[32] = {0};
   uint64_t cycles = 0;
-  r0h_session_stats stats = {0, 0, 0, 0, 0, 0};
+  r0h_session_stats stats = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t resident_limit = 0, resident_evaluations = 0;  // bytes of DATA evaluations kept between the phases (r0h_ctx_set_session_resident_limit)
   Clock::time_point t_begin;
   std::vector<r0h_ctx*> lane_ctx;
   ~r0h_session() {
@@ -209,6 +210,13 @@ const char* r0h_session_begin(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t*
   ses->part = part;
   ses->parts = parts;
   ses->t_begin = Clock::now();
+  ses->resident_limit = ctx->session_resident_limit;
+  if (!ses->resident_limit) {
+    size_t free_b = 0, total_b = 0;
+    R0H_TRY_HIP(hipSetDevice(ctx->device));
+    R0H_TRY_HIP(hipMemGetInfo(&free_b, &total_b));
+    ses->resident_limit = total_b / 8;  // 36 GB of 288: 17 segments of 2^20 rows; the camt53 stand-in's 12 stay whole, the reference's 37 do not
+  }
   r0h_session_stats& stats = ses->stats;
   r0h_vm* vm = nullptr;
   R0H_TRY(r0h_vm_new(&vm));
@@ -415,6 +423,17 @@ const char* r0h_session_begin(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t*
         R0H_TRY(r0h_proof_begin_committed(lctx, c, po2, cc, data, global.data(), nullptr, &pend.proof));
         struct Abort { r0h_proof*& p; bool armed; ~Abort() { if (armed && p) { r0h_proof_abort(p); p = nullptr; } } } abort_guard{pend.proof, true};
         R0H_TRY(r0h_proof_data_root(pend.proof, pend.root));
+        {  // beyond the session's resident limit a segment waits for the challenge without its evaluations
+          const uint64_t evaluations = (uint64_t)c->group_size[R0H_GROUP_DATA] * n * 16;
+          bool lean;
+          {
+            std::lock_guard<std::mutex> lk(result_mu);
+            lean = ses->resident_evaluations + evaluations > ses->resident_limit;
+            if (lean) stats.lean_segments++;
+            else ses->resident_evaluations += evaluations;
+          }
+          if (lean) R0H_TRY(r0h_proof_shrink(pend.proof, nullptr));
+        }
         const Clock::time_point t2 = Clock::now();
         pend.global = global;
         pend.data = data;

@@ -162,6 +162,12 @@ const char* r0h_proof_begin(r0h_ctx* ctx, const r0h_circuit* c, uint32_t po2, co
 const char* r0h_proof_finish(r0h_proof* proof, const r0h_buf* accum, uint32_t* seal_out, size_t seal_capacity_words,
                              size_t* seal_words_out);
 const char* r0h_proof_abort(r0h_proof* proof);
+/* A proof waiting between its phases holds its DATA group three ways: coefficients, evaluations on the 4N coset (4/5 of the bytes:
+ * 2 GiB for 128 columns of 2^20 rows) and Merkle nodes.  r0h_proof_shrink gives the evaluations back to the context's pool;
+ * r0h_proof_finish computes them again from the coefficients (one expanding NTT, the same words: the seal does not change).  A
+ * session does this by itself for the segments beyond its resident limit (r0h_ctx_set_session_resident_limit). */
+const char* r0h_proof_shrink(r0h_proof* proof, size_t* bytes_freed_out);
+size_t r0h_proof_resident_bytes(const r0h_proof* proof);
 /* Late public inputs (blob section LATE: inputs that depend on commitments made outside this proof -- the trace circuit's session
  * challenge, derived from the DATA roots of ALL segments, and the segment's sum under it).  For such a circuit r0h_proof_begin stops
  * after the DATA commitment without drawing the mix: r0h_proof_data_root gives the root, r0h_proof_late takes the last n_late
@@ -575,6 +581,11 @@ const char* r0h_vm_segment_claim(const r0h_vm* vm, size_t i, r0h_receipt_claim* 
  * and the guest runs ahead on its own thread while the device proves.  With any other circuit the witness is that circuit's
  * synthetic column program with the claim planted (the seal then proves only that a satisfying trace naming the claim exists). ---- */
 #define R0H_DEFAULT_SESSION_LIMIT ((uint64_t)1 << 32)
+/* How many bytes of committed DATA evaluations the sessions begun on this context keep on the device between their two phases; the
+ * segments beyond it keep coefficients and Merkle nodes only (0.6 instead of 2.7 GiB per 2^20-row segment) and are evaluated again
+ * when their proofs are finished (about 2 ms each).  0 = the default: an eighth of the device's memory.  The reference's own run is
+ * 37 segments (docs/runtime.md: session_cycles = 39,265,237): 100 GiB resident without a limit, per session in flight. */
+const char* r0h_ctx_set_session_resident_limit(r0h_ctx* ctx, uint64_t bytes);
 const char* r0h_prove_elf(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* elf, size_t elf_len, const uint32_t* input_words,
                           size_t n_input, uint32_t segment_po2, uint64_t max_cycles, r0h_receipt** receipt_out,
                           uint8_t image_id_out[32], uint64_t* cycles_out);
@@ -607,7 +618,7 @@ const char* r0h_session_free(r0h_session* s);
  * segment index missing or present twice, journals that differ, a receipt that is not composite. */
 const char* r0h_receipt_merge(const r0h_receipt* const* parts, size_t n, r0h_receipt** out);
 /* per-stage timing of the last r0h_prove_elf on this context (for tools/bench_session.py): names are static strings */
-typedef struct { uint32_t segments; uint64_t cycles; double executor_s, witgen_ms, prove_ms, wall_s; } r0h_session_stats;
+typedef struct { uint32_t segments, lean_segments /* proved without resident evaluations: r0h_ctx_set_session_resident_limit */; uint64_t cycles; double executor_s, witgen_ms, prove_ms, wall_s; } r0h_session_stats;
 const char* r0h_last_session_stats(r0h_ctx* ctx, r0h_session_stats* out);
 
 /* ---- recursion: risc0-zkvm `ProverServer::{lift, join}` (risc0-circuit-recursion 4.0.4, Cargo.lock:3050-3085; BASELINE.json

@@ -151,6 +151,14 @@ def test_prove_elf_with_the_trace_circuit_proves_the_run_it_executed(hal, orc):
     assert len(seals) == len(segs) >= 6 and stats["segments"] == len(segs) and stats["cycles"] == cycles
     want_json = template[:off] + b"%08x" % checksum(frames) + template[off + 8:]
     assert r0.journal_commitment(receipt.journal) == want_json
+    assert stats["lean_segments"] == 0
+    # the same session with (almost) nothing kept between the phases: all but the first segment give their evaluations back after the
+    # commitment and are evaluated again when the challenge is known -- the seals are the same words
+    hal.set_session_resident_limit(r0.TRACE_COLUMNS * (16 << r0.TRACE_MIN_PO2))
+    lean, _, _ = hal.prove_elf(gc, elf, stream, segment_po2=po2)
+    assert hal.last_session_stats()["lean_segments"] == len(segs) - 1
+    hal.set_session_resident_limit(0)
+    assert all(ia == ib and np.array_equal(a, b) for (ia, a), (ib, b) in zip(lean.seals(), seals)) and lean.journal == receipt.journal
     size = r0.TRACE_MIN_PO2
     cc = hal.code_commit(gc, size)
     roots, ocode = {size: cc.root()}, c.witgen(size, 0)[0]

@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--oracle-check", type=int, default=1, help="verify this many seals with the CPU oracle's verifier as well")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="all ranks on GPU 0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--sessions", type=int, default=1, help="sessions in flight on this GPU, each on a context of its own (single rank only)")
+    ap.add_argument("--resident-limit-gb", type=float, default=-1.0, help="r0h_ctx_set_session_resident_limit per session context (default: the library's, an eighth of the device)")
     args = ap.parse_args()
     world, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     import __graft_entry__ as entry
@@ -88,11 +90,42 @@ def main():
     blob = np.fromfile(entry.circuit_blob_path("trace"), dtype=np.uint32)
     hal = r0.Hal(0 if (env is None or args.share_device) else local)
     gc = hal.load_circuit(blob, entry.code_object_path("trace"))
+    if args.resident_limit_gb >= 0:
+        hal.set_session_resident_limit(int(args.resident_limit_gb * (1 << 30)))
+    others = []  # further sessions in flight beside this one: a context and a loaded circuit each
+    if env is None and args.sessions > 1:
+        import threading
+        for _ in range(args.sessions - 1):
+            h2 = r0.Hal(0)
+            if args.resident_limit_gb >= 0:
+                h2.set_session_resident_limit(int(args.resident_limit_gb * (1 << 30)))
+            others.append((h2, h2.load_circuit(blob, entry.code_object_path("trace"))))
+    peak_used = 0
     for _ in range(max(1, args.repeat)):
         if env is not None:
             env.barrier()
         t0 = time.perf_counter()
-        if env is None:
+        if env is None and others:
+            import torch  # (only to read the device's free memory while the sessions run)
+            results, stop = [None] * len(others), threading.Event()
+
+            def side(i):
+                results[i] = others[i][0].prove_elf(others[i][1], elf, stream, segment_po2=args.po2)
+
+            def watch():
+                nonlocal peak_used
+                while not stop.wait(0.02):
+                    free_b, total_b = torch.cuda.mem_get_info(0)
+                    peak_used = max(peak_used, total_b - free_b)
+
+            threads = [threading.Thread(target=side, args=(i,)) for i in range(len(others))] + [threading.Thread(target=watch)]
+            [t.start() for t in threads]
+            receipt, image_id, cycles = hal.prove_elf(gc, elf, stream, segment_po2=args.po2)
+            [t.join() for t in threads[:-1]]
+            stop.set()
+            threads[-1].join()
+            assert all(r is not None and r[0].journal == receipt.journal for r in results)
+        elif env is None:
             receipt, image_id, cycles = hal.prove_elf(gc, elf, stream, segment_po2=args.po2)
         else:
             receipt, image_id, cycles = driver.prove_elf_sharded(env, hal, gc, elf, stream, segment_po2=args.po2)
@@ -119,9 +152,10 @@ def main():
         oc = orc_binding.load().circuit(blob)
         for _, seal in seals[:args.oracle_check]:
             assert oc.verify(seal, code_root=roots[r0.verify_seal(blob, seal)[2]]) == (0, "ok")
-    n = len(seals)
-    line = {"metric": "segments/s of prove(env, elf) with the trace circuit: executor + device witgen + proof, all inside the timed region",
-            "value": round(n / wall, 4), "unit": "segments/s", "n_gpus": world, "sharding": None if env is None else "segments rank, rank + %d, ... per rank (%s%s); receipts merged on rank 0" % (world, args.backend, ", all ranks on one GPU" if args.share_device else ""), "segment_po2": args.po2, "segments": n, "cycles": cycles,
+    n = len(seals) * max(1, args.sessions if env is None else 1)
+    line = {"sessions_in_flight": args.sessions if env is None else 1, "lean_segments_of_the_reported_session": st["lean_segments"],
+            "peak_device_memory_used_GiB": round(peak_used / (1 << 30), 1) if peak_used else None, "metric": "segments/s of prove(env, elf) with the trace circuit: executor + device witgen + proof, all inside the timed region",
+            "value": round(n / wall, 4), "unit": "segments/s", "n_gpus": world, "sharding": None if env is None else "segments rank, rank + %d, ... per rank (%s%s); receipts merged on rank 0" % (world, args.backend, ", all ranks on one GPU" if args.share_device else ""), "segment_po2": args.po2, "segments": len(seals), "cycles": cycles,
             "wall_s": round(wall, 4), "guest": what,
             "executor": {"host_s": round(st["executor_s"], 4), "MHz_with_trace_kept": round(cycles / st["executor_s"] / 1e6, 2), "host_ms_per_segment": round(1e3 * st["executor_s"] / max(1, st["segments"]), 3),
                          "note": "own host thread, overlaps the device work of the previous segment"},
