@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Development check of the v4 trace circuit on the device (run under gpurun): device witness == host witness, device totals and
+"""Development check of the trace circuit on the device (run under gpurun): device witness == host witness, device totals and
 seal == the oracle's, a camt53 session proved in two phases and verified with the ELF, wrong ELF refused, timing.
-usage: python tools/dev_v4_gpu.py [--skip-session] [--po2 20]"""
+usage: python tools/dev_trace_gpu.py [--skip-session] [--po2 20]"""
 import argparse
 import json
 import os
@@ -120,7 +120,7 @@ def main():
         print("closing flags:", [int(orc.dec(int(s[16]))) for _, s in seals], "cycles:", [int(orc.dec(int(s[10]))) for _, s in seals])
     gc.free()
     hal.close()
-    print("dev_v4_gpu ok")
+    print("dev_trace_gpu ok")
 
 
 if __name__ == "__main__":
