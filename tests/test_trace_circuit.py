@@ -1,4 +1,4 @@
-"""The trace circuit (tools/trace_circuit.py, circuits/trace.r0c, version 4): a circuit whose DATA group IS the executor's preflight
+"""The trace circuit (tools/trace_circuit.py, circuits/trace.r0c, version 5): a circuit whose DATA group IS the executor's preflight
 trace -- what the prover commits to comes from an execution, not from a synthetic column program.
 It constrains that the cycles form one contiguous run from the public first pc to the public last pc in the public number of
 cycles, WHAT EVERY INSTRUCTION DOES (decode, ALU / shifter / multiplier results, branch decisions, jump targets, load / store
