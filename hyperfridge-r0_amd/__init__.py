@@ -206,6 +206,7 @@ _PLAIN = {
     "r0h_buf_bytes": ([_vp], _sz),
     "r0h_circuit_group_size": ([_vp, _u32], _u32),
     "r0h_circuit_n_global": ([_vp], _u32),
+    "r0h_proof_resident_bytes": ([_vp], _sz),
     "r0h_circuit_n_mix": ([_vp], _u32),
     "r0h_circuit_n_taps": ([_vp], _u32),
 }

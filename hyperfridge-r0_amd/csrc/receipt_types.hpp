@@ -46,5 +46,7 @@ void claim_globals(const uint8_t digest[32], uint32_t out[8]);
 bool is_trace_circuit(const r0h_circuit& circ);
 bool trace_seal_carries_claim(const uint32_t* seal, const r0h_receipt_claim& claim);
 void session_challenge(const uint32_t* records, size_t n_records, uint32_t out[16]);
+void image_stream(const std::vector<std::pair<uint32_t, uint32_t>>& image, std::vector<uint32_t>& words_out);  // rv32im.cpp: the image circuit's sponge blocks (Montgomery)
+void image_digest(const std::vector<std::pair<uint32_t, uint32_t>>& image, uint32_t digest_out[8]);             // ... and their digest: the root of the initial memory state
 const char* elf_image(const uint8_t* elf, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& image, uint32_t* entry, uint8_t image_id[32]);  // rv32im.cpp
 }  // namespace r0h

@@ -196,6 +196,21 @@ void sort_image(r0h_vm& vm) {
   vm.image_sorted = true;
 }
 
+// The root of the memory a run starts from -- what the image id names -- is not the page tree's: it is the Poseidon2 digest of the
+// image as the list of its words in address order (tools/image_circuit.py: blocks of four (word index, low half, high half) and a
+// mask), which the image circuit ties to the image's side of the session's memory argument.  A machine that has already run
+// (resumed after a PAUSE) starts from the page tree's root like any later segment.
+void initial_root(r0h_vm& vm, uint8_t out[32]) {
+  if (vm.cycles) { memory_root(vm, out); return; }
+  sort_image(vm);
+  uint32_t digest[8];
+  r0h::image_digest(vm.image, digest);
+  for (int i = 0; i < 8; i++) {
+    const uint32_t w = r0h::dec(digest[i]);
+    for (int b = 0; b < 4; b++) out[4 * i + b] = (uint8_t)(w >> (8 * b));
+  }
+}
+
 struct Touched { uint32_t addr, first_value, prev_seg; };
 inline bool operator<(const Touched& a, const Touched& b) { return a.addr < b.addr; }
 
@@ -225,7 +240,7 @@ struct Run {
     memset(&cur.info, 0, sizeof cur.info);
     cur.info.index = (uint32_t)vm.segments.size();
     cur.info.pre.pc = vm.pc;
-    if (!have_root) { memory_root(vm, root_now); have_root = true; }
+    if (!have_root) { initial_root(vm, root_now); have_root = true; }
     memcpy(cur.info.pre.merkle_root, root_now, 32);
     epoch = cur.info.index + 1;
     n_in = n_out = 0;
@@ -745,7 +760,7 @@ const char* r0h_compute_image_id(const uint8_t* elf, size_t n, uint8_t image_id_
   r0h_system_state st;
   memset(&st, 0, sizeof st);
   st.pc = vm->pc;
-  memory_root(*vm, st.merkle_root);
+  initial_root(*vm, st.merkle_root);
   system_state_digest(st, image_id_out);
   return nullptr;
   R0H_GUARD_END
@@ -814,6 +829,26 @@ const char* r0h_vm_run(r0h_vm* vm, const r0h_vm_limits* limits, int* exit_kind, 
 
 }  // extern "C"
 namespace r0h {
+// the sponge's blocks for an image (tools/image_circuit.py `blocks`), Montgomery words: 16 per block
+void image_stream(const std::vector<std::pair<uint32_t, uint32_t>>& image, std::vector<uint32_t>& out) {
+  const size_t n_blocks = image.empty() ? 1 : (image.size() + 3) / 4;
+  out.assign(16 * n_blocks, 0u);
+  for (size_t k = 0; k < image.size(); k++) {
+    uint32_t* blk = &out[16 * (k / 4)];
+    const size_t j = k % 4;
+    blk[3 * j] = enc(image[k].first);
+    blk[3 * j + 1] = enc(image[k].second & 0xffffu);
+    blk[3 * j + 2] = enc(image[k].second >> 16);
+    blk[12] = enc((2u << j) - 1u);  // the tuples there are a prefix of the block: the mask of the last one written stands
+  }
+}
+void image_digest(const std::vector<std::pair<uint32_t, uint32_t>>& image, uint32_t digest[8]) {
+  std::vector<uint32_t> stream;
+  image_stream(image, stream);
+  std::unique_ptr<P2Consts> k(new P2Consts);
+  p2_default_host(*k);
+  p2_hash_elems_host(*k, stream.data(), stream.size(), digest);
+}
 // what a verifier needs of an ELF: the image as (word index, word) in address order, the entry point, the image id
 const char* elf_image(const uint8_t* elf, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& image, uint32_t* entry, uint8_t image_id[32]) {
   r0h_vm* vm = nullptr;
@@ -826,7 +861,7 @@ const char* elf_image(const uint8_t* elf, size_t n, std::vector<std::pair<uint32
   r0h_system_state st;
   memset(&st, 0, sizeof st);
   st.pc = vm->pc;
-  memory_root(*vm, st.merkle_root);
+  initial_root(*vm, st.merkle_root);
   system_state_digest(st, image_id);
   return nullptr;
 }

@@ -4,12 +4,16 @@ against an independent interpreter written here in Python from the RISC-V specif
 page Merkle root are this library's own (documented in the source) and are checked for self-consistency: segments chain, the
 claims they yield verify as a receipt's claims do, the trace replays."""
 import hashlib
+import os
 import struct
+import sys
 
 import numpy as np
 import pytest
 
 import hyperfridge_r0_amd as r0
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 M32 = 0xFFFFFFFF
 
@@ -279,7 +283,13 @@ def test_segmenter_cuts_a_run_and_the_claims_chain_like_a_receipts(orc):
     for level in range(22):
         h = hashlib.sha256((z + h) if (idx >> level) & 1 else (h + z)).digest()
         z = hashlib.sha256(z + z).digest()
-    assert bytes(tiny.segments()[0].pre.merkle_root) == h
+    assert bytes(tiny.segments()[0].post.merkle_root) == h  # (the run stores nothing: the state it leaves has the image's pages)
+    # ... and the root of the state a run STARTS from -- what the image id names -- is the Poseidon2 digest of the image's word list
+    # (tools/image_circuit.py: the form the image circuit can tie to the session's memory argument), restated there in Python
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import image_circuit
+    _, digest = image_circuit.witness([(0x800 // 4, ADDI(A7, 0, 0)), (0x800 // 4 + 1, ECALL)], 64)
+    assert bytes(tiny.segments()[0].pre.merkle_root) == b"".join(int(w).to_bytes(4, "little") for w in digest)
     # the claims of the run are what a composite receipt carries: prove each segment for its claim (CPU oracle) and verify the receipt
     claims = vm.claims()
     assert claims[-1].digest() != claims[0].digest() and bytes(claims[-1].output_digest) == r0.output_digest(vm.journal)

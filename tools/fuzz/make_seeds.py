@@ -50,6 +50,10 @@ def main():
         print("no composite receipt seed:", e)
     put("seal", 6, seal.tobytes())
     put("circuit", 7, rd(ROOT, "circuits", "tiny.r0c"))
+    for name in ("recursion", "trace"):  # the sections only these carry: PERIODIC / SPONGE, LATE / LOGUP
+        path = os.path.join(ROOT, "circuits", name + ".r0c")
+        if os.path.exists(path):
+            put("circuit_" + name, 7, open(path, "rb").read())
     put("seal_edit", 8, struct.pack("<II", 1000, 12345))
     put("seal_cut", 8, struct.pack("<IIB", 7, 7, 3))
     print("seeds written to", out)

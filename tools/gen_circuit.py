@@ -15,7 +15,8 @@ Shapes:
   recursion  W=(24, 36, 161), 16 public inputs  the second circuit of SURVEY.md 8(a) a19 (lift/join at po2 = 18): the synthetic columns of
                                             W=(24, 8, 96) plus the Poseidon2 sponge component (tools/sponge_component.py) that computes the digest
                                             of what a node consumed -- public inputs 8..15 -- in-circuit
-  trace  W=(40, 6, 138)                     columns = the executor's preflight rows (tools/trace_circuit.py): one contiguous run, every instruction's
+  image  W=(8, 30, 69)                      the program image's digest tied to its side of a session's memory argument (tools/image_circuit.py)
+  trace  W=(40, 6, 128)                     columns = the executor's preflight rows (tools/trace_circuit.py): one contiguous run, every instruction's
                                             semantics, memory consistency, lookups, the session-wide memory argument
 """
 import argparse
@@ -449,12 +450,17 @@ SHAPES = {
 }
 
 
+def generate_image():
+    import image_circuit
+    return image_circuit.generate(Builder, E, fp4_mul_sym, OP_GET)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("shape", choices=sorted(SHAPES) + ["trace"])
+    ap.add_argument("shape", choices=sorted(SHAPES) + ["trace", "image"])
     ap.add_argument("out")
     args = ap.parse_args()
-    words, info = generate_trace() if args.shape == "trace" else generate(**SHAPES[args.shape])
+    words, info = generate_trace() if args.shape == "trace" else generate_image() if args.shape == "image" else generate(**SHAPES[args.shape])
     with open(args.out, "wb") as f:
         f.write(struct.pack("<%dI" % len(words), *words))
     print(args.shape, info, "words", len(words))

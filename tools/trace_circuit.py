@@ -304,6 +304,61 @@ def logup_section():
     return words
 
 
+def accum_constraints(b, E, fp4_mul_sym, accs, first, cons):
+    """The running sums of a log-derivative argument as constraints (appended to `cons`): accumulator j of a row adds its four
+    fractions to accumulator j - 1 of the same row, the first one to the last one of the row before -- around the end of the trace as
+    well, so the chain's total is zero; an accumulator with a public total runs on its own and wraps with that total.
+    accs: [(four Fractions, None | index of the first of the 4 public inputs its total is)]; first: the first-row indicator (an E)."""
+    n_chain = sum(1 for _, fin in accs if fin is None)
+
+    def ch_vars(ch):
+        if ch[0] == "mix":
+            return [b.glob(1, 4 * ch[1] + i) for i in range(4)]
+        if ch[0] == "glob":
+            return [b.glob(0, ch[1] + i) for i in range(4)]
+        return None
+
+    def fp4_scale(x, e):  # Fp4 (list of 4 fp vars) times a base expression
+        return list(x) if e.k == 1 else [b.mul(xi, e.v) for xi in x]
+
+    def fp4_add(x, y):
+        return [b.add(xi, yi) for xi, yi in zip(x, y)]
+
+    for j, (fr, final) in enumerate(accs):
+        dens, nums = [], []
+        for f in fr:
+            den = None
+            for ch, lf in f.parts:
+                e = lf.expr(b, E)
+                cv = ch_vars(ch)
+                if cv is None:
+                    part = [e.v, None, None, None]
+                else:
+                    part = [b.mul(x, e.v) if e.k != 1 else x for x in cv]
+                if den is None:
+                    den = [p_ if p_ is not None else b.const(0) for p_ in part]
+                else:
+                    den = [b.add(dq, pq) if pq is not None else dq for dq, pq in zip(den, part)]
+            dens.append(den)
+            nums.append(f.num.expr(b, E))
+        assert len(dens) == 4
+        d01, d23 = fp4_mul_sym(b, dens[0], dens[1]), fp4_mul_sym(b, dens[2], dens[3])
+        big = fp4_mul_sym(b, d01, d23)
+        n01 = fp4_add(fp4_scale(dens[1], nums[0]), fp4_scale(dens[0], nums[1]))   # n0 d1 + n1 d0
+        n23 = fp4_add(fp4_scale(dens[3], nums[2]), fp4_scale(dens[2], nums[3]))
+        numer = fp4_add(fp4_mul_sym(b, n01, d23), fp4_mul_sym(b, n23, d01))
+        cur = [b.get(G_ACCUM, 4 * j + i, 0) for i in range(4)]
+        if final is None:
+            prev = [b.get(G_ACCUM, 4 * (n_chain - 1) + i, 1) for i in range(4)] if j == 0 else [b.get(G_ACCUM, 4 * (j - 1) + i, 0) for i in range(4)]
+            diff = [b.sub(cur[i], prev[i]) for i in range(4)]
+        else:
+            prev = [b.get(G_ACCUM, 4 * j + i, 1) for i in range(4)]
+            diff = [b.add(b.sub(cur[i], prev[i]), b.mul(first.v, b.glob(0, final + i))) for i in range(4)]
+        lhs = fp4_mul_sym(b, diff, big)
+        for i in range(4):
+            cons.append(("accum:%d_%d" % (j, i), b.sub(lhs[i], numer[i]), 5, True))
+
+
 def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
     """-> (Builder, [(name, fp var, degree, touches ACCUM)]): every polynomial that must vanish on every row of a trace"""
     b = builder_cls()
@@ -649,59 +704,8 @@ def trace_constraints(builder_cls, E, lin, fp4_mul_sym):
         C("exit:%s_none" % tag, gate_ * (1 - gl(G_TERM)) * gl(G_KIND))
         C("exit:%s_lo" % tag, gate_ * (gl(G_TERM) * lo - gl(G_EXIT_LO)))
         C("exit:%s_hi" % tag, gate_ * (gl(G_TERM) * hi - gl(G_EXIT_HI)))
-    # --- the running sums: accumulator j of a row adds its (up to four) fractions to accumulator j - 1 of the same row, the first
-    # one to the last one of the row before -- around the end of the trace as well, so the chain's total is zero; the session
-    # accumulator runs on its own and wraps with its public total G_k
-    accs = accumulators()
-    n_chain = sum(1 for _, fin in accs if fin is None)
-
-    def ch_vars(ch):
-        if ch[0] == "mix":
-            return [b.glob(1, 4 * ch[1] + i) for i in range(4)]
-        if ch[0] == "glob":
-            return [b.glob(0, ch[1] + i) for i in range(4)]
-        return None
-
-    def fp4_scale(x, e):  # Fp4 (list of 4 fp vars) times a base expression
-        return list(x) if e.k == 1 else [b.mul(xi, e.v) for xi in x]
-
-    def fp4_add(x, y):
-        return [b.add(xi, yi) for xi, yi in zip(x, y)]
-
-    zero4 = None
-    for j, (fr, final) in enumerate(accs):
-        dens, nums = [], []
-        for f in fr:
-            den = None
-            for ch, lf in f.parts:
-                e = lf.expr(b, E)
-                cv = ch_vars(ch)
-                if cv is None:
-                    part = [e.v, None, None, None]
-                else:
-                    part = [b.mul(x, e.v) if e.k != 1 else x for x in cv]
-                if den is None:
-                    den = [p_ if p_ is not None else b.const(0) for p_ in part]
-                else:
-                    den = [b.add(dq, pq) if pq is not None else dq for dq, pq in zip(den, part)]
-            dens.append(den)
-            nums.append(f.num.expr(b, E))
-        assert len(dens) == 4
-        d01, d23 = fp4_mul_sym(b, dens[0], dens[1]), fp4_mul_sym(b, dens[2], dens[3])
-        big = fp4_mul_sym(b, d01, d23)
-        n01 = fp4_add(fp4_scale(dens[1], nums[0]), fp4_scale(dens[0], nums[1]))   # n0 d1 + n1 d0
-        n23 = fp4_add(fp4_scale(dens[3], nums[2]), fp4_scale(dens[2], nums[3]))
-        numer = fp4_add(fp4_mul_sym(b, n01, d23), fp4_mul_sym(b, n23, d01))
-        cur = [b.get(G_ACCUM, 4 * j + i, 0) for i in range(4)]
-        if final is None:
-            prev = [b.get(G_ACCUM, 4 * (n_chain - 1) + i, 1) for i in range(4)] if j == 0 else [b.get(G_ACCUM, 4 * (j - 1) + i, 0) for i in range(4)]
-            diff = [b.sub(cur[i], prev[i]) for i in range(4)]
-        else:
-            prev = [b.get(G_ACCUM, 4 * j + i, 1) for i in range(4)]
-            diff = [b.add(b.sub(cur[i], prev[i]), b.mul(first.v, b.glob(0, final + i))) for i in range(4)]
-        lhs = fp4_mul_sym(b, diff, big)
-        for i in range(4):
-            cons.append(("accum:%d_%d" % (j, i), b.sub(lhs[i], numer[i]), 5, True))
+    # --- the running sums
+    accum_constraints(b, E, fp4_mul_sym, accumulators(), first, cons)
     return b, cons
 
 
