@@ -78,6 +78,9 @@ _SIGNATURES = {
     "r0h_ctx_set_session_resident_limit": [_vp, _u64],
     "r0h_proof_shrink": [_vp, _vp],
     "r0h_sponge_trace": [_vp, _sz, _u32, _vp],
+    "r0h_image_po2": [_vp, _sz, _vp],
+    "r0h_image_witness": [_vp, _sz, _u32, _vp, _vp],
+    "r0h_prove_image": [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp],
     "r0h_accum": [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
     "r0h_eval_check": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "r0h_prove_segment": [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_sz)],
@@ -108,6 +111,10 @@ _SIGNATURES = {
     "r0h_receipt_segment_claim": [_vp, _sz, _vp, _c.POINTER(_c.c_int)],
     "r0h_receipt_verify": [_vp, _vp, _sz, _vp, _sz, _vp, _c.POINTER(_c.c_int), _c.POINTER(_sz), _c.POINTER(_c.c_int)],
     "r0h_receipt_verify_elf": [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _c.POINTER(_c.c_int), _c.POINTER(_sz), _c.POINTER(_c.c_int)],
+    "r0h_receipt_verify_image": [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _c.POINTER(_c.c_int), _c.POINTER(_sz), _c.POINTER(_c.c_int)],
+    "r0h_receipt_set_image_proof": [_vp, _vp, _sz],
+    "r0h_receipt_image_proof": [_vp, _c.POINTER(_vp), _c.POINTER(_sz)],
+    "r0h_ctx_set_image_circuit": [_vp, _vp],
     "r0h_sha256": [_vp, _sz, _vp],
     "r0h_image_id_from_hex": [_cp, _vp],
     "r0h_image_id_to_hex": [_vp, _vp],
@@ -448,6 +455,25 @@ def seal_digest(seal):
 
 
 SPONGE_DATA_COLUMNS = 65
+IMAGE_COLUMNS, IMAGE_GLOBALS, IMAGE_GAMMA, IMAGE_SUM = 69, 28, 8, 24  # R0H_IMAGE_*
+
+
+def image_po2(elf):
+    """smallest trace of the image circuit that holds the sponge over this ELF's words (r0h_image_po2)"""
+    buf = (ctypes.c_uint8 * len(elf)).from_buffer_copy(elf)
+    out = _u32(0)
+    _check(lib().r0h_image_po2(buf, len(elf), ctypes.byref(out)))
+    return out.value
+
+
+def image_witness(elf, po2=None):
+    """The image circuit's DATA group for an ELF and its public inputs with the digest filled in (r0h_image_witness):
+    ([IMAGE_COLUMNS][2^po2] Montgomery words, IMAGE_GLOBALS words)."""
+    po2 = image_po2(elf) if po2 is None else po2
+    buf = (ctypes.c_uint8 * len(elf)).from_buffer_copy(elf)
+    data, glob = np.zeros((IMAGE_COLUMNS, 1 << po2), dtype=np.uint32), np.zeros(IMAGE_GLOBALS, dtype=np.uint32)
+    _check(lib().r0h_image_witness(buf, len(elf), po2, data.ctypes.data_as(_vp), glob.ctypes.data_as(_vp)))
+    return data, glob
 
 
 def sponge_trace(words, po2):
@@ -976,6 +1002,35 @@ class Receipt:
                                             ctypes.byref(verdict), ctypes.byref(seg), ctypes.byref(sv)))
         return verdict.value, lib().r0h_receipt_verify_reason(verdict.value).decode(), seg.value, sv.value
 
+    def verify_image(self, blob, control_roots, image_blob, image_id, image_control_root=None):
+        """`receipt.verify(image_id)` for a trace-circuit session WITHOUT the ELF (r0h_receipt_verify_image): the receipt's image proof
+        stands for the program image.  -> (verdict, reason, segment at fault, seal verdict)"""
+        b, pb = _u32arr(blob)
+        ib, pib = _u32arr(image_blob)
+        table = np.zeros(max(1, len(control_roots)) * 9, dtype=np.uint32)
+        for k, (size, root) in enumerate(sorted(control_roots.items())):
+            table[9 * k] = size
+            table[9 * k + 1:9 * k + 9] = root
+        proot = None
+        if image_control_root is not None:
+            root, proot = _u32arr(image_control_root)
+        verdict, seg, sv = _c.c_int(-1), _sz(0), _c.c_int(0)
+        _check(lib().r0h_receipt_verify_image(self.handle, pb, b.size, table.ctypes.data_as(_vp), len(control_roots), pib, ib.size, proot,
+                                              None if image_id is None else bytes(image_id), ctypes.byref(verdict), ctypes.byref(seg), ctypes.byref(sv)))
+        return verdict.value, lib().r0h_receipt_verify_reason(verdict.value).decode(), seg.value, sv.value
+
+    @property
+    def image_proof(self):
+        """the image proof's seal (None when the receipt carries none)"""
+        p, n = _vp(), _sz(0)
+        _check(lib().r0h_receipt_image_proof(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        return np.frombuffer(ctypes.string_at(p, n.value * 4), dtype=np.uint32).copy() if n.value else None
+
+    @image_proof.setter
+    def image_proof(self, seal):
+        a, pa = _u32arr(seal if seal is not None else np.zeros(0, dtype=np.uint32))
+        _check(lib().r0h_receipt_set_image_proof(self.handle, pa, a.size))
+
     @property
     def kind(self):
         return "Fake" if lib().r0h_receipt_kind(self.handle) == 0 else "Composite"
@@ -1332,6 +1387,22 @@ class Hal:
         """bytes of committed DATA evaluations a session on this context keeps between its phases (r0h_ctx_set_session_resident_limit;
         0 = an eighth of the device's memory); segments beyond it are evaluated again when their proofs are finished -- same seals"""
         _check(lib().r0h_ctx_set_session_resident_limit(self.ctx, n_bytes))
+
+    def set_image_circuit(self, image_circuit):
+        """sessions on this context attach an image proof to their receipts from now on (r0h_ctx_set_image_circuit; None: stop)"""
+        _check(lib().r0h_ctx_set_image_circuit(self.ctx, image_circuit.handle if image_circuit is not None else None))
+        self._image_circuit = image_circuit  # (kept alive)
+
+    def prove_image(self, image_circuit, elf, challenge):
+        """One image proof under a session's challenge (r0h_prove_image): the seal's public inputs are the image's digest, the
+        challenge and the image's side of the session's balance."""
+        buf = (ctypes.c_uint8 * len(elf)).from_buffer_copy(elf)
+        ch, pch = _u32arr(challenge)
+        assert ch.size == 16
+        seal = np.empty(1 << 18, dtype=np.uint32)
+        n = _sz(0)
+        _check(lib().r0h_prove_image(self.ctx, image_circuit.handle, buf, len(elf), pch, seal.ctypes.data_as(_vp), seal.size, ctypes.byref(n)))
+        return seal[:n.value].copy()
 
     def last_session_stats(self):
         """Stage timing of the last prove_elf on this context (r0h_last_session_stats)."""

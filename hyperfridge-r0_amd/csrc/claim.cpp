@@ -263,14 +263,15 @@ const char* r0h_receipt_verify_reason(int verdict) {
                                       "seals, claims and chain are valid but no image id was given: nothing ties the receipt to a program",
                                       "a seal's session number, closing flag or challenge is not this session's",
                                       "the segments' session sums do not balance with the program image and the journal",
-                                      "seals, claims, chain and image id are valid, but the program image (the ELF) was not given: the session sum is unchecked"};
-  return verdict >= 0 && verdict <= R0H_RECEIPT_V_NEEDS_IMAGE ? names[verdict] : "unknown";
+                                      "seals, claims, chain and image id are valid, but the program image (the ELF) was not given: the session sum is unchecked",
+                                      "the receipt's image proof is missing, was rejected, or is not about this image or this session"};
+  return verdict >= 0 && verdict <= R0H_RECEIPT_V_IMAGE_PROOF ? names[verdict] : "unknown";
 }
 
 // risc0-zkvm receipt/composite.rs `verify_integrity_with_context` + receipt/mod.rs `Receipt::verify(image_id)`
 static const char* receipt_verify_impl(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots, size_t n_roots,
                                        const uint8_t* image_id, const std::vector<std::pair<uint32_t, uint32_t>>* image, int* verdict_out, size_t* segment_out,
-                                       int* seal_verdict_out) {
+                                       int* seal_verdict_out, const uint32_t* image_public = nullptr /* the verified image proof's 28 public inputs */) {
   R0H_GUARD_BEGIN
   R0H_REQUIRE(rc && blob && verdict_out && (control_roots || !n_roots), "r0h_receipt_verify: NULL argument");
   if (segment_out) *segment_out = 0;
@@ -369,7 +370,15 @@ static const char* receipt_verify_impl(const r0h_receipt* rc, const uint32_t* bl
         closed_up_to = hi;
       }
     }
-    if (!image) {
+    if (image_public) {  // the image's side comes from the image proof: it must be about THIS image (the digest in the first claim's pre-state,
+      // which is held against the image id below) and under THIS session's challenge
+      const uint8_t* root = rc->segments[0].claim.pre.merkle_root;
+      for (int i = 0; i < 8; i++) {
+        const uint32_t w = (uint32_t)root[4 * i] | (uint32_t)root[4 * i + 1] << 8 | (uint32_t)root[4 * i + 2] << 16 | (uint32_t)root[4 * i + 3] << 24;
+        if (w >= P || image_public[i] != enc(w)) return done(R0H_RECEIPT_V_IMAGE_PROOF, 0);
+      }
+      if (memcmp(&image_public[R0H_IMAGE_GAMMA], challenge, 64) != 0) return done(R0H_RECEIPT_V_IMAGE_PROOF, 0);
+    } else if (!image) {
       if (!image_id) return done(R0H_RECEIPT_V_UNBOUND, 0);
       uint8_t pre[32];
       system_state_digest(rc->segments[0].claim.pre, pre);
@@ -386,13 +395,14 @@ static const char* receipt_verify_impl(const r0h_receipt* rc, const uint32_t* bl
     }
     // batched inversion: the fingerprints are multiplied up, one inversion, and walked back
     std::vector<Fp4> fps;
-    fps.reserve(image->size() + rc->journal.size() / 4);
+    fps.reserve((image ? image->size() : 0) + rc->journal.size() / 4);
     auto fingerprint = [&](uint32_t addr, uint32_t word, uint32_t tag) {
       Fp4 f = ag - scale(g1, enc(word & 0xffffu)) - scale(g2, enc(word >> 16)) - scale(g3, enc(tag));
       f.e[0] = sub(f.e[0], enc(addr));
       fps.push_back(f);
     };
-    for (const auto& w : *image) fingerprint(w.first, w.second, R0H_SESSION_TAG_IMAGE);
+    if (image)
+      for (const auto& w : *image) fingerprint(w.first, w.second, R0H_SESSION_TAG_IMAGE);
     if (rc->journal.size() % 4) return done(R0H_RECEIPT_V_JOURNAL, term);  // COMMIT moves words
     for (size_t j = 0; j < rc->journal.size() / 4; j++) {
       const uint8_t* b = &rc->journal[4 * j];
@@ -405,6 +415,7 @@ static const char* receipt_verify_impl(const r0h_receipt* rc, const uint32_t* bl
       other = other + inv_run * prefix[k];
       inv_run = inv_run * fps[k];
     }
+    if (!image) other = other + Fp4{{image_public[R0H_IMAGE_SUM], image_public[R0H_IMAGE_SUM + 1], image_public[R0H_IMAGE_SUM + 2], image_public[R0H_IMAGE_SUM + 3]}};
     if (!(total == other)) return done(R0H_RECEIPT_V_SESSION_SUM, 0);
   }
   if (!image_id) return done(R0H_RECEIPT_V_UNBOUND, 0);  // `receipt.verify(image_id)` always names the program: without it this is not OK
@@ -418,6 +429,41 @@ static const char* receipt_verify_impl(const r0h_receipt* rc, const uint32_t* bl
 const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots, size_t n_roots,
                                const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out) {
   return receipt_verify_impl(rc, blob, blob_words, control_roots, n_roots, image_id, nullptr, verdict_out, segment_out, seal_verdict_out);
+}
+
+// `receipt.verify(image_id)` for a trace-circuit session, the program image NOT in hand: the receipt's image proof stands for it.
+// Checked: the image seal verifies against the image circuit bound to its control root (derived from the blob when not given), its
+// digest is the root in the first claim's pre-state -- whose digest must be image_id --, its challenge is this session's; then
+// everything r0h_receipt_verify_elf checks, with the image proof's total as the image's side of the balance.
+const char* r0h_receipt_verify_image(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots, size_t n_roots,
+                                     const uint32_t* image_blob, size_t image_blob_words, const uint32_t* image_control_root, const uint8_t* image_id, int* verdict_out,
+                                     size_t* segment_out, int* seal_verdict_out) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(rc && blob && image_blob && verdict_out, "r0h_receipt_verify_image: NULL argument");
+  if (segment_out) *segment_out = 0;
+  if (seal_verdict_out) *seal_verdict_out = R0H_VERIFY_OK;
+  r0h_circuit ic;
+  R0H_TRY(parse_blob(&ic, image_blob, image_blob_words));
+  R0H_REQUIRE(is_image_circuit(ic), "r0h_receipt_verify_image: the second blob is not the image circuit (circuits/image.r0c)");
+  if (rc->image_seal.size() <= R0H_IMAGE_GLOBALS) { *verdict_out = R0H_RECEIPT_V_IMAGE_PROOF; return nullptr; }
+  int sv = -1;
+  uint32_t po2 = 0, root[8];
+  if (!image_control_root) {  // a verifier with the blob derives the root of the size the seal names -- once the seal as such holds
+    R0H_TRY(r0h_verify_seal(image_blob, image_blob_words, nullptr, nullptr, rc->image_seal.data(), rc->image_seal.size(), &sv, &po2));
+    if (sv == R0H_VERIFY_OK) {
+      R0H_TRY(r0h_control_root_host(image_blob, image_blob_words, nullptr, nullptr, po2, root));
+      image_control_root = root;
+    }
+  }
+  if (image_control_root)
+    R0H_TRY(r0h_verify_seal_bound(image_blob, image_blob_words, nullptr, nullptr, rc->image_seal.data(), rc->image_seal.size(), image_control_root, &sv, &po2, nullptr));
+  if (sv != R0H_VERIFY_OK) {
+    if (seal_verdict_out) *seal_verdict_out = sv;
+    *verdict_out = R0H_RECEIPT_V_IMAGE_PROOF;
+    return nullptr;
+  }
+  return receipt_verify_impl(rc, blob, blob_words, control_roots, n_roots, image_id, nullptr, verdict_out, segment_out, seal_verdict_out, rc->image_seal.data());
+  R0H_GUARD_END
 }
 
 const char* r0h_receipt_verify_elf(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots, size_t n_roots, const uint8_t* elf,

@@ -106,6 +106,7 @@ struct r0h_ctx {
   size_t pool_bytes = 0;              // bytes parked in the pool; above POOL_LIMIT blocks are released instead
   r0h::Profile prof;
   r0h_session_stats session = {0, 0, 0, 0, 0, 0, 0};  // stage timing of the last r0h_prove_elf
+  const r0h_circuit* image_circuit = nullptr;  // r0h_ctx_set_image_circuit: sessions on this context attach an image proof to their receipts
   uint64_t session_resident_limit = 0;  // r0h_ctx_set_session_resident_limit (0: an eighth of the device's memory)
   void* session_rows = nullptr;   // session.cpp: the preflight row buffers of r0h_prove_elf, page-locked, kept from one call to the next (session_rows_free)
   std::vector<r0h_ctx*> helpers;  // further contexts of the same device, made on demand by r0h_prove_elf for its extra prover lanes; they go with this one

@@ -354,6 +354,12 @@ const char* parse_receipt(const Json& root, r0h_receipt& rc) {
     }
     rc.segments.push_back(std::move(seg));
   }
+  if (const Json* ip = body.get("image_proof")) {  // this library's own addition: absent from risc0's receipts
+    R0H_REQUIRE(ip->kind == Json::Obj, "receipt JSON: \"image_proof\" is not an object");
+    std::vector<uint64_t> words;
+    R0H_TRY(u32_array(ip->get("seal"), 0xffffffffull, "image_proof.seal", words));
+    rc.image_seal.assign(words.begin(), words.end());
+  }
   if (const Json* md = root.get("metadata")) {
     R0H_REQUIRE(md->kind == Json::Obj, "receipt JSON: \"metadata\" is not an object");
     R0H_TRY(parse_digest(md->get("verifier_parameters"), "metadata.verifier_parameters", rc.verifier_parameters));
@@ -544,6 +550,11 @@ const char* r0h_receipt_merge(const r0h_receipt* const* parts, size_t n, r0h_rec
   std::unique_ptr<r0h_receipt> rc(new r0h_receipt(*parts[0]));
   rc->segments.clear();
   for (size_t i = 0; i < total; i++) rc->segments.push_back(*at[i]);  // (every slot is filled: total indices below total, none twice)
+  for (size_t k = 0; k < n; k++) {  // the session's image proof travels with whichever part made it
+    if (parts[k]->image_seal.empty()) continue;
+    R0H_REQUIRE(rc->image_seal.empty() || rc->image_seal == parts[k]->image_seal, "r0h_receipt_merge: receipt %zu carries another image proof", k);
+    rc->image_seal = parts[k]->image_seal;
+  }
   *out = rc.release();
   return nullptr;
   R0H_GUARD_END
@@ -554,6 +565,21 @@ const char* r0h_receipt_segment_claim(const r0h_receipt* rc, size_t i, r0h_recei
   R0H_REQUIRE(i < rc->segments.size(), "r0h_receipt_segment_claim: segment %zu of %zu", i, rc->segments.size());
   *has_claim_out = rc->segments[i].has_claim ? 1 : 0;
   if (rc->segments[i].has_claim) *claim_out = rc->segments[i].claim;
+  return nullptr;
+}
+
+const char* r0h_receipt_set_image_proof(r0h_receipt* rc, const uint32_t* seal, size_t seal_words) {
+  R0H_GUARD_BEGIN
+  R0H_REQUIRE(rc && (seal || !seal_words), "r0h_receipt_set_image_proof: NULL argument");
+  R0H_REQUIRE(rc->kind == R0H_RECEIPT_COMPOSITE, "r0h_receipt_set_image_proof: not a composite receipt");
+  rc->image_seal.assign(seal, seal + seal_words);
+  return nullptr;
+  R0H_GUARD_END
+}
+const char* r0h_receipt_image_proof(const r0h_receipt* rc, const uint32_t** seal, size_t* seal_words) {
+  R0H_REQUIRE(rc && seal && seal_words, "r0h_receipt_image_proof: NULL argument");
+  *seal = rc->image_seal.empty() ? nullptr : rc->image_seal.data();
+  *seal_words = rc->image_seal.size();
   return nullptr;
 }
 
@@ -632,6 +658,11 @@ const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out) {
     }
     s += "],\"assumption_receipts\":[],\"verifier_parameters\":";
     append_hex(s, rc->verifier_parameters);
+    if (!rc->image_seal.empty()) {
+      s += ",\"image_proof\":{\"seal\":[";
+      for (size_t w = 0; w < rc->image_seal.size(); w++) { if (w) s += ','; append_u(s, rc->image_seal[w]); }
+      s += "]}";
+    }
     s += "}}";
   }
   s += ",\"journal\":{\"bytes\":[";

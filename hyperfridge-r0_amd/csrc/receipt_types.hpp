@@ -20,6 +20,7 @@ struct r0h_receipt {
     uint8_t verifier_parameters[32] = {0};
   };
   std::vector<Segment> segments;
+  std::vector<uint32_t> image_seal;  // optional: the image proof of a trace-circuit session (csrc/image.cpp), `inner.Composite.image_proof.seal`
   bool has_metadata = false;  // risc0 >= 1.0 `Receipt.metadata`; the reference's (older) Fake fixtures have none
   uint8_t verifier_parameters[32] = {0};
 };
@@ -44,6 +45,7 @@ void system_state_digest(const r0h_system_state& st, uint8_t out[32]);
 void claim_digest(const r0h_receipt_claim& c, uint8_t out[32]);
 void claim_globals(const uint8_t digest[32], uint32_t out[8]);
 bool is_trace_circuit(const r0h_circuit& circ);
+bool is_image_circuit(const r0h_circuit& circ);  // image.cpp
 bool trace_seal_carries_claim(const uint32_t* seal, const r0h_receipt_claim& claim);
 void session_challenge(const uint32_t* records, size_t n_records, uint32_t out[16]);
 void image_stream(const std::vector<std::pair<uint32_t, uint32_t>>& image, std::vector<uint32_t>& words_out);  // rv32im.cpp: the image circuit's sponge blocks (Montgomery)

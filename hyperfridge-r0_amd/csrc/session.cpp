@@ -155,6 +155,7 @@ struct r0h_session {
   std::vector<Pending> pending;  // this rank's segments, by index
   CodeCommits commits;
   std::vector<uint8_t> journal;
+  std::vector<uint8_t> elf;  // kept for the image proof (r0h_ctx_set_image_circuit)
   uint8_t image_id[32] = {0};
   uint64_t cycles = 0;
   r0h_session_stats stats = {0, 0, 0, 0, 0, 0, 0};
@@ -210,6 +211,7 @@ const char* r0h_session_begin(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t*
   ses->part = part;
   ses->parts = parts;
   ses->t_begin = Clock::now();
+  if (trace_mode && ctx->image_circuit && part == 0) ses->elf.assign(elf, elf + elf_len);
   ses->resident_limit = ctx->session_resident_limit;
   if (!ses->resident_limit) {
     size_t free_b = 0, total_b = 0;
@@ -533,6 +535,7 @@ const char* r0h_session_finish(r0h_session* s, const uint32_t* all_records, size
   R0H_GUARD_BEGIN
   R0H_REQUIRE(s && receipt_out, "r0h_session_finish: NULL argument");
   const r0h_circuit* c = s->c;
+  std::vector<uint32_t> image_seal;
   if (s->trace_mode) {
     R0H_REQUIRE(all_records && n_records == s->n_segments, "r0h_session_finish: the session has %zu segments, %zu records were given", s->n_segments, n_records);
     const uint32_t n_early = R0H_TRACE_GLOBALS - R0H_TRACE_LATE_GLOBALS;
@@ -592,6 +595,12 @@ const char* r0h_session_finish(r0h_session* s, const uint32_t* all_records, size
     guarded(s->lane_ctx[0]);
     for (std::thread& t : workers) t.join();
     if (first_err) return first_err;
+    if (!s->elf.empty() && s->ctx->image_circuit) {  // the image's side of the balance, proved: `receipt.verify(image_id)` then needs no ELF
+      image_seal.resize((size_t)1 << 18);
+      size_t words = 0;
+      R0H_TRY(r0h_prove_image(s->ctx, s->ctx->image_circuit, s->elf.data(), s->elf.size(), challenge, image_seal.data(), image_seal.size(), &words));
+      image_seal.resize(words);
+    }
   }
   r0h_receipt* rc = nullptr;
   R0H_TRY(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, nullptr, 0, &rc));
@@ -601,6 +610,7 @@ const char* r0h_session_finish(r0h_session* s, const uint32_t* all_records, size
     R0H_TRY(r0h_receipt_add_segment_claim(rc, p.seal.data(), p.seal.size(), (uint32_t)p.index, &p.claim, nullptr));
   }
   rc->journal = s->journal;
+  rc->image_seal = image_seal;
   if (image_id_out) memcpy(image_id_out, s->image_id, 32);
   if (cycles_out) *cycles_out = s->cycles;
   s->stats.wall_s = seconds(s->t_begin, Clock::now());

@@ -333,6 +333,7 @@ const char* r0h_receipt_to_json(const r0h_receipt* rc, char** json_out);
 #define R0H_RECEIPT_V_SESSION 13       /* trace circuit: a seal's session number / closing flags / challenge are not the session's */
 #define R0H_RECEIPT_V_SESSION_SUM 14   /* trace circuit: the segments' sums, the program image and the journal do not balance */
 #define R0H_RECEIPT_V_NEEDS_IMAGE 15   /* trace circuit: everything else holds, but the program image (the ELF) was not given */
+#define R0H_RECEIPT_V_IMAGE_PROOF 16   /* r0h_receipt_verify_image: the image proof is missing, rejected, or about another image / session */
 const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots,
                                size_t n_roots, const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out);
 /* `receipt.verify(image_id)` for receipts over the trace circuit (circuits/trace.r0c), where the program is bound by a session-wide
@@ -346,6 +347,14 @@ const char* r0h_receipt_verify(const r0h_receipt* rc, const uint32_t* blob, size
 const char* r0h_receipt_verify_elf(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots,
                                    size_t n_roots, const uint8_t* elf, size_t elf_len, int* verdict_out, size_t* segment_out,
                                    int* seal_verdict_out);
+/* The same verdict WITHOUT the ELF: the receipt's image proof (r0h_receipt_image_proof; r0h_prove_elf attaches one when the context
+ * was given the image circuit) stands for the image -- `receipt.verify(image_id)` as the reference calls it, with 32 bytes.  The image
+ * seal is verified against `image_blob` bound to `image_control_root` (NULL: derived from the blob at the size the seal names). */
+const char* r0h_receipt_verify_image(const r0h_receipt* rc, const uint32_t* blob, size_t blob_words, const uint32_t* control_roots,
+                                     size_t n_roots, const uint32_t* image_blob, size_t image_blob_words, const uint32_t* image_control_root,
+                                     const uint8_t* image_id, int* verdict_out, size_t* segment_out, int* seal_verdict_out);
+const char* r0h_receipt_set_image_proof(r0h_receipt* rc, const uint32_t* seal, size_t seal_words);
+const char* r0h_receipt_image_proof(const r0h_receipt* rc, const uint32_t** seal_out, size_t* seal_words_out); /* NULL / 0 when there is none */
 const char* r0h_receipt_verify_reason(int verdict); /* static string, do not free */
 /* The image id as text, the reference's way (host/src/main.rs:445-449, verifier/src/main.rs:131-143, host/out/IMAGE_ID.hex): eight
  * u32 words printed `{:08x}`, each stored little-endian in the 32-byte digest (`Digest::from([u32; 8])`) -- NOT the digest's bytes
@@ -620,6 +629,31 @@ const char* r0h_receipt_merge(const r0h_receipt* const* parts, size_t n, r0h_rec
 /* per-stage timing of the last r0h_prove_elf on this context (for tools/bench_session.py): names are static strings */
 typedef struct { uint32_t segments, lean_segments /* proved without resident evaluations: r0h_ctx_set_session_resident_limit */; uint64_t cycles; double executor_s, witgen_ms, prove_ms, wall_s; } r0h_session_stats;
 const char* r0h_last_session_stats(r0h_ctx* ctx, r0h_session_stats* out);
+
+/* ---- the image proof: `receipt.verify(image_id)` without the program image (verifier/src/main.rs:124-126).  r0h_receipt_verify_elf
+ * completes a trace-circuit session's memory argument with the ELF's own words; a verifier who holds only the 32 bytes of the image id
+ * cannot.  The image circuit (circuits/image.r0c, tools/image_circuit.py; W = 8 ACCUM + 30 CODE + 69 DATA) proves the image's side
+ * for it: its rows run the Poseidon2 sponge over the image's word list -- blocks of four (word index, low half, high half) and a mask
+ * -- whose digest is the root of the initial memory state the image id names (public inputs 0..7), and add every word's fraction
+ * 1 / (alpha_g - index - gamma lo - gamma^2 hi - gamma^3 TAG_IMAGE) under the session's challenge (inputs 8..23) to a running sum
+ * whose total is public (inputs 24..27).  r0h_prove_elf attaches such a seal to the receipt when the context has been given the image
+ * circuit (r0h_ctx_set_image_circuit); r0h_receipt_verify_image checks it and balances the session with its total. ---- */
+#define R0H_IMAGE_COLUMNS 69
+#define R0H_IMAGE_GLOBALS 28
+#define R0H_IMAGE_LATE_GLOBALS 20
+#define R0H_IMAGE_GAMMA 8
+#define R0H_IMAGE_SUM 24
+/* smallest trace that holds the image's sponge (30 rows per four words; at least 2^9) */
+const char* r0h_image_po2(const uint8_t* elf, size_t elf_len, uint32_t* po2_out);
+/* host: the image circuit's DATA group for an ELF ([R0H_IMAGE_COLUMNS][2^po2], Montgomery, column-major) and its public inputs with
+ * the digest filled in (challenge and total left zero) */
+const char* r0h_image_witness(const uint8_t* elf, size_t elf_len, uint32_t po2, uint32_t* data_out, uint32_t globals_out[R0H_IMAGE_GLOBALS]);
+/* sessions begun on `ctx` afterwards (r0h_prove_elf, r0h_session_begin with part 0) attach an image proof to their receipts; NULL stops
+ * that.  The circuit must have been loaded on this context and must outlive the sessions. */
+const char* r0h_ctx_set_image_circuit(r0h_ctx* ctx, const r0h_circuit* image_circuit);
+/* device: one image proof under `challenge` (r0h_session_challenge); seal_out may be NULL to ask for the size */
+const char* r0h_prove_image(r0h_ctx* ctx, const r0h_circuit* image_circuit, const uint8_t* elf, size_t elf_len, const uint32_t challenge[16],
+                            uint32_t* seal_out, size_t seal_capacity_words, size_t* seal_words_out);
 
 /* ---- recursion: risc0-zkvm `ProverServer::{lift, join}` (risc0-circuit-recursion 4.0.4, Cargo.lock:3050-3085; BASELINE.json
  * configs[4]).  `lift` stands one recursion-circuit proof for one segment seal and its claim; `join` folds two nodes into one whose

@@ -159,9 +159,29 @@ def test_prove_elf_with_the_trace_circuit_proves_the_run_it_executed(hal, orc):
     assert hal.last_session_stats()["lean_segments"] == len(segs) - 1
     hal.set_session_resident_limit(0)
     assert all(ia == ib and np.array_equal(a, b) for (ia, a), (ib, b) in zip(lean.seals(), seals)) and lean.journal == receipt.journal
+    # with the image circuit set on the context the receipt carries an image proof: the image id alone verifies it (no ELF), the proof
+    # is the oracle's word for word, and it is about THIS session (another session's challenge is refused)
+    iblob = np.fromfile(circuit_path("image"), dtype=np.uint32)
+    ic = hal.load_circuit(iblob, entry.code_object_path("image"))
+    hal.set_image_circuit(ic)
+    with_proof, _, _ = hal.prove_elf(gc, elf, stream, segment_po2=po2)
+    hal.set_image_circuit(None)
+    assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(with_proof.seals(), seals)) and with_proof.image_proof is not None and receipt.image_proof is None
+    oi = orc.circuit(iblob)
+    ipo2 = r0.image_po2(elf)
+    idata, iglob = r0.image_witness(elf, ipo2)
+    iglob[r0.IMAGE_GAMMA:r0.IMAGE_GAMMA + 16] = seals[0][1][r0.TRACE_GAMMA:r0.TRACE_GAMMA + 16]
+    icode = oi.witgen(ipo2, 0)[0]
+    want_image_seal = oi.prove(ipo2, icode, idata.reshape(-1), oi.logup_totals(ipo2, icode, idata.reshape(-1), iglob))
+    assert np.array_equal(with_proof.image_proof, want_image_seal) and np.array_equal(hal.prove_image(ic, elf, iglob[r0.IMAGE_GAMMA:r0.IMAGE_GAMMA + 16]), want_image_seal)
+    ic.free()
     size = r0.TRACE_MIN_PO2
     cc = hal.code_commit(gc, size)
     roots, ocode = {size: cc.root()}, c.witgen(size, 0)[0]
+    assert with_proof.verify_image(blob, roots, iblob, image_id)[:2] == (0, "ok") and receipt.verify_image(blob, roots, iblob, image_id)[0] == 16
+    assert with_proof.verify_image(blob, roots, iblob, bytes(32))[0] == 8
+    with_proof.image_proof = None  # (no proof: back to needing the ELF)
+    assert with_proof.verify_image(blob, roots, iblob, image_id)[0] == 16 and with_proof.verify(blob, roots, None, elf=elf)[:2] == (0, "ok")
     assert np.array_equal(r0.control_root_host(blob, size), roots[size])
     halting = max(k for k, s in enumerate(segs) if s.user_cycles)
     for k, (index, seal) in enumerate(seals):

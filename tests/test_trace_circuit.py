@@ -641,6 +641,91 @@ def test_the_session_binds_the_segments_the_program_and_the_journal(orc, prover)
     assert forged.verify(blob, roots5, None, elf=elf)[0] == 13
 
 
+def test_the_image_proof_lets_the_image_id_alone_verify_a_session(orc, prover):
+    """`receipt.verify(image_id)` as the reference calls it (verifier/src/main.rs:124-126): 32 bytes, no ELF.  The receipt carries an
+    image proof (circuits/image.r0c): the Poseidon2 digest of the image's word list -- the root of the state the image id names -- is
+    computed inside that proof, and its rows add the image words' fractions under the session's challenge; the verifier balances the
+    session with the proof's total instead of walking the ELF.  Here the session and the image proof are made by the oracle; refused:
+    a receipt without the proof, the proof of another image (whatever digest it claims), of another session (another challenge), a
+    total that is not the image's, an image id that is not the first pre-state's."""
+    from test_rv32im import ADDI
+    from bench_session import elf_of
+    import image_circuit as ic
+    blob, pv = prover
+    iblob = np.fromfile(circuit_path("image"), dtype=np.uint32)
+    oi = orc.circuit(iblob)
+    prog, base = _guest(120), 0x400
+    elf = elf_of(prog, base)
+    vm = r0.Vm()
+    vm.load_elf(elf)
+    vm.set_input([7, 0x01020304])
+    assert vm.run(segment_po2=12, keep_trace=True, boundary_rows=True) == (0, 0)
+    receipt, roots = sbh.prove_session(pv, vm)
+    image_id = r0.compute_image_id(elf)
+    assert receipt.verify(blob, roots, None, elf=elf)[:2] == (0, "ok") and receipt.verify(blob, roots, image_id)[0] == 15
+    assert receipt.image_proof is None and receipt.verify_image(blob, roots, iblob, image_id)[0] == 16  # no image proof: not accepted on the id alone
+    challenge = receipt.seals()[0][1][r0.TRACE_GAMMA:r0.TRACE_GAMMA + 16]
+
+    def image_seal(of_elf, under=challenge, edit=None):
+        po2 = r0.image_po2(of_elf)
+        data, glob = r0.image_witness(of_elf, po2)
+        glob[r0.IMAGE_GAMMA:r0.IMAGE_GAMMA + 16] = under
+        code = oi.witgen(po2, 0)[0]
+        glob = oi.logup_totals(po2, code, data.reshape(-1), glob)
+        if edit is not None:
+            edit(data, glob)
+        try:
+            return oi.prove(po2, code, data.reshape(-1), glob)
+        except AssertionError:  # the oracle prover found no polynomial quotient
+            return None
+
+    # the library's witness is the generator's restatement, word for word, and its digest is the root the image id names
+    po2 = r0.image_po2(elf)
+    data, glob = r0.image_witness(elf, po2)
+    cols, digest = ic.witness(_image(base, prog), 1 << po2)
+    assert np.array_equal(np.array([[orc.enc(v) for v in c] for c in cols], dtype=np.uint32), data) and [orc.enc(v) for v in digest] == glob[:8].tolist()
+    assert bytes(vm.segments()[0].pre.merkle_root) == b"".join(int(w).to_bytes(4, "little") for w in digest)
+    good = image_seal(elf)
+    assert oi.verify(good) == (0, "ok")
+    receipt.image_proof = good
+    assert receipt.verify_image(blob, roots, iblob, image_id)[:2] == (0, "ok")
+    back = r0.Receipt.parse(receipt.to_json())  # the proof travels in the receipt's JSON
+    assert np.array_equal(back.image_proof, good) and back.verify_image(blob, roots, iblob, image_id)[:2] == (0, "ok")
+    assert back.verify_image(blob, roots, iblob, image_id, image_control_root=r0.control_root_host(iblob, po2))[:2] == (0, "ok")
+    assert back.verify_image(blob, roots, iblob, image_id, image_control_root=r0.control_root_host(iblob, po2 + 1))[0] == 16
+    assert receipt.verify_image(blob, roots, iblob, r0.compute_image_id(elf_of(prog, base + 4)))[0] == 8       # another image id
+    # another program's image proof: honest about its own digest -> not this receipt's image
+    other = elf_of(prog[:-4] + [ADDI(0, 0, 0)] + prog[-3:], base)
+    receipt.image_proof = image_seal(other)
+    assert receipt.verify_image(blob, roots, iblob, image_id)[0] == 16
+    # ... claiming THIS image's digest over the other program's words: no such proof exists
+
+    def claim_digest(data, glob):
+        glob[:8] = r0.image_witness(elf, po2)[1][:8]
+    forged = image_seal(other, edit=claim_digest)
+    if forged is not None:
+        assert oi.verify(forged)[0] != 0
+        receipt.image_proof = forged
+        assert receipt.verify_image(blob, roots, iblob, image_id)[0] == 16
+    # the right image under another challenge (another session's proof replayed)
+    receipt.image_proof = image_seal(elf, under=np.roll(challenge, 4))
+    assert receipt.verify_image(blob, roots, iblob, image_id)[0] == 16
+    # a total that is not the image's: a word's fraction left out (its flag cleared, the mask still hashed) -- or simply another number
+
+    def drop_a_word(data, glob):
+        data[r0.SPONGE_DATA_COLUMNS + 1, 0] = 0
+        glob[:] = oi.logup_totals(po2, oi.witgen(po2, 0)[0], data.reshape(-1), glob)
+    forged = image_seal(elf, edit=drop_a_word)
+    assert forged is None or oi.verify(forged)[0] != 0
+
+    def other_total(data, glob):
+        glob[r0.IMAGE_SUM] = (int(glob[r0.IMAGE_SUM]) + 1) % P
+    forged = image_seal(elf, edit=other_total)
+    assert forged is None or oi.verify(forged)[0] != 0
+    receipt.image_proof = good
+    assert receipt.verify_image(blob, roots, iblob, image_id)[:2] == (0, "ok")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_loop,po2", [(60, 16), (9000, 17)])
 def test_the_device_expands_and_proves_an_execution_trace_word_for_word_like_the_cpu_side(hal, orc, n_loop, po2):
