@@ -11,6 +11,8 @@
 //
 //   usage: r0h_prove <trace.r0c> --elf guest.elf --input words.bin [--code-object file.hsaco] [--po2 N] [--device D] --receipt-out file.json
 //                    [--receipts R --contexts C --receipt-dir dir]   R sessions of the guest, C in flight (BASELINE.json configs[3]), each receipt verified with the ELF
+//                    [--image-circuit circuits/image.r0c --image-code-object circuits/image.evalcheck.hsaco]   the receipts carry an image proof and are also
+//                    verified with the image id alone (r0h_receipt_verify_image: the reference's `receipt.verify(image_id)`)
 // `prover.prove(env, ELF)` itself (host/src/main.rs:420-423) as a compiled host: the guest ELF is executed on the u32 input stream
 // (the ExecutorEnv frames, little-endian words in a file), every segment is proved (r0h_prove_elf: with circuits/trace.r0c the
 // seals are proofs over the segments' own cycles), the receipt is written as JSON, and one line of JSON names the image id in
@@ -54,6 +56,7 @@ int main(int argc, char** argv) {
   std::string blob_path = argv[1], co_path, seal_out, receipt_out, receipt_dir, journal_text, elf_path, input_path;
   std::map<std::string, std::string> camt;  // --camt53-response and what goes with it
   std::string receipt_prefix;               // --receipt-prefix P: the reference's file name, P-Receipt-<image id>-latest.json (host/src/main.rs:312-316)
+  std::string image_circuit_path, image_co_path;
   unsigned po2 = 16, segments = 1, device = 0, contexts = 1, verify = 0, receipts = 1;
   unsigned long long seed = 1;
   for (int i = 2; i + 1 < argc; i += 2) {
@@ -72,6 +75,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--elf")) elf_path = argv[i + 1];
     else if (!strcmp(argv[i], "--input")) input_path = argv[i + 1];
     else if (!strcmp(argv[i], "--receipt-prefix")) receipt_prefix = argv[i + 1];
+    else if (!strcmp(argv[i], "--image-circuit")) image_circuit_path = argv[i + 1];        // circuits/image.r0c: the receipts carry an image proof
+    else if (!strcmp(argv[i], "--image-code-object")) image_co_path = argv[i + 1];
     else if (!strcmp(argv[i], "--camt53-response")) camt["response"] = argv[i + 1];  // the library's own camt53 guest fed from an EBICS response
     else if (!strcmp(argv[i], "--pub-bank") || !strcmp(argv[i], "--pub-client") || !strcmp(argv[i], "--pub-witness") || !strcmp(argv[i], "--tx-key-raw") ||
              !strcmp(argv[i], "--witness-hex") || !strcmp(argv[i], "--iban") || !strcmp(argv[i], "--hostinfo") || !strcmp(argv[i], "--form"))
@@ -128,11 +133,22 @@ int main(int argc, char** argv) {
     if (contexts < 1 || contexts > 8) { fprintf(stderr, "r0h_prove: --contexts must be 1..8 with --elf\n"); return 1; }
     if (receipts > 1 && receipt_dir.empty()) { fprintf(stderr, "r0h_prove: --receipts R > 1 writes one file per receipt: use --receipt-dir\n"); return 1; }
     if (contexts > receipts) contexts = receipts;
-    struct Worker { r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; };
+    struct Worker { r0h_ctx* ctx = nullptr; r0h_circuit* circ = nullptr; r0h_circuit* image = nullptr; };
     std::vector<Worker> workers(contexts);
+    std::vector<uint32_t> image_blob;
+    if (!image_circuit_path.empty()) {
+      std::vector<uint8_t> bytes;
+      if (!slurp(image_circuit_path, &bytes) || bytes.size() % 4) { fprintf(stderr, "r0h_prove: cannot read %s\n", image_circuit_path.c_str()); return 1; }
+      image_blob.resize(bytes.size() / 4);
+      memcpy(image_blob.data(), bytes.data(), bytes.size());
+    }
     for (Worker& w : workers) {
       CHECK(r0h_ctx_create((int)device, &w.ctx));
       CHECK(r0h_circuit_load(w.ctx, blob.data(), blob.size(), co_path.empty() ? nullptr : co_path.c_str(), &w.circ));
+      if (!image_blob.empty()) {  // every receipt then carries an image proof: `receipt.verify(image_id)` needs no ELF
+        CHECK(r0h_circuit_load(w.ctx, image_blob.data(), image_blob.size(), image_co_path.empty() ? nullptr : image_co_path.c_str(), &w.image));
+        CHECK(r0h_ctx_set_image_circuit(w.ctx, w.image));
+      }
     }
     r0h_ctx* ctx = workers[0].ctx;
     r0h_circuit* circ = workers[0].circ;
@@ -209,6 +225,11 @@ int main(int argc, char** argv) {
         int verdict = -1;
         const char* e = r0h_receipt_verify_elf(made[u], blob.data(), blob.size(), root_table.data(), root_table.size() / 9, elf.data(), elf.size(), &verdict, nullptr, nullptr);
         if (e) { r0h_free_error(e); verdict = -1; }
+        if (verdict == R0H_RECEIPT_V_OK && !image_blob.empty()) {  // ... and the way the reference's verifier does: the image id's 32 bytes alone
+          e = r0h_receipt_verify_image(made[u], blob.data(), blob.size(), root_table.data(), root_table.size() / 9, image_blob.data(), image_blob.size(), nullptr, image_id, &verdict,
+                                       nullptr, nullptr);
+          if (e) { r0h_free_error(e); verdict = -1; }
+        }
         if (verdict != R0H_RECEIPT_V_OK) { fprintf(stderr, "r0h_prove: receipt %u is refused: %s\n", u, r0h_receipt_verify_reason(verdict)); refused++; }
       }
     };
@@ -225,8 +246,9 @@ int main(int argc, char** argv) {
     r0h_session_stats st;
     CHECK(r0h_last_session_stats(ctx, &st));
     printf("{\"receipt\": \"%s\", \"image_id\": \"%s\", \"receipts\": %u, \"contexts\": %u, \"segments\": %zu, \"cycles\": %llu, \"seconds\": %.4f, \"segments_per_s\": %.3f, \"receipts_per_s\": %.4f, "
-           "\"executor_s\": %.4f, \"receipts_verified_with_the_elf\": %u, \"verify_seconds\": %.3f, \"control_roots\": [",
-           receipt_out.c_str(), hex, receipts, contexts, n_seg, (unsigned long long)cycles, secs, (double)n_seg * receipts / secs, receipts / secs, st.executor_s, receipts, verify_secs);
+           "\"executor_s\": %.4f, \"receipts_verified_with_the_elf\": %u, \"receipts_verified_with_the_image_id_alone\": %u, \"verify_seconds\": %.3f, \"control_roots\": [",
+           receipt_out.c_str(), hex, receipts, contexts, n_seg, (unsigned long long)cycles, secs, (double)n_seg * receipts / secs, receipts / secs, st.executor_s, receipts,
+           image_blob.empty() ? 0u : receipts, verify_secs);
     for (size_t k = 0; k < sizes.size(); k++) {
       const uint32_t* root = &root_table[9 * k + 1];
       printf("%s\"%u:%u,%u,%u,%u,%u,%u,%u,%u\"", k ? ", " : "", sizes[k], root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7]);
@@ -235,6 +257,7 @@ int main(int argc, char** argv) {
     for (r0h_receipt* r : made) CHECK(r0h_receipt_free(r));
     for (Worker& w : workers) {
       CHECK(r0h_circuit_free(w.circ));
+      if (w.image) { CHECK(r0h_ctx_set_image_circuit(w.ctx, nullptr)); CHECK(r0h_circuit_free(w.image)); }
       CHECK(r0h_ctx_destroy(w.ctx));
     }
     return 0;

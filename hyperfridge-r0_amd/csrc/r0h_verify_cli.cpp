@@ -3,6 +3,8 @@
 // Needs no GPU.  Exit status: 0 accepted, 1 rejected (reason on stdout), 2 unusable input.
 //   usage: r0h_verify <circuit.r0c> <seal.bin>
 //          r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --control-root <po2>:<w0,..,w7> [--control-root ..]
+//          r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --image-circuit <image.r0c>   a trace-circuit receipt that carries
+//                     an image proof, checked with the 32 bytes of the image id alone (r0h_receipt_verify_image) -- the reference's call
 //          r0h_verify --image-id-of <guest.elf>          prints the image id in the reference's IMAGE_ID.hex form (`host show-image-id`)
 //          r0h_verify --receipt <receipt.json> <circuit.r0c> --elf <guest.elf> --control-root ...   (the image id computed from the ELF:
 //                     r0h_compute_image_id, what risc0_build embeds as HYPERFRIDGE_ID).  A receipt over the trace circuit binds its
@@ -46,7 +48,8 @@ static void print_json_string(const uint8_t* p, size_t n) {
 }
 
 // verifier/src/main.rs:114-128: read the receipt JSON, verify it against the image id, print the commitment
-static int verify_receipt(const char* receipt_path, const char* blob_path, const char* image_hex, std::vector<uint32_t> roots, const char* elf_path = nullptr) {
+static int verify_receipt(const char* receipt_path, const char* blob_path, const char* image_hex, std::vector<uint32_t> roots, const char* elf_path = nullptr,
+                          const char* image_circuit_path = nullptr) {
   std::vector<uint32_t> blob;
   if (!read_words(blob_path, &blob)) { fprintf(stderr, "r0h_verify: cannot read %s as 32-bit words\n", blob_path); return 2; }
   FILE* f = fopen(receipt_path, "rb");
@@ -105,8 +108,13 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
   size_t at = 0;
   const char* reason = "";
   bool seals_valid = false;
+  std::vector<uint32_t> image_blob;  // --image-circuit: the image id alone is enough when the receipt carries an image proof
+  if (image_circuit_path && elf.empty() && !read_words(image_circuit_path, &image_blob)) { fprintf(stderr, "r0h_verify: cannot read %s\n", image_circuit_path); r0h_receipt_free(rc); return 2; }
   if (bound) {
-    if (!elf.empty()) err = r0h_receipt_verify_elf(rc, blob.data(), blob.size(), roots.data(), roots.size() / 9, elf.data(), elf.size(), &verdict, &at, &seal_verdict);
+    if (!image_blob.empty())
+      err = r0h_receipt_verify_image(rc, blob.data(), blob.size(), roots.data(), roots.size() / 9, image_blob.data(), image_blob.size(), nullptr, image_id, &verdict, &at,
+                                     &seal_verdict);
+    else if (!elf.empty()) err = r0h_receipt_verify_elf(rc, blob.data(), blob.size(), roots.data(), roots.size() / 9, elf.data(), elf.size(), &verdict, &at, &seal_verdict);
     else err = r0h_receipt_verify(rc, blob.data(), blob.size(), roots.data(), roots.size() / 9, image_id, &verdict, &at, &seal_verdict);
     if (err) { fprintf(stderr, "r0h_verify: %s\n", err); r0h_free_error(err); r0h_receipt_free(rc); return 2; }
     reason = verdict == R0H_RECEIPT_V_SEAL ? r0h_verify_reason(seal_verdict) : r0h_receipt_verify_reason(verdict);
@@ -130,7 +138,8 @@ static int verify_receipt(const char* receipt_path, const char* blob_path, const
   if (err) { r0h_free_error(err); len = 0; }
   // what ties the receipt to a program: the session sum completed with the ELF's own words (trace circuit), or -- synthetic circuits --
   // only the chain of claims from the image id (their seals prove that a satisfying trace naming the claim exists, not that the program ran)
-  const char* program_bound = !accepted ? (verdict == R0H_RECEIPT_V_NEEDS_IMAGE ? "no: the receipt binds its program through the session sum; give --elf" : "no")
+  const char* program_bound = !accepted ? (verdict == R0H_RECEIPT_V_NEEDS_IMAGE ? "no: the receipt binds its program through the session sum; give --elf, or --image-circuit if it carries an image proof" : "no")
+                                        : !image_blob.empty() ? "yes: image id and the session sum balanced with the receipt's image proof (whose in-circuit digest is the root the image id names)"
                                         : !elf.empty() ? "yes: image id and, for a trace-circuit receipt, the session sum over the ELF's image words" : "by the claims' chain from the image id";
   printf("{\"accepted\": %s, \"seals_valid\": %s, \"journal_bound\": %s, \"program_bound\": \"%s\", \"segments\": %zu, \"segment_at_fault\": %zu, \"reason\": \"%s\", \"control_roots\": \"%s\", \"commitment\": ",
          accepted ? "true" : "false", seals_valid ? "true" : "false", accepted ? "true" : "false", program_bound, n_seg, at, accepted ? "ok" : reason,
@@ -160,10 +169,12 @@ int main(int argc, char** argv) {
   if (argc >= 4 && !strcmp(argv[1], "--receipt")) {
     const char* image_hex = nullptr;
     const char* elf_path = nullptr;
+    const char* image_circuit_path = nullptr;
     std::vector<uint32_t> roots;  // records of [po2, root[8]]
     for (int i = 4; i + 1 < argc; i += 2) {
       if (!strcmp(argv[i], "--image-id")) image_hex = argv[i + 1];
       else if (!strcmp(argv[i], "--elf")) elf_path = argv[i + 1];
+      else if (!strcmp(argv[i], "--image-circuit")) image_circuit_path = argv[i + 1];
       else if (!strcmp(argv[i], "--control-root")) {
         unsigned v[9];
         if (sscanf(argv[i + 1], "%u:%u,%u,%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) != 9) {
@@ -173,7 +184,7 @@ int main(int argc, char** argv) {
         roots.insert(roots.end(), v, v + 9);
       } else { fprintf(stderr, "r0h_verify: unknown option %s\n", argv[i]); return 2; }
     }
-    return verify_receipt(argv[2], argv[3], image_hex, roots, elf_path);
+    return verify_receipt(argv[2], argv[3], image_hex, roots, elf_path, image_circuit_path);
   }
   if (argc != 3) {
     printf("usage: r0h_verify <circuit.r0c> <seal.bin>\n       r0h_verify --receipt <receipt.json> <circuit.r0c> --image-id <64 hex> --control-root <po2>:<w0,..,w7>\n%s\n", r0h_version());

@@ -180,3 +180,21 @@ def test_compiled_hosts_prove_the_guest_and_verify_the_receipt_like_host_and_ver
     assert batch["receipts"] == 3 and batch["contexts"] == 2 and batch["receipts_verified_with_the_elf"] == 3 and batch["segments"] == info["segments"]
     for k in range(3):
         assert open(str(tmp_path / ("receipt_%04d.json" % k))).read() == open(receipt).read()  # the same session, the same receipt
+    # the reference's own call, `receipt.verify(image_id)` with 32 bytes and no ELF: the prover is given the image circuit, the receipt then
+    # carries an image proof, and the verifier -- given the image circuit's blob instead of the ELF -- accepts on the image id alone
+    receipt3 = str(tmp_path / "receipt3.json")
+    out = subprocess.run([CLI, circuit_path("trace"), "--code-object", entry.code_object_path("trace"), "--elf", elf_path, "--input", str(words), "--po2", "20",
+                          "--receipt-out", receipt3, "--image-circuit", circuit_path("image"), "--image-code-object", entry.code_object_path("image")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["receipts_verified_with_the_image_id_alone"] == 1
+    out = subprocess.run([VERIFY, "--receipt", receipt3, circuit_path("trace"), "--image-id", info["image_id"], "--image-circuit", circuit_path("image")] + bind[2:],
+                         capture_output=True, text=True, timeout=600)
+    report = json.loads(out.stdout)
+    assert out.returncode == 0 and report["accepted"] is True and "image proof" in report["program_bound"] and report["commitment"] == r0.journal_commitment(want).decode()
+    out = subprocess.run([VERIFY, "--receipt", receipt3, circuit_path("trace"), "--image-id", other, "--image-circuit", circuit_path("image")] + bind[2:],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 1 and "image id" in json.loads(out.stdout)["reason"]
+    out = subprocess.run([VERIFY, "--receipt", receipt, circuit_path("trace"), "--image-id", info["image_id"], "--image-circuit", circuit_path("image")] + bind[2:],
+                         capture_output=True, text=True, timeout=600)  # (the first receipt carries no image proof)
+    assert out.returncode == 1 and "image proof" in json.loads(out.stdout)["reason"]
