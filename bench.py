@@ -514,9 +514,13 @@ def session_bench(args, env, entry, torch, local_rank, numa):
     blob = np.fromfile(entry.circuit_blob_path("trace"), dtype=np.uint32)
     n_ses = 1 if args.sharded_session else max(1, args.contexts or 2)
     lanes = []
+    image_blob = np.fromfile(entry.circuit_blob_path("image"), dtype=np.uint32)
     for k in range(n_ses):
         hal = r0.Hal(local_rank)
         lanes.append(dict(hal=hal, gc=hal.load_circuit(blob, entry.code_object_path("trace")), segments=0, walls=[], receipt=None))
+        if not args.sharded_session:  # every receipt carries its image proof (inside the timed region): `receipt.verify(image_id)` then needs no ELF
+            lanes[-1]["ic"] = hal.load_circuit(image_blob, entry.code_object_path("image"))
+            hal.set_image_circuit(lanes[-1]["ic"])
 
     def one_session(lane):
         t0 = time.perf_counter()
@@ -576,6 +580,9 @@ def session_bench(args, env, entry, torch, local_rank, numa):
                 roots[size] = cc.root()
                 cc.free()
         verified = all(ln["receipt"].verify(blob, roots, None, elf=image)[:2] == (0, "ok") for ln in lanes if ln["receipt"] is not None)
+        # ... and the way the reference's verifier calls it: the image id's 32 bytes, no ELF (the receipt's image proof stands for the image)
+        image_id = r0.compute_image_id(image)
+        by_id = None if args.sharded_session else all(ln["receipt"].verify_image(blob, roots, image_blob, image_id)[:2] == (0, "ok") for ln in lanes if ln["receipt"] is not None)
         n_seg = len(seals)
         # ---- per-kernel accounting: one session alone on one context with ONE prover lane (so that every launch is on the context
         # whose HIP events are read), outside the timed region
@@ -624,13 +631,14 @@ def session_bench(args, env, entry, torch, local_rank, numa):
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.sharded_session else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "configs[1]: the camt53 guest at po2 = 20 -- prove(env, elf) end to end: %s; executed on a host thread (%d cycles, %d segments of at most 2^20 rows), rows "
-                                   "expanded on the device, proved with circuits/trace.r0c W=(%d accum, %d code, %d data) in two phases under the session challenge; %s; every receipt "
-                                   "verified with the ELF after the timed region.  data is 'synthetic' in the contract's sense only: the guest is hand-assembled (the reference ships no ELF) and its "
+                                   "expanded on the device, proved with circuits/trace.r0c W=(%d accum, %d code, %d data) in two phases under the session challenge, and the image proof of circuits/image.r0c attached (inside the timed region); %s; every receipt "
+                                   "verified with the ELF, and with the image id alone, after the timed region.  data is 'synthetic' in the contract's sense only: the guest is hand-assembled (the reference ships no ELF) and its "
                                    "input is the reference's own EBICS fixture" % (what, lanes[0]["cycles"], n_seg, gs[0], gs[1], gs[2],
                                    "ONE session sharded over all ranks (records all-reduced between the phases)" if args.sharded_session else "%d session(s) in flight per GPU, each with an executor thread and two prover lanes; a step = every session context proves one session" % n_ses),
                        "po2": po2, "columns": cols, "segments_per_session": n_seg, "sessions_per_step_per_gpu": n_ses, "seal_words": int(seals[0][1].size),
                        "parallelism": ("one session over %d GPUs" if args.sharded_session else "independent sessions x%d GPUs") % env.world, "host_threads": "rank 0: " + numa},
             "receipts_verified_with_the_elf": bool(verified),
+            "receipts_verified_with_the_image_id_alone": by_id,
             "journal_is_the_reference_receipt_fixtures": receipt.journal == want_journal,
             "journal": r0.journal_commitment(receipt.journal).decode()[:80] + " ...",
             "per_session_wall_s": {"median": round(timed_walls[len(timed_walls) // 2], 4), "min": round(timed_walls[0], 4), "max": round(timed_walls[-1], 4), "sessions_timed": len(timed_walls)},
@@ -649,6 +657,9 @@ def session_bench(args, env, entry, torch, local_rank, numa):
         emit_result(line)
     for ln in lanes:
         ln["receipt"] = None
+        if ln.get("ic") is not None:
+            ln["hal"].set_image_circuit(None)
+            ln["ic"].free()
         ln["gc"].free()
         ln["hal"].close()
     env.close()
