@@ -96,19 +96,37 @@ const char* r0h_prove_image(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* e
   R0H_REQUIRE(ctx && c && elf && challenge && seal_words_out, "r0h_prove_image: NULL argument");
   R0H_REQUIRE(is_image_circuit(*c), "r0h_prove_image: the circuit is not the image circuit (circuits/image.r0c) this library was built for");
   for (int i = 0; i < 16; i++) R0H_REQUIRE(challenge[i] < P, "r0h_prove_image: challenge word %d is not a canonical field word", i);
-  uint32_t po2 = 0;
-  R0H_TRY(r0h_image_po2(elf, elf_len, &po2));
+  std::vector<std::pair<uint32_t, uint32_t>> image;
+  uint32_t entry, po2 = 9;
+  uint8_t id[32];
+  R0H_TRY(elf_image(elf, elf_len, image, &entry, id));
+  std::vector<uint32_t> stream, global(R0H_IMAGE_GLOBALS, 0);
+  image_stream(image, stream);
+  const size_t n_blocks = stream.size() / 16, rows = n_blocks * R0H_SPONGE_PERIOD;
+  while (((size_t)1 << po2) <= rows) po2++;
+  R0H_REQUIRE(po2 <= R0H_MAX_PO2, "r0h_prove_image: an image of %zu words does not fit a trace", image.size());
   const size_t n = (size_t)1 << po2;
-  std::vector<uint32_t> host((size_t)R0H_IMAGE_COLUMNS * n), global(R0H_IMAGE_GLOBALS, 0);
-  R0H_TRY(r0h_image_witness(elf, elf_len, po2, host.data(), global.data()));
+  {
+    std::unique_ptr<P2Consts> k(new P2Consts);
+    p2_default_host(*k);
+    p2_hash_elems_host(*k, stream.data(), stream.size(), global.data());
+  }
   memcpy(&global[R0H_IMAGE_GAMMA], challenge, 64);
   r0h_buf *code = nullptr, *data = nullptr, *scratch = nullptr;
   struct Free { r0h_buf*& b; ~Free() { if (b) r0h_buf_free(b); } } f0{code}, f1{data}, f2{scratch};
+  const size_t data_bytes = (size_t)R0H_IMAGE_COLUMNS * n * 4;
   R0H_TRY(buf_alloc_pooled(ctx, (size_t)c->group_size[R0H_GROUP_CODE] * n * 4, &code));
-  R0H_TRY(buf_alloc_pooled(ctx, host.size() * 4, &data));
-  R0H_TRY(buf_alloc_pooled(ctx, host.size() * 4, &scratch));
+  R0H_TRY(buf_alloc_pooled(ctx, data_bytes, &data));
+  R0H_TRY(buf_alloc_pooled(ctx, data_bytes, &scratch));
   R0H_TRY(r0h_witgen(ctx, c, po2, 0, code, scratch, nullptr));  // (the CODE columns; the DATA it fills beside them is not the image's)
-  R0H_TRY(r0h_buf_h2d(ctx, data, 0, host.data(), host.size() * 4));
+  // the witness: the sponge's rows over the blocks (only the rows in use travel), the flags on the rows that absorb a block
+  R0H_TRY(sponge_plant(ctx, c, po2, stream.data(), stream.size(), data));
+  std::vector<uint32_t> flags(4 * n_blocks, 0u);  // [flag][block]
+  for (size_t k = 0; k < image.size(); k++) flags[(k % 4) * n_blocks + k / 4] = ONE;
+  uint32_t* first_flag = (uint32_t*)data->ptr + (size_t)R0H_SPONGE_DATA_COLUMNS * n;
+  R0H_TRY_HIP(hipMemsetAsync(first_flag, 0, 4 * n * 4, ctx->stream));
+  for (size_t j = 0; j < 4; j++)  // one word every thirty rows
+    R0H_TRY_HIP(hipMemcpy2DAsync(first_flag + j * n, (size_t)R0H_SPONGE_PERIOD * 4, flags.data() + j * n_blocks, 4, 4, n_blocks, hipMemcpyHostToDevice, ctx->stream));
   R0H_TRY(r0h_logup_totals(ctx, c, po2, code, data, global.data()));
   return r0h_prove_segment(ctx, c, po2, code, data, global.data(), seal_out, seal_capacity_words, seal_words_out);
   R0H_GUARD_END

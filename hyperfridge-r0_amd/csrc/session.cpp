@@ -548,6 +548,15 @@ const char* r0h_session_finish(r0h_session* s, const uint32_t* all_records, size
     const char* first_err = nullptr;
     auto lane = [&](r0h_ctx* lctx) {
       std::vector<uint32_t> seal((size_t)1 << 20), mix(c->n_mix);
+      if (lctx == s->ctx && !s->elf.empty() && s->ctx->image_circuit) {
+        // the image's side of the balance, proved (`receipt.verify(image_id)` then needs no ELF): first thing on the first lane, beside
+        // the other lanes' segments -- all it waits for is the challenge
+        size_t words = 0;
+        const char* err = r0h_prove_image(s->ctx, s->ctx->image_circuit, s->elf.data(), s->elf.size(), challenge, seal.data(), seal.size(), &words);
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (err) { if (!first_err) first_err = err; else r0h_free_error(err); return; }
+        image_seal.assign(seal.begin(), seal.begin() + words);
+      }
       for (Pending& p : s->pending) {
         if (p.lctx != lctx || p.done) continue;
         {
@@ -595,12 +604,6 @@ const char* r0h_session_finish(r0h_session* s, const uint32_t* all_records, size
     guarded(s->lane_ctx[0]);
     for (std::thread& t : workers) t.join();
     if (first_err) return first_err;
-    if (!s->elf.empty() && s->ctx->image_circuit) {  // the image's side of the balance, proved: `receipt.verify(image_id)` then needs no ELF
-      image_seal.resize((size_t)1 << 18);
-      size_t words = 0;
-      R0H_TRY(r0h_prove_image(s->ctx, s->ctx->image_circuit, s->elf.data(), s->elf.size(), challenge, image_seal.data(), image_seal.size(), &words));
-      image_seal.resize(words);
-    }
   }
   r0h_receipt* rc = nullptr;
   R0H_TRY(r0h_receipt_new(R0H_RECEIPT_COMPOSITE, nullptr, 0, &rc));

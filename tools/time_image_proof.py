@@ -1,0 +1,14 @@
+import sys, time; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+import numpy as np
+import __graft_entry__ as e
+import hyperfridge_r0_amd as r0
+import guest_camt53
+elf, stream, what = guest_camt53.elf_and_input()
+hal = r0.Hal(0)
+ic = hal.load_circuit(np.fromfile(e.circuit_blob_path("image"), dtype=np.uint32), e.code_object_path("image"))
+ch = np.arange(16, dtype=np.uint32) + 5
+for i in range(6):
+    t0 = time.perf_counter(); s = hal.prove_image(ic, elf, ch); dt = time.perf_counter() - t0
+    print("prove_image %.2f ms, %d words, po2 %d" % (1e3 * dt, s.size, r0.image_po2(elf)), flush=True)
+    print("  phases:", ", ".join("%s=%.2f" % p for p in hal.last_profile()))
+t0 = time.perf_counter(); r0.image_witness(elf); print("host witness %.2f ms" % (1e3 * (time.perf_counter() - t0)))
