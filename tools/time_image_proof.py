@@ -1,4 +1,12 @@
-import sys, time; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+#!/usr/bin/env python3
+"""Time of one image proof (r0h_prove_image) for the camt53 guest on the GPU box, with the prover's phases, and of the host-side witness."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import __graft_entry__ as e
 import hyperfridge_r0_amd as r0
