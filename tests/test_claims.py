@@ -200,9 +200,18 @@ def test_the_receipts_of_several_ranks_merge_into_the_sessions_receipt():
         r0.Receipt.merge([a, r0.Receipt.new(journal + b"\0\0\0\0", seals[1::2], claims[1::2], indices=[1, 3, 5])])
     with pytest.raises(r0.R0HipError, match="not a composite"):
         r0.Receipt.merge([a, r0.Receipt.new(journal)])
+    # the session's image proof travels with whichever part carries it (rank 0 makes it), through JSON too; two different ones are refused
+    proof = np.arange(100, dtype=np.uint32) * 7
+    b.image_proof = proof
+    merged = r0.Receipt.merge([a, b])
+    assert np.array_equal(merged.image_proof, proof) and np.array_equal(r0.Receipt.parse(merged.to_json()).image_proof, proof)
+    assert r0.Receipt.merge([a, r0.Receipt.new(journal, seals[1::2], claims[1::2], indices=[1, 3, 5])]).image_proof is None
+    a.image_proof = proof + 1
+    with pytest.raises(r0.R0HipError, match="another image proof"):
+        r0.Receipt.merge([a, b])
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "recursion", "trace", "bench"])
+@pytest.mark.parametrize("name", ["tiny", "small", "recursion", "trace", "bench", "image"])
 def test_the_verifier_can_derive_a_circuits_control_roots_itself(orc, name):
     """r0h_control_root_host: the CODE columns of the circuit's column program committed on the host -- interpolate, shift by 3,
     evaluate on the 4N coset, hash rows, fold -- give the control root the oracle computes from the CODE group it generates (and, on
