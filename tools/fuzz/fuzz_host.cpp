@@ -29,7 +29,7 @@ static bool good(const char* err) { drop(err); return err == nullptr; }
 
 struct Fixtures {
   std::vector<uint8_t> xml, pub_bank, pub_client, pub_witness, client_pem, witness_pem, tx_raw, witness_hex, circuit, seal_npy;
-  std::vector<uint32_t> blob, seal;
+  std::vector<uint32_t> blob, seal, image_blob;
   Fixtures() {
     const char* env = getenv("R0H_FUZZ_ROOT");
     const std::string root = env ? env : ".";
@@ -39,6 +39,10 @@ struct Fixtures {
     tx_raw = slurp(g + "test.xml-TransactionKeyDecrypt.bin"); witness_hex = slurp(g + "test.xml-Witness.hex");
     circuit = slurp(root + "/circuits/tiny.r0c");
     blob.assign((const uint32_t*)circuit.data(), (const uint32_t*)circuit.data() + circuit.size() / 4);
+    {
+      const std::vector<uint8_t> ic = slurp(root + "/circuits/image.r0c");
+      image_blob.assign((const uint32_t*)ic.data(), (const uint32_t*)ic.data() + ic.size() / 4);
+    }
     seal_npy = slurp(root + "/tests/golden/seal_tiny_po2_9_seed_1.npy");  // .npy v1: magic, version, u16 header length, header, then the words
     if (seal_npy.size() < 10) abort();
     const size_t off = 10 + (seal_npy[8] | (size_t)seal_npy[9] << 8);
@@ -140,6 +144,13 @@ extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
       if (!good(r0h_vm_new(&vm))) break;
       if (good(r0h_vm_load_elf(vm, d, n))) run_vm(vm);
       { uint8_t id[32]; drop(r0h_compute_image_id(d, n, id)); }
+      {  // the image circuit's witness of whatever this file loads as an image
+        uint32_t po2 = 0;
+        if (good(r0h_image_po2(d, n, &po2)) && po2 <= 14) {
+          std::vector<uint32_t> cols((size_t)R0H_IMAGE_COLUMNS << po2), glob(R0H_IMAGE_GLOBALS);
+          drop(r0h_image_witness(d, n, po2, cols.data(), glob.data()));
+        }
+      }
       r0h_vm_free(vm);
       break;
     }
@@ -166,6 +177,9 @@ extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
         uint32_t roots[9] = {9, 1, 2, 3, 4, 5, 6, 7, 8};
         uint8_t image[32] = {0};
         drop(r0h_receipt_verify(rc, fx().blob.data(), fx().blob.size(), roots, 1, image, &verdict, &seg, &sv));
+        if (!fx().image_blob.empty())  // ... and with whatever it carries as an image proof
+          drop(r0h_receipt_verify_image(rc, fx().blob.data(), fx().blob.size(), roots, 1, fx().image_blob.data(), fx().image_blob.size(), nullptr, image, &verdict, &seg, &sv));
+        { const uint32_t* ip; size_t ipn; drop(r0h_receipt_image_proof(rc, &ip, &ipn)); }
         {  // a receipt merged with itself (segments twice: refused for a composite one) and on its own (complete or not)
           const r0h_receipt* twice[2] = {rc, rc};
           r0h_receipt* merged = nullptr;

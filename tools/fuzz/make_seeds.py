@@ -46,6 +46,8 @@ def main():
         import hyperfridge_r0_amd as r0
         rc = r0.Receipt.new(b'{"iban":"CH43"}', [seal], None)
         put("receipt_composite", 5, rc.to_json().encode() if isinstance(rc.to_json(), str) else rc.to_json())
+        rc.image_proof = seal[:64]  # (the optional image proof of a trace-circuit session)
+        put("receipt_composite_image_proof", 5, rc.to_json().encode())
     except Exception as e:  # noqa: BLE001
         print("no composite receipt seed:", e)
     put("seal", 6, seal.tobytes())

@@ -8,7 +8,7 @@ SECS=${1:-120}; WORK=${2:-/tmp/r0h_fuzz}; JOBS=${3:-1}
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 mkdir -p "$WORK/obj" "$WORK/corpus"
 FLAGS="-O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined,fuzzer-no-link -fno-sanitize-recover=undefined"
-for f in ebics rv32im receipt claim verify ctx circuit; do
+for f in ebics rv32im receipt claim verify ctx circuit image; do
   src=$ROOT/hyperfridge-r0_amd/csrc/$f.cpp; [ -f "$src" ] || src=$ROOT/hyperfridge-r0_amd/csrc/$f.hip  # host-only units are .cpp, circuit is .hip
   if [ ! -f "$WORK/obj/$f.o" ] || [ "$src" -nt "$WORK/obj/$f.o" ]; then
     # circuit.hip (the blob parser and the code generator live there) carries kernels: its host stubs need the code object, so it
@@ -22,12 +22,15 @@ for f in ebics rv32im receipt claim verify ctx circuit; do
 done
 # what these objects reference from the kernel translation units that are not part of this build (never reached without a GPU)
 cat > "$WORK/stubs.cpp" <<'STUB'
+#include <stddef.h>
 #include <stdint.h>
 struct r0h_ctx; struct r0h_buf;
 namespace r0h { const char* ntt_init_device() { return nullptr; } void session_rows_free(r0h_ctx*) {} }  // (session.cpp needs a device)
 struct r0h_circuit;
 namespace r0h { const char* logup_accum(r0h_ctx*, const r0h_circuit*, uint32_t, const r0h_buf*, const r0h_buf*, const uint32_t*, const uint32_t*, r0h_buf*) { __builtin_trap(); } }
 extern "C" const char* r0h_prefix_products(r0h_ctx*, r0h_buf*, uint32_t) { __builtin_trap(); }
+extern "C" const char* r0h_logup_totals(r0h_ctx*, const r0h_circuit*, uint32_t, const r0h_buf*, const r0h_buf*, uint32_t*) { __builtin_trap(); }
+extern "C" const char* r0h_prove_segment(r0h_ctx*, const r0h_circuit*, uint32_t, const r0h_buf*, const r0h_buf*, const uint32_t*, uint32_t*, size_t, size_t*) { __builtin_trap(); }
 STUB
 $CLANG $FLAGS -c "$WORK/stubs.cpp" -o "$WORK/obj/stubs.o"
 # the harness itself carries ASan only: with UBSan on this file too, ASan's start-up check trips over two merged string literals
