@@ -2,7 +2,9 @@
 is the driver's to run; the code path per rank is the one exercised here; configs[1] is also bench.py's default):
   configs[0]  one 2^18-row segment, the size a CPU prover still runs; configs[1] one 2^20-row segment -> device seal == CPU port's seal, word for word
   configs[2]  the same trace as ~64 segments at po2 = 20, sharded segment-parallel          -> bench.py --segments 64
-  configs[3]  a batch of 32 independent receipts, throughput mode                            -> r0h_prove --receipts 32 --segments 2
+  configs[3]  a batch of 32 independent receipts, throughput mode                            -> r0h_prove --receipts 32 --segments 2 (synthetic circuit)
+                                                                                               and r0h_prove --elf guest_camt53.elf --receipts 32 --contexts 2 (the real workload:
+                                                                                               every receipt verified with the ELF and with the image id alone)
   configs[4]  lift + join of segment receipts up a binary tree, ranks exchanging seals       -> tools/bench_recursion.py --gpus 2 (gloo, one GPU)
 Every seal that leaves these runs is checked by the CPU oracle's verifier (bound to the control root), not by the product's."""
 import glob
@@ -106,6 +108,42 @@ def test_config3_batch_of_32_receipts_at_full_size(tmp_path, bench_circuit):
         assert rc.to_json() == text
         assert rc.verify(bench_circuit["blob"], roots, r0.image_id_from_hex(ids["image_ids"][r]))[:2] == (0, "ok"), path
         assert rc.verify(bench_circuit["blob"], roots, r0.image_id_from_hex(ids["image_ids"][(r + 1) % 32]))[0] == 8  # another receipt's image id
+
+
+def test_config3_batch_of_32_receipts_of_the_camt53_guest(tmp_path):
+    """BASELINE.json configs[3] on the REAL workload (round 3's verdict, missing #3): 32 independent sessions of the hyperfridge guest on the
+    reference's fixture through the compiled host, two in flight (host/src/main.rs:389-423 looped by data/watchdog.sh:46-109), one
+    receipt file each; the host verifies every receipt with the ELF and with the image id alone; here: every file is the same receipt
+    (the same session), its journal is the reference's committed receipt's, and a sample is verified again through the library."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import guest_camt53
+    elf_path = os.path.join(ROOT, "circuits", "guest_camt53.elf")
+    elf, stream, _ = guest_camt53.elf_and_input(form=1)
+    words = tmp_path / "env.bin"
+    np.array(stream, dtype=np.uint32).tofile(words)
+    rdir = tmp_path / "receipts"
+    rdir.mkdir()
+    cli = os.path.join(ROOT, "hyperfridge-r0_amd", "r0h_prove")
+    out = subprocess.run([cli, circuit_path("trace"), "--code-object", entry.code_object_path("trace"), "--elf", elf_path, "--input", str(words), "--po2", str(PO2),
+                          "--receipts", "32", "--contexts", "2", "--receipt-dir", str(rdir), "--image-circuit", circuit_path("image"),
+                          "--image-code-object", entry.code_object_path("image")], capture_output=True, text=True, timeout=1100)
+    assert out.returncode == 0, out.stderr[-3000:]
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["receipts"] == 32 and info["contexts"] == 2 and info["receipts_verified_with_the_elf"] == 32 and info["receipts_verified_with_the_image_id_alone"] == 32
+    assert info["segments"] >= 11 and info["segments_per_s"] > 20 and info["image_id"] == r0.image_id_to_hex(r0.compute_image_id(elf))
+    files = sorted(glob.glob(str(rdir / "receipt_*.json")))
+    assert len(files) == 32
+    first = open(files[0]).read()
+    assert all(open(f).read() == first for f in files[1:])  # the same session proved 32 times: the same receipt
+    want = bytes(json.load(open(os.path.join(ROOT, "tests", "golden", "reference_receipt_6bb95807_latest.json")))["journal"]["bytes"])
+    rc = r0.Receipt.parse(first)
+    assert rc.journal == want and len(rc.seals()) == info["segments"] and rc.image_proof is not None
+    blob, iblob = np.fromfile(circuit_path("trace"), dtype=np.uint32), np.fromfile(circuit_path("image"), dtype=np.uint32)
+    roots = {}
+    for root in info["control_roots"]:
+        size, ws = root.split(":")
+        roots[int(size)] = np.array([int(w) for w in ws.split(",")], dtype=np.uint32)
+    assert rc.verify(blob, roots, None, elf=elf)[:2] == (0, "ok") and rc.verify_image(blob, roots, iblob, r0.compute_image_id(elf))[:2] == (0, "ok")
 
 
 def test_config4_lift_join_tree_of_8_leaves_over_two_ranks(tmp_path, orc):
