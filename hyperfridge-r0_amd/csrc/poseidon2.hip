@@ -10,11 +10,7 @@
 
 namespace r0h {
 
-#ifndef R0H_P2_ATTR
-#define R0H_P2_ATTR  // A/B hook: e.g. -DR0H_P2_ATTR='__attribute__((amdgpu_waves_per_eu(5,5)))' (profiles/r04/p2_occupancy_ab.md)
-#endif
-
-__global__ __launch_bounds__(256) R0H_P2_ATTR void hash_rows_kernel(uint32_t* __restrict__ digests, const uint32_t* __restrict__ matrix,
+__global__ __launch_bounds__(256) void hash_rows_kernel(uint32_t* __restrict__ digests, const uint32_t* __restrict__ matrix,
                                                          uint32_t rows, uint32_t cols, const P2Consts* __restrict__ k) {
   uint32_t row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
@@ -40,7 +36,7 @@ __global__ __launch_bounds__(256) R0H_P2_ATTR void hash_rows_kernel(uint32_t* __
 }
 
 // nodes[i] = H(nodes[2i] || nodes[2i+1]), output_size <= i < 2*output_size
-__global__ __launch_bounds__(256) R0H_P2_ATTR void hash_fold_kernel(uint32_t* __restrict__ nodes, uint32_t output_size,
+__global__ __launch_bounds__(256) void hash_fold_kernel(uint32_t* __restrict__ nodes, uint32_t output_size,
                                                          const P2Consts* __restrict__ k) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= output_size) return;
