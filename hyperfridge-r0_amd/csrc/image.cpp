@@ -96,6 +96,7 @@ const char* r0h_prove_image(r0h_ctx* ctx, const r0h_circuit* c, const uint8_t* e
   R0H_REQUIRE(ctx && c && elf && challenge && seal_words_out, "r0h_prove_image: NULL argument");
   R0H_REQUIRE(is_image_circuit(*c), "r0h_prove_image: the circuit is not the image circuit (circuits/image.r0c) this library was built for");
   for (int i = 0; i < 16; i++) R0H_REQUIRE(challenge[i] < P, "r0h_prove_image: challenge word %d is not a canonical field word", i);
+  R0H_TRY_HIP(hipSetDevice(ctx->device));
   std::vector<std::pair<uint32_t, uint32_t>> image;
   uint32_t entry, po2 = 9;
   uint8_t id[32];
