@@ -685,6 +685,12 @@ def test_the_image_proof_lets_the_image_id_alone_verify_a_session(orc, prover):
     cols, digest = ic.witness(_image(base, prog), 1 << po2)
     assert np.array_equal(np.array([[orc.enc(v) for v in c] for c in cols], dtype=np.uint32), data) and [orc.enc(v) for v in digest] == glob[:8].tolist()
     assert bytes(vm.segments()[0].pre.merkle_root) == b"".join(int(w).to_bytes(4, "little") for w in digest)
+    for count in (1, 3, 4, 5, 8, 9):  # block boundaries: a short last block, a full one, one word over
+        small = elf_of(prog[:count], base)
+        d2, g2 = r0.image_witness(small, 9)
+        c2, dg2 = ic.witness(_image(base, prog[:count]), 1 << 9)
+        assert np.array_equal(np.array([[orc.enc(v) for v in col] for col in c2], dtype=np.uint32), d2) and [orc.enc(v) for v in dg2] == g2[:8].tolist(), count
+        assert r0.image_po2(small) == 9
     good = image_seal(elf)
     assert oi.verify(good) == (0, "ok")
     receipt.image_proof = good
