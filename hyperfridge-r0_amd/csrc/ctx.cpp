@@ -97,18 +97,22 @@ void p2_mix_host(const P2Consts& k, uint32_t* c) {
 // words: st[24] the state after the row's step, aux[24] the cubes (x + rc)^3 of the lanes the round's S-box touches, in[16] the words
 // absorbed on a permutation's first row, act = 1.  Only rows [0, *rows_used) are written; the caller clears the rest.
 void p2_sponge_rows_host(const P2Consts& k, const uint32_t* words, size_t n_words, uint32_t* cols, size_t stride, size_t* rows_used) {
+  constexpr int ROWS = 1 + 2 * P2_HALF_FULL + P2_PARTIAL;  // one permutation: the absorbing row, then a row per round
   const size_t n_perm = n_words ? (n_words + P2_RATE - 1) / P2_RATE : 1;
   uint32_t st[P2_CELLS] = {0};
-  size_t row = 0;
-  auto put_state = [&] {
-    for (int j = 0; j < P2_CELLS; j++) cols[(size_t)j * stride + row] = st[j];
-    cols[(size_t)64 * stride + row] = ONE;
-  };
+  // a permutation's rows are made in a small block [column][row of the permutation] and go out column by column: 65 runs of 30
+  // consecutive words instead of 1,950 single words a stride apart
+  uint32_t blk[65][ROWS];
   for (size_t q = 0; q < n_perm; q++) {
-    for (int j = 0; j < P2_CELLS; j++) cols[(size_t)(24 + j) * stride + row] = 0;
+    memset(blk, 0, sizeof blk);
+    int row = 0;
+    auto put_state = [&] {
+      for (int j = 0; j < P2_CELLS; j++) blk[j][row] = st[j];
+      blk[64][row] = ONE;
+    };
     for (size_t j = 0; j < P2_RATE; j++) {
       st[j] = q * P2_RATE + j < n_words ? words[q * P2_RATE + j] : 0u;
-      cols[(48 + j) * stride + row] = st[j];
+      blk[48 + j][0] = st[j];
     }
     m_ext_host(st);
     put_state();
@@ -116,14 +120,10 @@ void p2_sponge_rows_host(const P2Consts& k, const uint32_t* words, size_t n_word
     for (int r = 0; r < 2 * P2_HALF_FULL + P2_PARTIAL; r++, row++) {
       const bool full = r < P2_HALF_FULL || r >= P2_HALF_FULL + P2_PARTIAL;
       const uint32_t* rc = full ? k.rc_full[r < P2_HALF_FULL ? r : r - P2_PARTIAL] : &k.rc_partial[r - P2_HALF_FULL];
-      for (int j = 0; j < P2_CELLS; j++) {
-        uint32_t cube = 0;
-        if (full || j == 0) {
-          const uint32_t t = add(st[j], rc[j]);
-          cube = mul(mul(t, t), t);
-          st[j] = mul(mul(cube, cube), t);
-        }
-        cols[(size_t)(24 + j) * stride + row] = cube;
+      for (int j = 0; j < (full ? P2_CELLS : 1); j++) {
+        const uint32_t t = add(st[j], rc[j]), cube = mul(mul(t, t), t);
+        st[j] = mul(mul(cube, cube), t);
+        blk[24 + j][row] = cube;
       }
       if (full) m_ext_host(st);
       else {
@@ -131,11 +131,11 @@ void p2_sponge_rows_host(const P2Consts& k, const uint32_t* words, size_t n_word
         for (int i = 0; i < P2_CELLS; i++) sum = add(sum, st[i]);
         for (int i = 0; i < P2_CELLS; i++) st[i] = add(sum, mul(k.diag[i], st[i]));
       }
-      for (size_t j = 0; j < P2_RATE; j++) cols[(48 + j) * stride + row] = 0;
       put_state();
     }
+    for (int c = 0; c < 65; c++) memcpy(cols + (size_t)c * stride + q * ROWS, blk[c], sizeof blk[c]);
   }
-  *rows_used = row;
+  *rows_used = n_perm * ROWS;
 }
 void p2_hash_elems_host(const P2Consts& k, const uint32_t* elems, size_t n, uint32_t digest[8]) {
   uint32_t st[P2_CELLS] = {0};
