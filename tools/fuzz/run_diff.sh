@@ -23,7 +23,9 @@ done
 cat > "$WORK/stubs.cpp" <<'STUB'
 #include <stdint.h>
 struct r0h_ctx; struct r0h_buf;
-namespace r0h { const char* ntt_init_device() { return nullptr; } }
+struct r0h_circuit;
+namespace r0h { const char* ntt_init_device() { return nullptr; } void session_rows_free(r0h_ctx*) {}
+const char* logup_accum(r0h_ctx*, const r0h_circuit*, uint32_t, const r0h_buf*, const r0h_buf*, const uint32_t*, const uint32_t*, r0h_buf*) { __builtin_trap(); } }
 extern "C" const char* r0h_prefix_products(r0h_ctx*, r0h_buf*, uint32_t) { __builtin_trap(); }
 STUB
 $CLANG $FLAGS -c "$WORK/stubs.cpp" -o "$WORK/obj/stubs.o"
